@@ -1,0 +1,91 @@
+"""ctypes binding of libdanhip.so (the C ABI declared in include/danhip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdanhip.so")
+
+F32, BF16 = 0, 1
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride")]
+
+
+P = ctypes.c_void_p
+I32 = ctypes.c_int32
+I64 = ctypes.c_int64
+FL = ctypes.c_float
+DESC = ctypes.POINTER(ConvDesc)
+
+# name -> argtypes (every function returns int status except the two noted below)
+SIGNATURES = {
+    "danhip_conv_packed_dims": [DESC, ctypes.c_int, ctypes.POINTER(I64), ctypes.POINTER(I64)],
+    "danhip_pack_conv_weight": [DESC, P, I32, P, P, P],
+    "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],
+    "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
+    "danhip_conv2d_bwd_weight": [DESC, P, P, P, I32, P],
+    "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
+    "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
+    "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, P],
+    "danhip_l2norm_fwd": [P, P, P, I64, I32, P],
+    "danhip_l2norm_bwd": [P, P, P, P, P, I64, I32, ctypes.c_int, P],
+    "danhip_preprocess_u8": [P, P, I64, P],
+    "danhip_cast_pad_f32_to_bf16": [P, P, I64, I32, I32, P],
+    "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
+    "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
+    "danhip_hard_neg_select": [P, P, P, P, P, P, I32, I32, FL, ctypes.c_int, P],
+    "danhip_detection_loss_fwd": [P, P, P, P, P, P, P, P, I32, I32, P],
+    "danhip_detection_loss_bwd": [P, P, P, P, P, P, P, FL, FL, I32, I32, P],
+    "danhip_sgd_momentum_flat": [P, P, P, P, P, P, I32, I64, FL, FL, FL, P, P],
+}
+
+_lib = None
+
+
+class DanhipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libdanhip.so; raises loudly when it is missing (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise DanhipError("libdanhip.so not found at %s — run `python -m dan_amd.build` (there is no fallback path)" % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        L.danhip_last_error.restype = ctypes.c_char_p
+        L.danhip_last_error.argtypes = []
+        L.danhip_version.restype = ctypes.c_int
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the export is missing
+            fn.restype = ctypes.c_int
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DanhipError("%s failed (%d): %s" % (what, rc, lib().danhip_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "danhip needs contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,17 @@
+// Error plumbing of the C ABI: thread-local message, never throws.
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/danhip.h"
+
+static thread_local char g_err[512] = "";
+
+void danhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* danhip_last_error(void) { return g_err; }
+extern "C" int danhip_version(void) { return 1; }

@@ -1,0 +1,455 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (bf16 in, fp32 accumulate), NHWC.
+//
+// Replaces tf.layers.conv2d(padding='same') on the reference's hot path (net/sfd_net.py:81-89 and every conv in
+// net/*.py) and, run on dY with tap-flipped weights, its data gradient.
+//
+// GEMM view:  out[m, co] = sum_k  A[m, k] * Wp[co, k],   m = (n, ho, wo),  k = (tap, c)
+//   A[m,k] is gathered on the fly from the NHWC input (im2col never materialised): one 16-byte LDS-DMA
+//   (global_load_lds_dwordx4) per lane moves 8 consecutive channels of one (pixel, tap); padding and
+//   out-of-range rows read a page of zeros.  Both operands are K-contiguous, so both tiles are
+//   [rows][64 bf16] = 128-byte rows in LDS, XOR-swizzled at 16-byte granularity (chunk ^= row & 7; applied on
+//   the SOURCE address because the LDS-DMA destination is lane-linear) so every ds_read_b128 is conflict-free.
+//   MFMA: v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand and the PIXEL fragment as B, so
+//   each lane ends up with 4 consecutive output channels of one pixel (8/16-byte stores into NHWC).
+//
+// Pipeline: two LDS stages; tile k+1's DMA is issued before tile k's MFMAs (one barrier per K tile);
+// two workgroups per CU overlap each other's barrier stalls.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  const bf16_t* mask;
+  const bf16_t* resid;
+  void* y;
+  int N, H, W, C;
+  int Ho, Wo, Co;
+  int kh, kw, stride, pad_t, pad_l;
+  int M, Kpad, ktiles, taps, cpt;
+  FastDiv div_wo, div_howo, div_c, div_kw;
+  int relu, out_f32, accumulate;
+};
+
+template <int BM, int BN, int WN_WAVES, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int RA = BM / 32;                 // LDS-DMA rounds for the pixel tile (each round: 4 waves x 8 rows)
+  constexpr int RB = (BN + 31) / 32;          // rounds for the weight tile
+  constexpr int STAGE = (BM + BN) * 128;      // bytes per pipeline stage
+  constexpr int WM_WAVES = 4 / WN_WAVES;
+  constexpr int TP = BM / WM_WAVES;           // pixels per wave
+  constexpr int TC = BN / WN_WAVES;           // output channels per wave
+  constexpr int NPT = TP / 16, NCT = TC / 16;
+  static_assert(TP % 16 == 0 && TC % 16 == 0, "wave tile must be MFMA-tile aligned");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_WAVES, wn = wave % WN_WAVES;
+
+  // ---- tile coordinates: blockIdx.x walks pixel tiles (XCD-friendly: neighbouring pixel tiles share halo rows),
+  //      blockIdx.y walks output-channel tiles.
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- per-lane staging geometry (constant over the K loop)
+  const int srow = lane >> 3;                          // row inside an 8-row DMA piece
+  const int schunk = (lane & 7) ^ srow;                // source 16-byte chunk (XOR swizzle on the source side)
+  int rn[RA], rh[RA], rw[RA];                          // per staged pixel row: image base offset, h0, w0
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + j * 32 + wave * 8 + srow;
+    if (m < a.M) {
+      const unsigned n = fdiv((unsigned)m, a.div_howo);
+      const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+      const unsigned ho = fdiv(rem, a.div_wo);
+      const unsigned wo = rem - ho * (unsigned)a.Wo;
+      rn[j] = (int)n * a.H * a.W;                      // pixel index of (n,0,0)
+      rh[j] = (int)ho * a.stride - a.pad_t;
+      rw[j] = (int)wo * a.stride - a.pad_l;
+    } else {
+      rn[j] = 0; rh[j] = -(1 << 20); rw[j] = 0;        // never valid
+    }
+  }
+  const bf16_t* wrow[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    int r = j * 32 + wave * 8 + srow;
+    if (BN < 32 && r >= BN) r = 0;                     // (those waves skip the DMA below)
+    wrow[j] = a.w + (size_t)(n0 + r) * a.Kpad + schunk * 8;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_danhip_zero_page);
+
+  // FAST path tap walker (uniform): tile kt covers channels [c0, c0+64) of tap (ti, tj)
+  int ti = 0, tj = 0, c0 = 0;
+
+  auto stage = [&](int kt, int buf) {
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + BM * 128;
+    if (FAST) {
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        const int hi = rh[j] + ti, wi = rw[j] + tj;
+        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + c0 + schunk * 8) : zero;
+        glds16(src, sA + (j * 32 + wave * 8) * 128);
+      }
+    } else {
+      const unsigned e = (unsigned)(kt * 8 + schunk) * 8u;   // first k element of this lane's chunk
+      const unsigned tap = fdiv(e, a.div_c);
+      const int cc = (int)(e - tap * (unsigned)a.C);
+      const int i = (int)fdiv(tap, a.div_kw);
+      const int jj = (int)tap - i * a.kw;
+      const bool tapok = (int)tap < a.taps;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        const int hi = rh[j] + i, wi = rw[j] + jj;
+        const bool ok = tapok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + cc) : zero;
+        glds16(src, sA + (j * 32 + wave * 8) * 128);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      if (BN >= 32 || (j * 32 + wave * 8) < BN) glds16(wrow[j] + kt * 64, sB + (j * 32 + wave * 8) * 128);
+    }
+    if (FAST) {                                         // advance the tap walker
+      c0 += 64;
+      if (c0 == a.C) { c0 = 0; if (++tj == a.kw) { tj = 0; ++ti; } }
+    }
+  };
+
+  f32x4 acc[NCT][NPT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+
+  stage(0, 0);
+  for (int kt = 0; kt < a.ktiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // tile kt landed; everyone is done reading the other stage
+    if (kt + 1 < a.ktiles) stage(kt + 1, (kt + 1) & 1);
+    const char* sA = smem + (kt & 1) * STAGE;
+    const char* sB = sA + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[NCT], xf[NPT];
+      const int q = ks * 4 + fq;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int r = wn * TC + c * 16 + frow;
+        wf[c] = *reinterpret_cast<const bf16x8*>(sB + r * 128 + ((q ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const int r = wm * TP + p * 16 + frow;
+        xf[p] = *reinterpret_cast<const bf16x8*>(sA + r * 128 + ((q ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[c][p], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds out[pixel = p*16 + (lane&15)][co = c*16 + (lane>>4)*4 + 0..3]
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int m = m0 + wm * TP + p * 16 + frow;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int co = n0 + wn * TC + c * 16 + fq * 4;
+      if (co >= a.Co) continue;
+      float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
+      const size_t o = (size_t)m * a.Co + co;
+      const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (co + r < a.Co) v[r] += a.bias[co + r];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.out_f32) {
+        float* y = reinterpret_cast<float*>(a.y) + o;
+        if (full) {
+          float4 t = make_float4(v[0], v[1], v[2], v[3]);
+          if (a.accumulate) { float4 u = *reinterpret_cast<float4*>(y); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+          *reinterpret_cast<float4*>(y) = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < a.Co) y[r] = a.accumulate ? y[r] + v[r] : v[r];
+        }
+      } else {
+        bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
+        if (full) {
+          if (a.mask) {
+            const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+            const bf16_t* mp = reinterpret_cast<const bf16_t*>(&mk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+          }
+          if (a.resid) {
+            const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + o);
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
+          }
+          if (a.accumulate) {
+            const uint2 old = *reinterpret_cast<const uint2*>(y);
+            const bf16_t* op = reinterpret_cast<const bf16_t*>(&old);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
+          }
+          uint2 t;
+          t.x = pack2bf(v[0], v[1]);
+          t.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(y) = t;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (co + r < a.Co) {
+              float t = v[r];
+              if (a.mask && !(bf2f(a.mask[o + r]) > 0.f)) t = 0.f;
+              if (a.resid) t += bf2f(a.resid[o + r]);
+              if (a.accumulate) t += bf2f(y[r]);
+              y[r] = f2bf(t);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Tile selection: output-channel tile BN from the (padded) channel count.
+inline int pick_bn(int co) {
+  if (co % 128 == 0) return 128;
+  if (co % 64 == 0) return 64;
+  if (co <= 16) return 16;
+  if (co <= 32) return 32;
+  return 64;
+}
+
+template <int BM, int BN, int WN_WAVES>
+int launch_cfg(const ConvArgs& a, bool fast, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.Co, BN));
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static const bool attr_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WN_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(2 * (BM + BN) * 128)) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WN_WAVES, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)(2 * (BM + BN) * 128)) == hipSuccess;
+  (void)attr_ok;
+  if (fast)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WN_WAVES, true>), grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WN_WAVES, false>), grid, dim3(256), lds, s, a);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+  const bool fast = (a.C % 64 == 0);
+  switch (pick_bn(a.Co)) {
+    case 128: return launch_cfg<128, 128, 2>(a, fast, s);
+    case 64: return launch_cfg<256, 64, 1>(a, fast, s);
+    case 32: return launch_cfg<256, 32, 1>(a, fast, s);
+    default: return launch_cfg<256, 16, 1>(a, fast, s);
+  }
+}
+
+inline int same_pad_before(int in, int out, int k, int s) {
+  int total = (out - 1) * s + k - in;
+  if (total < 0) total = 0;
+  return total / 2;
+}
+
+int check_desc(const danhip_conv_desc* d) {
+  DH_REQUIRE(d != nullptr, DANHIP_EINVAL, "conv: null descriptor");
+  DH_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, DANHIP_EINVAL, "conv: non-positive dims");
+  DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv: Cin=%d must be a multiple of 8 (pad the activation)", d->Cin);
+  DH_REQUIRE(d->kh >= 1 && d->kh <= 7 && d->kw >= 1 && d->kw <= 7, DANHIP_EINVAL, "conv: kernel %dx%d unsupported", d->kh, d->kw);
+  DH_REQUIRE(d->stride >= 1 && d->stride <= 4, DANHIP_EINVAL, "conv: stride %d unsupported", d->stride);
+  DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
+             "conv: Ho/Wo (%d,%d) != ceil(H/s),ceil(W/s) (TF SAME)", d->Ho, d->Wo);
+  DH_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * (int64_t)((d->Cout + 7) / 8 * 8) < (1ll << 31),
+             DANHIP_EINVAL, "conv: tensor exceeds 2^31 elements");
+  return DANHIP_OK;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" int danhip_conv_packed_dims(const danhip_conv_desc* d, int which, int64_t* rows, int64_t* cols) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(rows && cols, DANHIP_EINVAL, "conv_packed_dims: null output");
+  const int taps = d->kh * d->kw;
+  if (which == 0) {
+    *rows = round_up(d->Cout, pick_bn(d->Cout));
+    *cols = round_up(taps * d->Cin, 64);
+  } else {
+    const int co8 = round_up(d->Cout, 8);
+    *rows = round_up(d->Cin, pick_bn(d->Cin));
+    *cols = round_up(taps * co8, 64);
+  }
+  return DANHIP_OK;
+}
+
+namespace {
+// one thread per packed element
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb, int kh, int kw,
+                                   int cin, int cin_real, int cout, int rows_f, int cols_f, int rows_b, int cols_b, int co8) {
+  const long total_f = (long)rows_f * cols_f, total_b = wb ? (long)rows_b * cols_b : 0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
+    if (idx < total_f) {
+      const int co = (int)(idx / cols_f), k = (int)(idx % cols_f);
+      const int tap = k / cin, c = k % cin;
+      float v = 0.f;
+      if (co < cout && tap < kh * kw && c < cin_real) v = w[((long)tap * cin_real + c) * cout + co];
+      wf[idx] = f2bf(v);
+    } else {
+      const long j = idx - total_f;
+      const int ci = (int)(j / cols_b), k = (int)(j % cols_b);
+      const int tapf = k / co8, co = k % co8;          // flipped tap index
+      float v = 0.f;
+      if (ci < cin_real && tapf < kh * kw && co < cout) {
+        const int fi = tapf / kw, fj = tapf % kw;
+        const int tap = (kh - 1 - fi) * kw + (kw - 1 - fj);
+        v = w[((long)tap * cin_real + ci) * cout + co];
+      }
+      wb[j] = f2bf(v);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int danhip_pack_conv_weight(const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real, uint16_t* wf_packed,
+                                       uint16_t* wb_packed, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(w_hwio && wf_packed, DANHIP_EINVAL, "pack_conv_weight: null pointer");
+  DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "pack_conv_weight: cin_real=%d out of range", cin_real);
+  int64_t rf, cf, rb, cb;
+  danhip_conv_packed_dims(d, 0, &rf, &cf);
+  danhip_conv_packed_dims(d, 1, &rb, &cb);
+  const long total = rf * cf + (wb_packed ? rb * cb : 0);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, wf_packed, wb_packed, d->kh, d->kw,
+                     d->Cin, cin_real, d->Cout, (int)rf, (int)cf, (int)rb, (int)cb, round_up(d->Cout, 8));
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, void* y,
+                                 int out_dtype, int relu, const uint16_t* residual, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd: null pointer");
+  DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
+  DH_REQUIRE(!(residual && out_dtype == DANHIP_F32), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
+  ConvArgs a{};
+  a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Cout;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
+  a.pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride);
+  a.pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
+  a.M = d->N * d->Ho * d->Wo;
+  a.taps = d->kh * d->kw;
+  a.Kpad = round_up(a.taps * a.C, 64);
+  a.ktiles = a.Kpad / 64;
+  a.cpt = a.C / 64;
+  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
+  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
+  return launch_conv(a, (hipStream_t)stream);
+}
+
+namespace {
+// Direct (gather-form) data gradient for strided convolutions (only conv6_2 / conv7_2, 3x3 stride 2, tiny maps).
+// One thread per (input pixel, 8 input channels).
+__global__ void conv_bwd_data_strided_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wb, const bf16_t* __restrict__ mask,
+                                             bf16_t* __restrict__ dx, int N, int H, int W, int Cin, int Ho, int Wo, int co8, int kh, int kw,
+                                             int stride, int pad_t, int pad_l, int kpad_b, int accumulate) {
+  const long total = (long)N * H * W * (Cin / 8);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(idx % (Cin / 8));
+    long pix = idx / (Cin / 8);
+    const int wi = (int)(pix % W); pix /= W;
+    const int hi = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < kh; ++i) {
+      const int hn = hi + pad_t - i;
+      if (hn < 0 || hn % stride) continue;
+      const int ho = hn / stride;
+      if (ho >= Ho) continue;
+      for (int j = 0; j < kw; ++j) {
+        const int wn = wi + pad_l - j;
+        if (wn < 0 || wn % stride) continue;
+        const int wo = wn / stride;
+        if (wo >= Wo) continue;
+        const bf16_t* g = dy + ((long)(n * Ho + ho) * Wo + wo) * co8;
+        const int tapf = (kh - 1 - i) * kw + (kw - 1 - j);      // wb stores flipped taps
+        for (int co = 0; co < co8; ++co) {
+          const float gv = bf2f(g[co]);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[r] += gv * bf2f(wb[(long)(cg * 8 + r) * kpad_b + tapf * co8 + co]);
+        }
+      }
+    }
+    const long o = ((long)(n * H + hi) * W + wi) * Cin + cg * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = acc[r];
+      if (mask && !(bf2f(mask[o + r]) > 0.f)) v = 0.f;
+      if (accumulate) v += bf2f(dx[o + r]);
+      dx[o + r] = f2bf(v);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
+                                      uint16_t* dx, int accumulate, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(dy && wb_packed && dx, DANHIP_EINVAL, "conv2d_bwd_data: null pointer");
+  const int co8 = round_up(d->Cout, 8);
+  const int taps = d->kh * d->kw;
+  const int pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride), pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
+  if (d->stride != 1) {
+    const long total = (long)d->N * d->H * d->W * (d->Cin / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(conv_bwd_data_strided_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, wb_packed, relu_mask, dx, d->N,
+                       d->H, d->W, d->Cin, d->Ho, d->Wo, co8, d->kh, d->kw, d->stride, pad_t, pad_l, round_up(taps * co8, 64), accumulate);
+    DH_LAUNCH_CHECK();
+    return DANHIP_OK;
+  }
+  // stride 1: a forward convolution of dy with the tap-flipped, transposed weights; pad' = k-1-pad
+  ConvArgs a{};
+  a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = relu_mask; a.resid = nullptr; a.y = dx;
+  a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = co8; a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin;
+  a.kh = d->kh; a.kw = d->kw; a.stride = 1;
+  a.pad_t = d->kh - 1 - pad_t; a.pad_l = d->kw - 1 - pad_l;
+  a.M = d->N * d->H * d->W;
+  a.taps = taps;
+  a.Kpad = round_up(taps * co8, 64);
+  a.ktiles = a.Kpad / 64;
+  a.cpt = a.C / 64;
+  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
+  a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
+  return launch_conv(a, (hipStream_t)stream);
+}

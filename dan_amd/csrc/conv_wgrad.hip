@@ -1,0 +1,227 @@
+// Weight gradient of the NHWC convolution on MFMA (gfx950): dW[tap][ci][co] += sum_m X[m@tap][ci] * dY[m][co].
+//
+// GEMM view per tap: C[ci, co] = A^T[ci, m] * B[m, co] with the reduction over PIXELS, which is the slow (strided)
+// axis of both NHWC operands.  Both tiles are therefore staged exactly as they lie in HBM ([pixel][channel] rows,
+// 16-byte LDS-DMA pieces) and the MFMA fragments are produced by the gfx950 transpose read ds_read_b64_tr_b16
+// (a 4-pixel x 16-channel block per 16-lane group), so nothing is ever transposed in registers or through HBM.
+// The reduction over pixels is split across workgroups (grid.z); partial tiles are combined with fp32 atomics
+// straight into the HWIO gradient (zeroed by the caller once per step).
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  const bf16_t* x;     // [N,H,W,C]
+  const bf16_t* dy;    // [N,Ho,Wo,Co8]
+  float* dw;           // [kh,kw,cin_real,Cout]
+  int N, H, W, C, Ho, Wo, Co8, Cout, cin_real;
+  int kh, kw, stride, pad_t, pad_l;
+  int M, ktiles, kt_per_split;
+  int ci_tiles;        // number of input-channel tiles (blockIdx.x = co_tile * ci_tiles + ci_tile)
+  int tapcols;         // 1: tile columns are the taps (C == 8 first layer): column chunk t = tap t, channels 0..7
+  FastDiv div_wo, div_howo;
+};
+
+template <int RB>
+__device__ __forceinline__ int swz(int pix) {  // 32-byte-slot XOR making the transpose reads conflict-free
+  if (RB == 256) return ((pix & 3) | (((pix >> 3) & 1) << 2)) << 1;
+  if (RB == 128) return (((pix >> 1) & 1) | (((pix >> 3) & 1) << 1)) << 1;
+  return 0;
+}
+
+template <int BCI, int BCO, int WCI_WAVES>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int RBX = BCI * 2, RBY = BCO * 2;            // row bytes of the two tiles
+  constexpr int XB = 64 * RBX, YB = 64 * RBY;            // tile bytes (64 pixels per K tile)
+  constexpr int STAGE = XB + YB;
+  constexpr int PX = XB / 1024, PY = YB / 1024;          // 1 KiB LDS-DMA pieces per tile
+  constexpr int RPX = 1024 / RBX, RPY = 1024 / RBY;      // pixel rows per piece
+  constexpr int WCO_WAVES = 4 / WCI_WAVES;
+  constexpr int TCI = BCI / WCI_WAVES, TCO = BCO / WCO_WAVES;
+  constexpr int NI = TCI / 16, NO = TCO / 16;
+  static_assert(TCI % 16 == 0 && TCO % 16 == 0, "wave tile must be MFMA aligned");
+  constexpr int RX = (PX + 3) / 4, RY = (PY + 3) / 4;    // DMA rounds per wave
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wci = wave / WCO_WAVES, wco = wave % WCO_WAVES;
+
+  const int ci_tile = blockIdx.x % a.ci_tiles, co_tile = blockIdx.x / a.ci_tiles;
+  const int ci0 = ci_tile * BCI, co0 = co_tile * BCO;
+  const int tap = a.tapcols ? 0 : blockIdx.y;
+  const int ti = tap / a.kw, tj = tap % a.kw;
+  const int kt_begin = blockIdx.z * a.kt_per_split;
+  const int kt_end = min(a.ktiles, kt_begin + a.kt_per_split);
+  if (kt_begin >= kt_end) return;
+
+  // per-lane staging geometry
+  const int xr = (lane * 16) / RBX, xc = ((lane * 16) % RBX) / 16;   // row in piece, chunk position
+  const int yr = (lane * 16) / RBY, yc = ((lane * 16) % RBY) / 16;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_danhip_zero_page);
+
+  auto stage = [&](int kt, int buf) {
+    char* sX = smem + buf * STAGE;
+    char* sY = sX + XB;
+    const int mb = kt * 64;
+#pragma unroll
+    for (int r = 0; r < RX; ++r) {
+      const int piece = r * 4 + wave;
+      if (PX % 4 == 0 || piece < PX) {
+        const int prow = piece * RPX + xr;
+        const int m = mb + prow;
+        const int cs = xc ^ swz<RBX>(prow);                           // source chunk for this LDS position
+        const bf16_t* src = zero;
+        if (m < a.M) {
+          const unsigned n = fdiv((unsigned)m, a.div_howo);
+          const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+          const unsigned ho = fdiv(rem, a.div_wo);
+          const unsigned wo = rem - ho * (unsigned)a.Wo;
+          int i = ti, j = tj, cc = ci0 + cs * 8;
+          bool ok = true;
+          if (a.tapcols) { i = cs / a.kw; j = cs % a.kw; cc = 0; ok = cs < a.kh * a.kw; }
+          const int hi = (int)ho * a.stride - a.pad_t + i, wi = (int)wo * a.stride - a.pad_l + j;
+          ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && cc < a.C;
+          if (ok) src = a.x + ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.C + cc);
+        }
+        glds16(src, sX + piece * 1024);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const int piece = r * 4 + wave;
+      if (PY % 4 == 0 || piece < PY) {
+        const int prow = piece * RPY + yr;
+        const int m = mb + prow;
+        const int cs = yc ^ swz<RBY>(prow);
+        const int cc = co0 + cs * 8;
+        const bf16_t* src = (m < a.M && cc < a.Co8) ? a.dy + ((size_t)m * a.Co8 + cc) : zero;
+        glds16(src, sY + piece * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[NI][NO];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+
+  stage(kt_begin, 0);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
+    const char* sX = smem + buf * STAGE;
+    const char* sY = sX + XB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x4 xh[2][NI], yh[2][NO];   // halves of the fragments: k = 8g+0..3 and 8g+4..7
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pix = ks * 32 + 8 * g + 4 * h + q;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int cb = (wci * TCI + i * 16) / 16;
+          const int ch = cb * 2 + (p >> 1);
+          xh[h][i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (LDS_AS s16x4*)(sX + pix * RBX + ((ch ^ swz<RBX>(pix)) << 4) + (p & 1) * 8));
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const int cb = (wco * TCO + o * 16) / 16;
+          const int ch = cb * 2 + (p >> 1);
+          yh[h][o] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (LDS_AS s16x4*)(sY + pix * RBY + ((ch ^ swz<RBY>(pix)) << 4) + (p & 1) * 8));
+        }
+      }
+      // whole-vector concatenation + bitcast (element-wise extraction of the tr-read result miscompiles on ROCm 7.2:
+      // hipcc splats element 0)
+      bf16x8 xf[NI], yf[NO];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        xf[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xh[0][i], xh[1][i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        yf[o] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(yh[0][o], yh[1][o], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[o], acc[i][o], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds C[ci = i*16 + (lane>>4)*4 + r][co = o*16 + (lane&15)]
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cil = wci * TCI + i * 16 + g * 4 + r;                 // column inside the X tile
+      int t = tap, ci = ci0 + cil;
+      if (a.tapcols) { t = cil / 8; ci = cil % 8; if (t >= a.kh * a.kw) continue; }
+      if (ci >= a.cin_real) continue;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const int co = co0 + wco * TCO + o * 16 + (lane & 15);
+        if (co < a.Cout) atomicAdd(a.dw + ((size_t)(t * a.cin_real + ci) * a.Cout + co), acc[i][o][r]);
+      }
+    }
+  }
+}
+
+template <int BCI, int BCO, int WCI_WAVES>
+int launch_wgrad(WgradArgs& a, hipStream_t s) {
+  static const bool attr_ok = (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BCI, BCO, WCI_WAVES>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (BCI + BCO) * 2) == hipSuccess);
+  (void)attr_ok;
+  const int co_tiles = cdiv(a.Co8, BCO);
+  a.ci_tiles = a.tapcols ? 1 : cdiv(a.C, BCI);
+  const int taps = a.tapcols ? 1 : a.kh * a.kw;
+  const int base_blocks = co_tiles * a.ci_tiles * taps;
+  // split the pixel reduction so that ~4 workgroups per CU exist, but keep >= 8 K tiles per split
+  int splits = (1024 + base_blocks - 1) / base_blocks;
+  const int max_splits = (a.ktiles + 7) / 8;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.kt_per_split = (a.ktiles + splits - 1) / splits;
+  splits = (a.ktiles + a.kt_per_split - 1) / a.kt_per_split;
+  dim3 grid((unsigned)(co_tiles * a.ci_tiles), (unsigned)taps, (unsigned)splits);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BCI, BCO, WCI_WAVES>), grid, dim3(256), 2 * 64 * (BCI + BCO) * 2, s, a);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, int32_t cin_real,
+                                        void* stream) {
+  DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
+  DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
+  DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
+  DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
+             "conv2d_bwd_weight: Ho/Wo mismatch");
+  WgradArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw_hwio;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Co8 = (d->Cout + 7) / 8 * 8;
+  a.cin_real = cin_real;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
+  int total = (d->Ho - 1) * d->stride + d->kh - d->H; if (total < 0) total = 0; a.pad_t = total / 2;
+  total = (d->Wo - 1) * d->stride + d->kw - d->W; if (total < 0) total = 0; a.pad_l = total / 2;
+  a.M = d->N * d->Ho * d->Wo;
+  a.ktiles = (a.M + 63) / 64;
+  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->Cin == 8 && d->kh * d->kw <= 16) {       // first layer: taps ride in the tile columns
+    a.tapcols = 1;
+    return a.Co8 > 64 ? launch_wgrad<128, 128, 2>(a, s) : launch_wgrad<128, 64, 2>(a, s);
+  }
+  a.tapcols = 0;
+  const bool ci_small = d->Cin <= 64, co_small = a.Co8 <= 64;
+  if (ci_small && co_small) return launch_wgrad<64, 64, 2>(a, s);
+  if (ci_small) return launch_wgrad<64, 128, 2>(a, s);
+  if (co_small) return launch_wgrad<128, 64, 2>(a, s);
+  return launch_wgrad<128, 128, 2>(a, s);
+}

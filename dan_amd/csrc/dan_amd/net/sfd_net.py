@@ -1,0 +1,111 @@
+"""S3FD graph on the libdanhip kernels — mirrors the operator surface of the reference's net/sfd_net.py
+(class VGG16Backbone: l2_normalize, conv_relu, conv_block, get_featmaps, multibox_head; same argument meaning),
+native layout NHWC bf16 activations / fp32 HWIO variables under the reference's TF variable names.
+"""
+import torch
+
+from .. import ops
+from .variables import VariableStore
+
+
+class VGG16Backbone(object):
+    def __init__(self, data_format="channels_last", bn_epsilon=1e-5, bn_momentum=0.997, use_fused_bn=True, variables=None):
+        if data_format != "channels_last":
+            raise ValueError("the MI355X build is NHWC-native: use data_format='channels_last' "
+                             "(the reference's eval scripts' default, eval_sfd.py:63)")
+        self._data_format = data_format
+        self._bn_epsilon = bn_epsilon
+        self._bn_momentum = bn_momentum
+        self._use_fused_bn = use_fused_bn
+        self.vs = variables if variables is not None else VariableStore()
+
+    # ---- layers ---------------------------------------------------------------------------------------------
+    def l2_normalize(self, inputs, init_value, training, name=None):
+        """net/sfd_net.py:68-79."""
+        w = self.vs.get((name or "l2_normalize") + "/weight", (inputs.shape[-1],), init_value)
+        return ops.l2_normalize(inputs, w)
+
+    def conv2d(self, inputs, filters, kernel_size, strides, scope, relu, out_f32=False, residual=None, init="glorot"):
+        kh, kw = kernel_size
+        s = strides[0] if isinstance(strides, (tuple, list)) else strides
+        cin = inputs.shape[-1]
+        w = self.vs.get(scope + "/kernel", (kh, kw, getattr(inputs, "_real_channels", cin), filters), init)
+        b = self.vs.get(scope + "/bias", (filters,), "zeros")
+        return ops.conv2d(inputs, w, b, stride=s, relu=relu, out_f32=out_f32, residual=residual)
+
+    def conv_relu(self, inputs, filters, kernel_size, strides, scope, padding="same", dilate_rate=1, reuse=None):
+        """net/sfd_net.py:81-89."""
+        assert padding == "same" and dilate_rate == 1
+        return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True)
+
+    def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None):
+        """net/sfd_net.py:121-125."""
+        for ind in range(1, num_blocks + 1):
+            inputs = self.conv_relu(inputs, filters, kernel_size, strides, "{0}/{0}_{1}".format(name, ind))
+        return inputs
+
+    def get_featmaps(self, inputs, training=False):
+        """net/sfd_net.py:127-156.  inputs: bf16 NHWC BGR mean-subtracted, channels zero-padded to 8
+        (ops.preprocess_u8 makes it; `_real_channels` = 3 keeps the TF kernel shape [3,3,3,64])."""
+        feature_layers = []
+        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1")
+        inputs = ops.max_pool_2x2(inputs)
+        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2")
+        inputs = ops.max_pool_2x2(inputs)
+        inputs = self.conv_block(inputs, 3, 256, (3, 3), (1, 1), "conv3")
+        feature_layers.append(self.l2_normalize(inputs, 10, training, "l2_norm_layer_3"))
+        inputs = ops.max_pool_2x2(inputs)
+        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv4")
+        feature_layers.append(self.l2_normalize(inputs, 8, training, "l2_norm_layer_4"))
+        inputs = ops.max_pool_2x2(inputs)
+        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv5")
+        feature_layers.append(self.l2_normalize(inputs, 5, training, "l2_norm_layer_5"))
+        inputs = ops.max_pool_2x2(inputs)
+        inputs = self.conv_relu(inputs, 1024, (3, 3), (1, 1), "fc6")
+        inputs = self.conv_relu(inputs, 1024, (1, 1), (1, 1), "fc7")
+        feature_layers.append(inputs)
+        inputs = self.conv_relu(inputs, 256, (1, 1), (1, 1), "additional_layers/conv6_1")
+        inputs = self.conv_relu(inputs, 512, (3, 3), (2, 2), "additional_layers/conv6_2")
+        feature_layers.append(inputs)
+        inputs = self.conv_relu(inputs, 128, (1, 1), (1, 1), "additional_layers/conv7_1")
+        inputs = self.conv_relu(inputs, 256, (3, 3), (2, 2), "additional_layers/conv7_2")
+        feature_layers.append(inputs)
+        return feature_layers
+
+    def predict_heads(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name, shared_conv=False):
+        """Shared body of multibox_head (net/sfd_net.py:159-219), pb_net.get_predict_module (:230-290) and
+        danet.get_predict_module (:469-532).  loc_i and cls_i stay separate TF variables but run as ONE 3x3 conv
+        (their HWIO kernels concatenated on Cout: the feature map is read once — HBM-bound head), then
+        max-out + reshape_pred write straight into the level-concatenated [B, A, 4] / [B, A, 2] buffers."""
+        B = feature_layers[0].shape[0]
+        assert all(d == 1 for d in num_anchors_depth_per_layer), "one anchor per cell (all reference configs)"
+        A = sum(f.shape[1] * f.shape[2] for f in feature_layers)
+        dev = feature_layers[0].device
+        loc = torch.zeros((B, A, 4), dtype=torch.float32, device=dev)
+        cls = torch.zeros((B, A, 2), dtype=torch.float32, device=dev)
+        off = 0
+        for ind, feat in enumerate(feature_layers):
+            if shared_conv:
+                feat = self.conv_relu(feat, feat.shape[-1], (3, 3), (1, 1), "{}/shared_conv_{}".format(name, ind))
+            c = feat.shape[-1]
+            ncls = pos_maxout[ind] + neg_maxout[ind]
+            wl = self.vs.get("{}/loc_{}/kernel".format(name, ind), (3, 3, c, 4), "glorot")
+            bl = self.vs.get("{}/loc_{}/bias".format(name, ind), (4,), "zeros")
+            wc = self.vs.get("{}/cls_{}/kernel".format(name, ind), (3, 3, c, ncls), "glorot")
+            bc = self.vs.get("{}/cls_{}/bias".format(name, ind), (ncls,), "zeros")
+            h = ops.conv2d(feat, torch.cat([wl, wc], dim=3).contiguous(), torch.cat([bl, bc]), stride=1, relu=False, out_f32=True)
+            loc, cls = ops.head_split(h, loc, cls, neg_maxout[ind], pos_maxout[ind], off)
+            off += feat.shape[1] * feat.shape[2]
+        return loc, cls
+
+    def multibox_head(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer):
+        """net/sfd_net.py:159-219 + reshape/concat of train_sfd.py:293-304: returns (location_pred [B,A,4],
+        cls_pred [B,A,2]) already in (level, y, x, anchor) order."""
+        return self.predict_heads(feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, "multibox_head")
+
+
+def prepare_input(img_u8_rgb):
+    """uint8 RGB [B,H,W,3] (device) -> network input."""
+    x = ops.preprocess_u8(img_u8_rgb)
+    x._real_channels = 3
+    return x

@@ -1,0 +1,60 @@
+"""tf.get_variable-style lazy variable store on the GPU (variable names = the reference's TF names)."""
+import math
+
+import torch
+
+
+class VariableStore(torch.nn.Module):
+    """Creates fp32 nn.Parameters on first use with the reference's initialisers and keeps them under their TF
+    names ('conv1/conv1_1/conv2d/kernel' HWIO, '.../bias', 'l2_norm_layer_3/weight', ...)."""
+
+    def __init__(self, device="cuda", seed=20180817):
+        super().__init__()
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.vars = torch.nn.ParameterDict()
+        self.order = []
+
+    @staticmethod
+    def _key(name):
+        return name.replace(".", "|")
+
+    def get(self, name, shape, init):
+        k = self._key(name)
+        if k not in self.vars:
+            shape = tuple(int(s) for s in shape)
+            if init == "glorot":                       # tf.glorot_uniform_initializer on an HWIO kernel (net/sfd_net.py:65)
+                kh, kw, ci, co = shape
+                lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+                v = (torch.rand(shape, generator=self.gen) * 2.0 - 1.0) * lim
+            elif init == "glorot_oihw":                # deform kernel (Cout,Cin,kh,kw): fans from the shape as given
+                co, ci, kh, kw = shape
+                lim = math.sqrt(6.0 / (co * ci * kh + co * ci * kw))
+                v = (torch.rand(shape, generator=self.gen) * 2.0 - 1.0) * lim
+            elif init == "zeros":
+                v = torch.zeros(shape)
+            else:
+                v = torch.full(shape, float(init))
+            self.vars[k] = torch.nn.Parameter(v.to(self.device))
+            self.order.append(name)
+        p = self.vars[k]
+        assert tuple(p.shape) == tuple(shape), (name, tuple(p.shape), tuple(shape))
+        return p
+
+    def named(self):
+        return [(n, self.vars[self._key(n)]) for n in self.order]
+
+    def load_tf_named(self, tensors):
+        """tensors: {tf_name: array/tensor} (e.g. from the CPU oracle or a converted checkpoint)."""
+        for n, t in tensors.items():
+            t = torch.as_tensor(t, dtype=torch.float32)
+            k = self._key(n)
+            if k in self.vars:
+                with torch.no_grad():
+                    self.vars[k].copy_(t.to(self.device))
+            else:
+                self.vars[k] = torch.nn.Parameter(t.to(self.device).clone())
+                self.order.append(n)
+
+    def export_tf_named(self):
+        return {n: p.detach().cpu().clone() for n, p in self.named()}

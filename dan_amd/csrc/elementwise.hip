@@ -1,0 +1,306 @@
+// HBM-bound layer kernels of the backbone / heads (gfx950): every access is a 16-byte (8 x bf16) vector per lane,
+// reductions are wavefront (64-lane) shuffles.  Replaces the TF built-ins named at each entry point.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct bf8 { uint4 v; };
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+  return u;
+}
+
+// ------------------------------------------------------------------ ReLU backward + bias gradient (one pass over dy)
+// grid: (column groups of 8 channels) x (row chunks).  Each thread owns 8 channels and strides over rows.
+__global__ void relu_bwd_bias_kernel(bf16_t* __restrict__ dy, const bf16_t* __restrict__ y, float* __restrict__ db, long M, int C) {
+  const int cg = C / 8;                                   // channel groups per row
+  const int tpr = blockDim.x / cg > 0 ? blockDim.x / cg : 1;  // rows handled in parallel by one block
+  const int g = threadIdx.x % cg, rsub = threadIdx.x / cg;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rsub < tpr) {
+    for (long m = (long)blockIdx.x * tpr + rsub; m < M; m += (long)gridDim.x * tpr) {
+      const long o = m * C + g * 8;
+      uint4 d = *reinterpret_cast<const uint4*>(dy + o);
+      float f[8];
+      unpack8(d, f);
+      if (y) {
+        uint4 yy = *reinterpret_cast<const uint4*>(y + o);
+        float yf[8];
+        unpack8(yy, yf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (!(yf[i] > 0.f)) f[i] = 0.f;
+        *reinterpret_cast<uint4*>(dy + o) = pack8(f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
+  }
+  if (!db) return;
+  extern __shared__ float red[];                          // [blockDim.x][8]
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[threadIdx.x * 8 + i] = s[i];
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < tpr; ++r)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] += red[(r * cg + threadIdx.x) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(db + threadIdx.x * 8 + i, t[i]);
+  }
+}
+
+// ------------------------------------------------------------------ 2x2/2 max pool, TF 'same'
+__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int cg = C / 8;
+  const long total = (long)N * Ho * Wo * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % cg);
+    long p = idx / cg;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int h = ho * 2 + dh, w = wo * 2 + dw;
+        if (h < H && w < W) {
+          float f[8];
+          unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + h) * W + w) * C + g * 8), f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], f[i]);
+        }
+      }
+    *reinterpret_cast<uint4*>(y + idx * 8) = pack8(m);
+  }
+}
+
+// backward: the gradient goes to the FIRST maximal element in window order (0,0),(0,1),(1,0),(1,1)
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H, int W,
+                                   int C, int Ho, int Wo) {
+  const int cg = C / 8;
+  const long total = (long)N * Ho * Wo * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % cg);
+    long p = idx / cg;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float v[4][8];
+    bool in[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int h = ho * 2 + (t >> 1), w = wo * 2 + (t & 1);
+      in[t] = h < H && w < W;
+      if (in[t]) unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + h) * W + w) * C + g * 8), v[t]);
+      else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[t][i] = -INFINITY;
+    }
+    float gy[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + idx * 8), gy);
+    float o[4][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int best = 0;
+      float bv = v[0][i];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) if (v[t][i] > bv) { bv = v[t][i]; best = t; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[t][i] = (t == best) ? gy[i] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int h = ho * 2 + (t >> 1), w = wo * 2 + (t & 1);
+      if (in[t]) *reinterpret_cast<uint4*>(dx + (((long)n * H + h) * W + w) * C + g * 8) = pack8(o[t]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ channel L2 normalisation with learned scale
+// one wave per pixel; lane owns C/64 consecutive channels (C in {64..1024}, multiple of 64; handled as float regs)
+template <int CPL>
+__global__ void l2norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, bf16_t* __restrict__ y, long M, int C) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pix >= M) return;
+  float f[CPL];
+  const bf16_t* px = x + pix * C + lane * CPL;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) f[i] = bf2f(px[i]);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) ss += f[i] * f[i];
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(fmaxf(ss, 1e-10f));
+  bf16_t* py = y + pix * C + lane * CPL;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) py[i] = f2bf(f[i] * inv * gamma[lane * CPL + i]);
+}
+
+// dx = gamma*inv*dy - x*inv^3 * sum_c(dy*gamma*x)   (second term dropped where sum x^2 <= 1e-10: clamp inactive grad)
+// dgamma[c] += sum_pix dy*x*inv.  dx is ACCUMULATED into (the tapped map also feeds the next conv block).
+template <int CPL>
+__global__ void l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const bf16_t* __restrict__ dy,
+                                  bf16_t* __restrict__ dx, float* __restrict__ dgamma, long M, int C, int accumulate) {
+  extern __shared__ float sg[];                           // [waves][C] partial dgamma
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float dg[CPL];
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) dg[i] = 0.f;
+  for (long pix = (long)blockIdx.x * nw + wv; pix < M; pix += (long)gridDim.x * nw) {
+    float f[CPL], g[CPL];
+    const long o = pix * C + lane * CPL;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { f[i] = bf2f(x[o + i]); g[i] = bf2f(dy[o + i]); }
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { ss += f[i] * f[i]; dot += g[i] * gamma[lane * CPL + i] * f[i]; }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float inv = rsqrtf(fmaxf(ss, 1e-10f));
+    const float k = (ss > 1e-10f) ? dot * inv * inv * inv : 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      float v = gamma[lane * CPL + i] * inv * g[i] - f[i] * k;
+      if (accumulate) v += bf2f(dx[o + i]);
+      dx[o + i] = f2bf(v);
+      dg[i] += g[i] * f[i] * inv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) sg[wv * C + lane * CPL + i] = dg[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int w = 0; w < nw; ++w) t += sg[w * C + c];
+    atomicAdd(dgamma + c, t);
+  }
+}
+
+// ------------------------------------------------------------------ input preprocessing
+// uint8 RGB [N,H,W,3] -> bf16 [N,H,W,8] = (BGR - mean, 0,0,0,0,0)   (preprocessing/dan_preprocessing.py:55-57,755-758)
+__global__ void preprocess_kernel(const unsigned char* __restrict__ img, bf16_t* __restrict__ out, long npix) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const float r = (float)img[p * 3] - 123.68f, g = (float)img[p * 3 + 1] - 116.78f, b = (float)img[p * 3 + 2] - 103.94f;
+    float f[8] = {b, g, r, 0, 0, 0, 0, 0};
+    *reinterpret_cast<uint4*>(out + p * 8) = pack8(f);
+  }
+}
+
+__global__ void cast_pad_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, int c_src, int c_dst) {
+  const long total = rows * c_dst;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c_dst;
+    const int c = (int)(i % c_dst);
+    dst[i] = f2bf(c < c_src ? src[r * c_src + c] : 0.f);
+  }
+}
+
+inline int grid_for(long total, int block, int cap = 8192) {
+  long b = (total + block - 1) / block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_t M, int32_t C, void* stream) {
+  DH_REQUIRE(dy && M > 0 && C > 0, DANHIP_EINVAL, "relu_bwd_bias_grad: bad arguments");
+  DH_REQUIRE(C % 8 == 0 && C / 8 <= 256, DANHIP_EINVAL, "relu_bwd_bias_grad: C=%d must be a multiple of 8 and <= 2048", C);
+  if (!y && !db) return DANHIP_OK;
+  const int cg = C / 8;
+  const int block = 256;
+  const int tpr = block / cg > 0 ? block / cg : 1;
+  long blocks = (M + tpr - 1) / tpr;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3((unsigned)blocks), dim3(block), block * 8 * sizeof(float), (hipStream_t)stream, dy, y, db,
+                     (long)M, C);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  DH_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool2x2_fwd: bad arguments (C%%8)");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                     void* stream) {
+  DH_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool2x2_bwd: bad arguments (C%%8)");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t* y, int64_t M, int32_t C, void* stream) {
+  DH_REQUIRE(x && gamma && y && M > 0, DANHIP_EINVAL, "l2norm_fwd: bad arguments");
+  DH_REQUIRE(C == 256 || C == 512 || C == 1024 || C == 128 || C == 64, DANHIP_EINVAL, "l2norm_fwd: C=%d unsupported", C);
+  const unsigned blocks = (unsigned)((M + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C / 64) {
+    case 1: hipLaunchKernelGGL(l2norm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+    case 2: hipLaunchKernelGGL(l2norm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+    case 4: hipLaunchKernelGGL(l2norm_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+    case 8: hipLaunchKernelGGL(l2norm_fwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+    default: hipLaunchKernelGGL(l2norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+  }
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const uint16_t* dy, uint16_t* dx, float* dgamma, int64_t M,
+                                 int32_t C, int accumulate, void* stream) {
+  DH_REQUIRE(x && gamma && dy && dx && dgamma && M > 0, DANHIP_EINVAL, "l2norm_bwd: bad arguments");
+  DH_REQUIRE(C == 256 || C == 512 || C == 1024 || C == 128 || C == 64, DANHIP_EINVAL, "l2norm_bwd: C=%d unsupported", C);
+  long blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = 4 * (size_t)C * sizeof(float);
+  switch (C / 64) {
+    case 1: hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+    case 2: hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+    case 4: hipLaunchKernelGGL(l2norm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+    case 8: hipLaunchKernelGGL(l2norm_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+    default: hipLaunchKernelGGL(l2norm_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+  }
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64_t npix, void* stream) {
+  DH_REQUIRE(img_rgb && out && npix > 0, DANHIP_EINVAL, "preprocess_u8: bad arguments");
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, img_rgb, out, (long)npix);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_cast_pad_f32_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst, void* stream) {
+  DH_REQUIRE(src && dst && rows > 0 && c_src > 0 && c_dst >= c_src, DANHIP_EINVAL, "cast_pad: bad arguments");
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * c_dst, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)rows, c_src, c_dst);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}

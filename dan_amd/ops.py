@@ -1,0 +1,256 @@
+"""torch.autograd.Function wrappers over the libdanhip C ABI (device memory / streams / autograd are PyTorch
+plumbing; all arithmetic happens in the HIP kernels).  Activations are NHWC torch.bfloat16 tensors.
+
+Gradient sinks: when a parameter carries a `_danhip_grad` tensor (a view into the trainer's flat fp32 gradient
+buffer) the backward kernels accumulate straight into it and return None to autograd; otherwise a fresh
+gradient tensor is returned as usual (used by the parity tests with torch.autograd.grad).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvDesc, call, ptr, stream
+
+
+def _desc(N, H, W, Cin, Cout, kh, kw, stride):
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride = N, H, W, Cin, Cout, kh, kw, stride
+    d.Ho, d.Wo = -(-H // stride), -(-W // stride)
+    return d
+
+
+def packed_dims(d, which):
+    r, c = ctypes.c_int64(), ctypes.c_int64()
+    call("danhip_conv_packed_dims", ctypes.byref(d), which, ctypes.byref(r), ctypes.byref(c))
+    return r.value, c.value
+
+
+def pack_conv_weight(d, w_hwio, need_bwd=True):
+    """fp32 HWIO [kh,kw,cin_real,Cout] -> (wf bf16 [Cout_pad,Kpad], wb bf16 [Cin_pad,Kpad_b] or None)."""
+    assert w_hwio.dtype == torch.float32 and w_hwio.is_contiguous()
+    rf, cf = packed_dims(d, 0)
+    wf = torch.empty((rf, cf), dtype=torch.bfloat16, device=w_hwio.device)
+    wb = None
+    if need_bwd:
+        rb, cb = packed_dims(d, 1)
+        wb = torch.empty((rb, cb), dtype=torch.bfloat16, device=w_hwio.device)
+    call("danhip_pack_conv_weight", ctypes.byref(d), ptr(w_hwio), w_hwio.shape[2], ptr(wf), ptr(wb), stream())
+    return wf, wb
+
+
+def _grad_sink(p):
+    return getattr(p, "_danhip_grad", None)
+
+
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param):
+        N, H, W, C = x.shape
+        kh, kw, cin_real, cout = w.shape
+        assert x.dtype == torch.bfloat16 and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
+        assert C % 8 == 0 and cin_real <= C
+        d = _desc(N, H, W, C, cout, kh, kw, stride)
+        need_bwd = w.requires_grad or x.requires_grad
+        wf, wb = pack_conv_weight(d, w.detach(), need_bwd=need_bwd)
+        y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
+             F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
+        ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
+        ctx.has_res = residual is not None
+        ctx.w_param, ctx.b_param = w_param, b_param
+        ctx.save_for_backward(x, wb, y if relu else None)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb, y = ctx.saved_tensors
+        d = ctx.d
+        co8 = (d.Cout + 7) // 8 * 8
+        M = d.N * d.Ho * d.Wo
+        if dy.dtype != torch.bfloat16 or dy.shape[-1] != co8:
+            # fp32 / unpadded upstream gradient (head convs): cast + pad channels to a multiple of 8
+            src = dy.contiguous().to(torch.float32)
+            dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=torch.bfloat16, device=dy.device)
+            call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(dyp), M, d.Cout, co8, stream())
+            dy = dyp
+            owned = True
+        else:
+            dy = dy.contiguous()
+            owned = False
+        dres = dy if ctx.has_res else None          # residual is added after the activation
+        wp, bp = ctx.w_param, ctx.b_param
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        db = None
+        db_sink = _grad_sink(bp) if bp is not None else None
+        if need_db:
+            db = db_sink if db_sink is not None else torch.zeros(d.Cout, dtype=torch.float32, device=dy.device)
+        if ctx.relu or need_db:
+            if ctx.relu and not owned:
+                dy = dy.clone()                      # the incoming gradient tensor may be shared with other consumers
+            call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y) if ctx.relu else None, ptr(db) if (need_db and co8 == d.Cout) else None,
+                 M, co8, stream())
+            if need_db and co8 != d.Cout:            # padded head gradient: reduce the real channels with torch (tiny)
+                s = dy.view(M, co8)[:, :d.Cout].to(torch.float32).sum(0)
+                db.add_(s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = _grad_sink(wp) if wp is not None else None
+            dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=dy.device)
+            call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ctx.cin_real, stream())
+            if sink is not None:
+                dw = None
+        if db_sink is not None:
+            db = None
+        return dx, dw, db, None, None, None, dres, None, None
+
+
+def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None):
+    wp = w if isinstance(w, torch.nn.Parameter) else None
+    bp = b if isinstance(b, torch.nn.Parameter) else None
+    return _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp)
+
+
+class _MaxPool(torch.autograd.Function):
+    """tf.layers.max_pooling2d([2,2],[2,2],'same') — net/sfd_net.py:132."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
+        call("danhip_maxpool2x2_fwd", ptr(x), ptr(y), N, H, W, C, stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        call("danhip_maxpool2x2_bwd", ptr(x), ptr(dy.contiguous()), ptr(dx), N, H, W, C, stream())
+        return dx
+
+
+def max_pool_2x2(x):
+    return _MaxPool.apply(x)
+
+
+class _L2Norm(torch.autograd.Function):
+    """VGG16Backbone.l2_normalize — net/sfd_net.py:68-79."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, g_param):
+        y = torch.empty_like(x)
+        M = x.numel() // x.shape[-1]
+        call("danhip_l2norm_fwd", ptr(x), ptr(gamma.detach()), ptr(y), M, x.shape[-1], stream())
+        ctx.save_for_backward(x, gamma.detach())
+        ctx.g_param = g_param
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        M = x.numel() // x.shape[-1]
+        dx = torch.empty_like(x)
+        sink = _grad_sink(ctx.g_param) if ctx.g_param is not None else None
+        dg = sink if sink is not None else torch.zeros_like(gamma)
+        call("danhip_l2norm_bwd", ptr(x), ptr(gamma), ptr(dy.contiguous()), ptr(dx), ptr(dg), M, x.shape[-1], 0, stream())
+        return dx, (None if sink is not None else dg), None
+
+
+def l2_normalize(x, gamma):
+    return _L2Norm.apply(x, gamma, gamma if isinstance(gamma, torch.nn.Parameter) else None)
+
+
+class _HeadSplit(torch.autograd.Function):
+    """Max-out + reshape_pred for one pyramid level (depth 1): head conv output fp32 [B,H,W,4+nneg+npos] ->
+    writes loc[B, off:off+HW, :], cls[B, off:off+HW, :] of the concatenated prediction buffers
+    (net/sfd_net.py:175-216; train_sfd.py:293-304)."""
+
+    @staticmethod
+    def forward(ctx, h, loc, cls, nneg, npos, off):
+        B, H, W, Ch = h.shape
+        A = loc.shape[1]
+        call("danhip_head_split_fwd", ptr(h), ptr(loc), ptr(cls), B, H * W, Ch, nneg, npos, A, off, stream())
+        ctx.save_for_backward(h)
+        ctx.cfg = (nneg, npos, off, A)
+        ctx.mark_dirty(loc, cls)
+        return loc, cls
+
+    @staticmethod
+    def backward(ctx, dloc, dcls):
+        (h,) = ctx.saved_tensors
+        nneg, npos, off, A = ctx.cfg
+        B, H, W, Ch = h.shape
+        ch8 = (Ch + 7) // 8 * 8
+        dy = torch.empty((B, H, W, ch8), dtype=torch.bfloat16, device=h.device)
+        call("danhip_head_split_bwd", ptr(h), ptr(dloc.contiguous()), ptr(dcls.contiguous()), ptr(dy), B, H * W, Ch, nneg, npos, A, off, stream())
+        return dy, dloc, dcls, None, None, None
+
+
+def head_split(h, loc, cls, nneg, npos, off):
+    return _HeadSplit.apply(h, loc, cls, nneg, npos, off)
+
+
+class _DetectionLoss(torch.autograd.Function):
+    """Hard-negative mining + CE*(ratio+1) + smooth-L1 (train_sfd.py:350-417 / train_dan.py:286-324,470-478).
+    Returns a 4-vector acc = [ce_sum, n_selected, loc_sum, n_pos] (device, no sync); the loss is
+    (ratio+1)*ce_sum/n_selected + loc_sum/n_pos.  backward() expects the upstream gradient of that 4-vector to be
+    ignored: it uses ctx.scale (= d total_loss / d this loss term) instead."""
+
+    @staticmethod
+    def forward(ctx, cls, loc, labels, loc_t, ratio, at_least_one, scale):
+        B, A, _ = cls.shape
+        dev = cls.device
+        score = torch.empty((B, A), dtype=torch.float32, device=dev)
+        counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+        thr = torch.empty((B,), dtype=torch.float32, device=dev)
+        k = torch.empty((B,), dtype=torch.int32, device=dev)
+        sel = torch.empty((B, A), dtype=torch.uint8, device=dev)
+        acc = torch.empty((4,), dtype=torch.float32, device=dev)
+        call("danhip_hard_neg_select", ptr(cls), ptr(labels), ptr(score), ptr(counts), ptr(thr), ptr(k), B, A, float(ratio), int(at_least_one), stream())
+        call("danhip_detection_loss_fwd", ptr(cls), ptr(loc), ptr(labels), ptr(loc_t), ptr(score), ptr(thr), ptr(sel), ptr(acc), B, A, stream())
+        ctx.save_for_backward(cls, loc, loc_t, sel, acc)
+        ctx.cfg = (ratio, scale)
+        ctx.aux = (score, thr, k, counts)
+        return acc
+
+    @staticmethod
+    def backward(ctx, dacc):
+        cls, loc, loc_t, sel, acc = ctx.saved_tensors
+        ratio, scale = ctx.cfg
+        B, A, _ = cls.shape
+        dcls = torch.empty_like(cls)
+        dloc = torch.empty_like(loc)
+        call("danhip_detection_loss_bwd", ptr(cls), ptr(loc), ptr(loc_t), ptr(sel), ptr(acc), ptr(dcls), ptr(dloc), float((ratio + 1.0) * scale),
+             float(scale), B, A, stream())
+        return dcls, dloc, None, None, None, None, None
+
+
+def detection_loss(cls, loc, labels, loc_t, ratio=3.0, at_least_one=False, scale=1.0):
+    return _DetectionLoss.apply(cls, loc, labels, loc_t, ratio, at_least_one, scale)
+
+
+def preprocess_u8(img_rgb_u8):
+    """uint8 RGB [N,H,W,3] -> bf16 [N,H,W,8] (BGR - mean, zero padded): dan_preprocessing.py:55-57,755-758."""
+    assert img_rgb_u8.dtype == torch.uint8 and img_rgb_u8.shape[-1] == 3
+    N, H, W, _ = img_rgb_u8.shape
+    out = torch.empty((N, H, W, 8), dtype=torch.bfloat16, device=img_rgb_u8.device)
+    call("danhip_preprocess_u8", ptr(img_rgb_u8.contiguous()), ptr(out), N * H * W, stream())
+    return out
+
+
+def cast_pad(x_f32, c_dst):
+    """fp32 [..., C] -> bf16 [..., c_dst] zero padded."""
+    shp = x_f32.shape
+    rows = x_f32.numel() // shp[-1]
+    out = torch.empty(shp[:-1] + (c_dst,), dtype=torch.bfloat16, device=x_f32.device)
+    call("danhip_cast_pad_f32_to_bf16", ptr(x_f32.contiguous()), ptr(out), rows, shp[-1], c_dst, stream())
+    return out

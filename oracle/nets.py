@@ -1,0 +1,242 @@
+"""The four detector graphs restated on PyTorch-CPU, NHWC (channels_last) — oracle only.
+
+Follows net/sfd_net.py, net/pb_net.py, net/danet.py, net/danet_deform.py and
+utility/custom_op.py:128-146 of the reference.  Variables live in a flat dict keyed by the
+TF variable names (without the model scope), e.g. "conv1/conv1_1/conv2d/kernel" [kh,kw,Cin,Cout].
+
+`Params(create=True, seed=...)` creates variables on first use with the reference's initialisers
+(glorot-uniform kernels net/sfd_net.py:65, zero biases, l2-norm scale 10/8/5), which is how the
+synthetic weights of SURVEY §8(d) are made.
+"""
+import torch
+
+from . import tf_ops as T
+from .deform import deform_conv_forward
+
+
+class Params:
+    def __init__(self, tensors=None, create=False, seed=20180817, dtype=torch.float32):
+        self.t = dict(tensors or {})
+        self.create = create
+        self.gen = torch.Generator().manual_seed(seed)
+        self.dtype = dtype
+
+    def get(self, name, shape, init):
+        if name not in self.t:
+            if not self.create:
+                raise KeyError(name)
+            if init == "glorot":                       # HWIO conv kernel
+                kh, kw, ci, co = shape
+                v = T.glorot_uniform_(shape, kh * kw * ci, kh * kw * co, self.gen)
+            elif init == "glorot_oihw":                # deform kernel (Cout,Cin,kh,kw): TF computes fans from
+                co, ci, kh, kw = shape                  # the shape as given: receptive=co*ci, in=kh, out=kw
+                v = T.glorot_uniform_(shape, co * ci * kh, co * ci * kw, self.gen)
+            elif init == "zeros":
+                v = torch.zeros(shape)
+            elif isinstance(init, (int, float)):
+                v = torch.full(shape, float(init))
+            else:
+                raise ValueError(init)
+            self.t[name] = v.to(self.dtype)
+        v = self.t[name]
+        assert tuple(v.shape) == tuple(shape), (name, tuple(v.shape), tuple(shape))
+        return v
+
+
+def conv(P, x, filters, ksize, stride, scope, relu, init="glorot"):
+    """tf.layers.conv2d(name=<scope>) with bias; kernel var '<scope>/kernel', bias '<scope>/bias'."""
+    kh, kw = ksize
+    w = P.get(scope + "/kernel", (kh, kw, x.shape[-1], filters), init)
+    b = P.get(scope + "/bias", (filters,), "zeros")
+    return T.conv2d_same(x, w, b, stride=stride, relu=relu)
+
+
+def conv_relu(P, x, filters, ksize, stride, scope):
+    """VGG16Backbone.conv_relu — net/sfd_net.py:81-89 (variables under '<scope>/conv2d/')."""
+    return conv(P, x, filters, ksize, stride, scope + "/conv2d", relu=True)
+
+
+def conv_block(P, x, n, filters, name):
+    """net/sfd_net.py:121-125."""
+    for i in range(1, n + 1):
+        x = conv_relu(P, x, filters, (3, 3), 1, "{0}/{0}_{1}".format(name, i))
+    return x
+
+
+def get_featmaps(P, x):
+    """VGG16Backbone.get_featmaps — net/sfd_net.py:127-156 (identical in pb_net/danet)."""
+    feats = []
+    x = conv_block(P, x, 2, 64, "conv1")
+    x = T.max_pool_2x2_same(x)
+    x = conv_block(P, x, 2, 128, "conv2")
+    x = T.max_pool_2x2_same(x)
+    x = conv_block(P, x, 3, 256, "conv3")
+    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_3/weight", (256,), 10.0)))
+    x = T.max_pool_2x2_same(x)
+    x = conv_block(P, x, 3, 512, "conv4")
+    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_4/weight", (512,), 8.0)))
+    x = T.max_pool_2x2_same(x)
+    x = conv_block(P, x, 3, 512, "conv5")
+    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_5/weight", (512,), 5.0)))
+    x = T.max_pool_2x2_same(x)
+    x = conv_relu(P, x, 1024, (3, 3), 1, "fc6")
+    x = conv_relu(P, x, 1024, (1, 1), 1, "fc7")
+    feats.append(x)
+    x = conv_relu(P, x, 256, (1, 1), 1, "additional_layers/conv6_1")
+    x = conv_relu(P, x, 512, (3, 3), 2, "additional_layers/conv6_2")
+    feats.append(x)
+    x = conv_relu(P, x, 128, (1, 1), 1, "additional_layers/conv7_1")
+    x = conv_relu(P, x, 256, (3, 3), 2, "additional_layers/conv7_2")
+    feats.append(x)
+    return feats
+
+
+def predict_module(P, feats, pos_maxout, neg_maxout, depth, name, shared_conv=False):
+    """multibox_head (net/sfd_net.py:159-219, name='multibox_head'), PB get_predict_module
+    (net/pb_net.py:230-290) and DAN get_predict_module with shared conv (net/danet.py:469-532)."""
+    locs, clss = [], []
+    for i, f in enumerate(feats):
+        if shared_conv:
+            f = conv_relu(P, f, f.shape[-1], (3, 3), 1, "{}/shared_conv_{}".format(name, i))
+        locs.append(conv(P, f, depth[i] * 4, (3, 3), 1, "{}/loc_{}".format(name, i), relu=False))
+        c = conv(P, f, depth[i] * (pos_maxout[i] + neg_maxout[i]), (3, 3), 1, "{}/cls_{}".format(name, i), relu=False)
+        clss.append(T.maxout_cls(c, depth[i], neg_maxout[i], pos_maxout[i]))
+    return locs, clss
+
+
+def build_lfpn(P, feats, skip_last=3, name="lfpn", fused_channels=None):
+    """PB build_lfpn (net/pb_net.py:185-226; fused_conv -> down_channels) and DAN build_lfpn
+    (net/danet.py:339-380; fused_conv -> 256). No activation on any conv; the running
+    `up_sampling` is the SUM (lateral + upsampled), not the fused output."""
+    outs = []
+    up = None
+    for ind in range(skip_last, 0, -1):
+        sc = "{}/fpn_{}".format(name, ind - 1)
+        down = feats[ind - 1].shape[-1]
+        if up is None:
+            up = feats[ind]
+        up = conv(P, up, down, (1, 1), 1, sc + "/upsample_conv", relu=False)
+        lat = conv(P, feats[ind - 1], down, (1, 1), 1, sc + "/lateral", relu=False)
+        up = T.resize_bilinear_legacy(up, lat.shape[1], lat.shape[2])
+        up = lat + up
+        outs.append(conv(P, up, fused_channels or down, (3, 3), 1, sc + "/fused_conv", relu=False))
+    return list(reversed(outs)) + list(feats[skip_last:])
+
+
+def context_pred_module(P, feats):
+    """PyramidBox CPM — net/pb_net.py:158-183 (hard-coded 1024 channels)."""
+    def block(x, nc, last_div, name):
+        x = conv_relu(P, x, nc, (3, 3), 1, name + "/conv1")
+        x = conv_relu(P, x, nc // 4, (3, 3), 1, name + "/conv2")
+        return conv_relu(P, x, nc // last_div, (3, 3), 1, name + "/conv3")
+    outs = []
+    for i, f in enumerate(feats):
+        nc = 1024
+        b1 = block(f, nc, 4, "cpm/branch{}_1".format(i))
+        b2 = block(f, nc, 4, "cpm/branch{}_2".format(i))
+        b2_1 = block(b2, nc, 8, "cpm/branch{}_2_1".format(i))
+        b2_2_1 = block(b2, nc, 8, "cpm/branch{}_2_2_1".format(i))
+        b2_2_2 = block(b2_2_1, nc, 8, "cpm/branch{}_2_2_2".format(i))
+        outs.append(torch.cat([b1, b2_1, b2_2_2], dim=-1))
+    return outs
+
+
+def se_inception_block_v1(P, x, name):
+    """DAN context module V1 — net/danet.py:842-918."""
+    c = x.shape[-1]
+    cr = lambda inp, f, k, n: conv(P, inp, f, k, 1, name + "/" + n, relu=True)
+    b1 = cr(x, 64, (1, 1), "branch1_conv_1x1")
+    b2 = cr(T.avg_pool_2x2_s1_same(x), 64, (1, 1), "branch2_conv_1x1")
+    b3 = cr(x, 64, (1, 1), "branch3_conv_1x1")
+    b3a = cr(b3, 32, (3, 1), "branch3_conv_3x1")
+    b3b = cr(b3, 32, (1, 3), "branch3_conv_1x3")
+    b4 = cr(x, 64, (1, 1), "branch4_conv_1x1")
+    b4 = cr(b4, 64, (3, 3), "branch4_conv_3x3")
+    b4a = cr(b4, 32, (3, 1), "branch4_conv_1x3")      # (sic) names swapped in the reference
+    b4b = cr(b4, 32, (1, 3), "branch4_conv_3x1")
+    hyper = torch.cat([b1, b2, b3a, b3b, b4a, b4b], dim=-1)
+    return cr(hyper, c, (1, 1), "residual_conv") + x
+
+
+def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False):
+    """custom_op.deform_conv_2d — utility/custom_op.py:128-146 (channels_last: transposes around the op).
+    Offset conv: tf.layers.conv2d default name 'conv2d', zero-init kernel+bias; kernel var OIHW."""
+    off = conv(P, x, 2 * dg * 9, (3, 3), 1, name + "/conv2d", relu=False, init="zeros")
+    w = P.get(name + "/kernel", (num_outputs, x.shape[-1], 3, 3), "glorot_oihw")
+    y = deform_conv_forward(x.permute(0, 3, 1, 2), w, off.permute(0, 3, 1, 2), 1, 1, dg).permute(0, 2, 3, 1)
+    if not no_bias:
+        y = y + P.get(name + "/bias", (num_outputs,), "zeros")
+    return y
+
+
+def se_inception_block_v2(P, x, name):
+    """DAN-Deform context module V2 — net/danet_deform.py:267-290."""
+    c = x.shape[-1]
+    d = conv(P, x, 256, (1, 1), 1, name + "/conv_1x1_down", relu=True)
+    y = deform_conv_2d(P, d, 256, name + "/deform_conv", dg=4, no_bias=False)
+    return conv(P, torch.relu(y), c, (1, 1), 1, name + "/conv_1x1_up", relu=True) + x
+
+
+def get_features_stage1(P, feats, block, name="prediction_modules_stage1"):
+    """net/danet.py:920-929 / net/danet_deform.py:292-301."""
+    return [block(P, f, "{}/predict_stage1_{}".format(name, i)) for i, f in enumerate(feats)]
+
+
+def get_features_stage2(P, stage1, feats, block, name="prediction_modules_stage2"):
+    """net/danet.py:931-954: stop_gradient(stage1) -> 1x1 C//3; backbone feat -> 1x1 C - C//3; concat; block."""
+    outs = []
+    for i, f in enumerate(feats):
+        c = f.shape[-1]
+        s1 = conv(P, stage1[i].detach(), c // 3, (1, 1), 1, "{}/satge1_conv_1x1_{}".format(name, i), relu=True)
+        rs = conv(P, f, c - c // 3, (1, 1), 1, "{}/residual_conv_1x1_{}".format(name, i), relu=True)
+        outs.append(block(P, torch.cat([s1, rs], dim=-1), "{}/predict_stage2_{}".format(name, i)))
+    return outs
+
+
+def flatten_preds(preds, k):
+    """reshape_pred — train_dan.py:340-355 / train_sfd.py:293-304: [B,H,W,A*k] -> [B, HW*A, k], concat levels."""
+    b = preds[0].shape[0]
+    return torch.cat([p.reshape(b, -1, k) for p in preds], dim=1)
+
+
+# ------------------------------------------------------------------ whole-model forwards
+def sfd_forward(P, x):
+    """train_sfd.py:286-304 / eval_sfd.py:262-283: returns (loc [B,A,4], cls [B,A,2])."""
+    feats = get_featmaps(P, x)
+    loc, cls = predict_module(P, feats, [1] * 6, [3] + [1] * 5, [1] * 6, "multibox_head")
+    return flatten_preds(loc, 4), flatten_preds(cls, 2)
+
+
+def pb_forward(P, x):
+    """train_pb.py:396-420: face head on all 6 levels, head head on levels 1.., body head on levels 2..."""
+    feats = get_featmaps(P, x)
+    feats = build_lfpn(P, feats, skip_last=3, name="lfpn")
+    feats = context_pred_module(P, feats)
+    fl, fc = predict_module(P, feats, [1] + [3] * 5, [3] + [1] * 5, [1] * 6, "predict_face")
+    hl, hc = predict_module(P, feats[1:], [1] * 5, [1] * 5, [1] * 5, "predict_head")
+    bl, bc = predict_module(P, feats[2:], [1] * 4, [1] * 4, [1] * 4, "predict_body")
+    return {"face": (flatten_preds(fl, 4), flatten_preds(fc, 2)),
+            "head": (flatten_preds(hl, 4), flatten_preds(hc, 2)),
+            "body": (flatten_preds(bl, 4), flatten_preds(bc, 2))}
+
+
+def dan_forward(P, x, deform=False):
+    """train_dan.py:410-428 / eval_dan.py:316-371: two-stage heads; returns stage-1 and stage-2 (loc, cls)."""
+    block = se_inception_block_v2 if deform else se_inception_block_v1
+    feats = get_featmaps(P, x)
+    feats = build_lfpn(P, feats, skip_last=3, name="lfpn", fused_channels=256)
+    s1 = get_features_stage1(P, feats, block)
+    s1p = build_lfpn(P, s1, skip_last=3, name="lfpn_stage1", fused_channels=256)
+    l1, c1 = predict_module(P, s1p, [1] * 6, [1] * 6, [1] * 6, "predict_face", shared_conv=True)
+    s2 = get_features_stage2(P, s1p, feats, block)   # stage 2 consumes the LFPN'd stage-1 maps (train_dan.py:423)
+    s2p = build_lfpn(P, s2, skip_last=3, name="lfpn_stage2", fused_channels=256)
+    l2, c2 = predict_module(P, s2p, [1] * 6, [3] + [1] * 5, [1] * 6, "predict_cascade", shared_conv=True)
+    return (flatten_preds(l1, 4), flatten_preds(c1, 2)), (flatten_preds(l2, 4), flatten_preds(c2, 2))
+
+
+def preprocess_synthetic(img_u8_rgb):
+    """preprocess_for_eval arithmetic — preprocessing/dan_preprocessing.py:55-57,755-758:
+    float - (R,G,B means), then RGB->BGR, no scaling.  img [B,H,W,3] uint8 RGB -> float32 BGR."""
+    means = torch.tensor([123.68, 116.78, 103.94])
+    x = img_u8_rgb.to(torch.float32) - means
+    return x.flip(-1).contiguous()

@@ -1,0 +1,97 @@
+"""Parity of the HIP implicit-GEMM convolution (fwd / data-grad / weight-grad, through the C ABI) against the CPU
+oracle's TF-SAME convolution.  bf16 storage + fp32 accumulate: inputs are rounded to bf16 first, the oracle then
+computes in fp32 on exactly those values, so the only differences are accumulation order and the final bf16
+rounding of the output: tolerance 2^-7 relative to the output scale (+ small abs)."""
+import pytest
+import torch
+
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, Cin, Cout, kh, kw, stride) — all 12 distinct backbone 3x3 shapes at reduced spatial size, 1x1, ragged edges
+SHAPES = [
+    (2, 24, 24, 64, 64, 3, 3, 1), (1, 20, 28, 64, 128, 3, 3, 1), (1, 16, 16, 128, 128, 3, 3, 1), (1, 16, 16, 128, 256, 3, 3, 1),
+    (2, 12, 12, 256, 256, 3, 3, 1), (1, 10, 10, 256, 512, 3, 3, 1), (1, 10, 10, 512, 512, 3, 3, 1), (1, 6, 6, 512, 1024, 3, 3, 1),
+    (1, 6, 6, 1024, 1024, 1, 1, 1), (1, 6, 6, 1024, 256, 1, 1, 1), (2, 20, 20, 256, 512, 3, 3, 2), (2, 10, 10, 128, 256, 3, 3, 2),
+    (1, 5, 5, 128, 256, 3, 3, 2), (1, 9, 7, 64, 64, 3, 3, 1), (1, 33, 17, 8, 64, 3, 3, 1), (1, 8, 8, 256, 8, 3, 3, 1),
+    (1, 8, 8, 512, 6, 3, 3, 1), (1, 12, 12, 64, 32, 3, 1, 1), (1, 12, 12, 64, 32, 1, 3, 1), (1, 7, 9, 72, 24, 3, 3, 1),
+]
+
+
+def _mk(shape, seed):
+    N, H, W, Cin, Cout, kh, kw, s = shape
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn((N, H, W, Cin), generator=g)).to(torch.bfloat16)
+    w = (torch.randn((kh, kw, Cin, Cout), generator=g) / (kh * kw * Cin) ** 0.5).to(torch.bfloat16).to(torch.float32)
+    b = torch.randn((Cout,), generator=g)
+    return x, w, b, s
+
+
+def _tol(ref):
+    return 2.0 ** -7 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_forward(shape, relu, dev):
+    from dan_amd import ops
+    x, w, b, s = _mk(shape, 1)
+    ref = T.conv2d_same(x.float(), w, b, stride=s, relu=relu)
+    y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=s, relu=relu)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= _tol(ref), (shape, err, _tol(ref))
+    y32 = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=s, relu=relu, out_f32=True)
+    err32 = (y32.cpu() - ref).abs().max().item()
+    assert err32 <= 2e-3 * max(1.0, ref.abs().max().item()), (shape, err32)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_backward(shape, dev):
+    from dan_amd import ops
+    x, w, b, s = _mk(shape, 2)
+    Cout = shape[4]
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = T.conv2d_same(xr, wr, br, stride=s, relu=False)
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    ref.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride=s, relu=False)
+    if Cout % 8 == 0:
+        y.backward(dy.to(dev))
+    else:
+        y.float().backward(dy.to(dev).float())
+    torch.cuda.synchronize()
+    for name, got, want in (("dx", xd.grad.float().cpu(), xr.grad), ("dw", wd.grad.cpu(), wr.grad), ("db", bd.grad.cpu(), br.grad)):
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= 2.0 ** -6 * scale + 2e-3, (shape, name, err, scale)
+
+
+def test_relu_mask_and_bias_grad(dev):
+    """ReLU backward uses the stored bf16 output as the mask; bias gradient = column sums of the masked gradient."""
+    from dan_amd import ops
+    x, w, b, s = _mk((2, 12, 12, 64, 64, 3, 3, 1), 5)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride=1, relu=True)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(torch.bfloat16)
+    y.backward(dy.to(dev))
+    mask = (y.detach().float().cpu() > 0).float()
+    dym = dy.float() * mask
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    T.conv2d_same(xr, wr, br, stride=1, relu=False).backward(dym)
+    for name, got, want in (("dx", xd.grad.float().cpu(), xr.grad), ("dw", wd.grad.cpu(), wr.grad), ("db", bd.grad.cpu(), br.grad)):
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= 2.0 ** -6 * scale + 2e-3, (name, err, scale)
