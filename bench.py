@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Headline benchmark: S3FD (VGG-16 backbone + 6 detection heads) 640x640 bf16 TRAINING throughput
+(forward + backward + gradient all-reduce + momentum-SGD step) in images/second, whole job.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one optimisation step on a synthetic batch of 16 images per GPU (BASELINE.json configs[1]); inputs
+(uint8 images, encoded anchor targets) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (PyTorch-CPU fp32 restatement of train_sfd.py's step; TF 1.8 is not installable offline) timed on
+    the host cores on a bounded sample: batch 1 at 640x640, fwd + bwd + momentum step."""
+    from oracle import nets as ON
+    from oracle import train as OT
+    torch.manual_seed(0)
+    P = ON.Params(create=True, seed=20180817)
+    B = 1
+    img = torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8)
+    x = ON.preprocess_synthetic(img)
+    with torch.no_grad():
+        ON.sfd_forward(P, x[:, :64, :64])
+    params = {n: v.clone().requires_grad_(True) for n, v in P.t.items()}
+    mom = {n: torch.zeros_like(v) for n, v in params.items()}
+    A = 34125
+    cls_t = torch.zeros((B, A), dtype=torch.int64)
+    cls_t[:, ::97] = 1
+    loc_t = torch.randn((B, A, 4))
+
+    def step():
+        PO = ON.Params(params)
+        loc, cls = ON.sfd_forward(PO, x)
+        ce, ll, _ = OT.detection_loss(cls, loc, cls_t, loc_t)
+        loss = ce + ll + OT.l2_regularizer(params)
+        grads = torch.autograd.grad(loss, list(params.values()))
+        with torch.no_grad():
+            OT.momentum_sgd_step({n: p for n, p in params.items()}, dict(zip(params.keys(), grads)), mom, 1e-4)
+
+    step()                                   # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d S3FD train steps (fwd+bwd+SGD), batch %d, 640x640 fp32, oracle/nets.py on PyTorch-CPU" % (n, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=16)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from dan_amd import ops, synthetic
+    from dan_amd.trainer import init_distributed
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+
+    rank, world, local = init_distributed()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local)
+    B, S = args.batch_per_gpu, args.size
+
+    model = SFDModel(device=dev)
+    trainer = SFDTrainer(model, world=world)
+    anchors = AnchorConfig(S, S, dev)
+    # synthetic shard of this rank (contiguous split of the global batch, tf_replicate_model_fn.py:458-498)
+    imgs = synthetic.make_images(B, S, S, dev, seed=synthetic.SEED + rank)
+    gts = synthetic.make_gt_boxes(B, S, S, seed=synthetic.SEED + 100 * rank)
+    loc_t, cls_t, _ = anchors.encode_batch(gts)     # input pipeline work (anchor encoding) — not part of the step
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(imgs, loc_t, cls_t)
+    barrier()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(imgs, loc_t, cls_t)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ce, ll, l2, total = trainer.losses()
+        # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
+        stats = []
+        for label, evs in prof.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            stats.append((ms, label, len(evs), fl))
+        stats.sort(reverse=True)
+        ms, label, n, fl = stats[0]
+        achieved = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // args.steps,
+                "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
+                "share_of_step_time": round(ms / (dt * 1e3), 4)}
+        out = {
+            "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "S3FD VGG-16 backbone + 6 detection heads, %dx%d bf16 training (fwd+bwd+SGD), batch %d per GPU" % (S, S, B),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors},
+            "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
+            "roofline": roof,
+            "kernels": [{"kernel": l, "ms_per_step": round(m / args.steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

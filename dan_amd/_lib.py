@@ -43,6 +43,12 @@ SIGNATURES = {
     "danhip_detection_loss_fwd": [P, P, P, P, P, P, P, P, I32, I32, P],
     "danhip_detection_loss_bwd": [P, P, P, P, P, P, P, FL, FL, I32, I32, P],
     "danhip_sgd_momentum_flat": [P, P, P, P, P, P, I32, I64, FL, FL, FL, P, P],
+    "danhip_anchors_generate": [P, P, P, P, P, P, I32, I32, I32, FL, FL, FL, I32, P],
+    "danhip_iou_matrix": [P, P, P, P, P, P, P, I32, I32, P],
+    "danhip_dual_max_match": [P, I32, I32, FL, FL, ctypes.c_int, P, P, P, ctypes.c_size_t, P],
+    "danhip_small_mining_match": [P, I32, I32, FL, FL, FL, I32, FL, P, P, P, ctypes.c_size_t, P],
+    "danhip_encode_anchors": [P, P, P, P, P, P, P, P, P, I32, FL, FL, FL, FL, FL, P],
+    "danhip_decode_anchors": [P, P, P, P, P, P, I32, I32, FL, FL, FL, FL, P],
 }
 
 _lib = None
@@ -62,6 +68,10 @@ def lib():
         L.danhip_last_error.restype = ctypes.c_char_p
         L.danhip_last_error.argtypes = []
         L.danhip_version.restype = ctypes.c_int
+        L.danhip_match_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_conv_kernel_label.restype = ctypes.c_char_p
+        L.danhip_conv_kernel_label.argtypes = [DESC, ctypes.c_int]
+        L.danhip_match_workspace_bytes.argtypes = [I32, I32]
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.restype = ctypes.c_int

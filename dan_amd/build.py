@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = ["hipcc"] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        extra = ["-ffp-contract=off"] if s.endswith("_exact.hip") else []   # bit-exact index/box kernels: no FMA contraction
+        cmd = ["hipcc"] + FLAGS + extra + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr))

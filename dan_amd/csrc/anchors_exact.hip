@@ -1,0 +1,354 @@
+// Anchor / box index-compare kernels (gfx950), bit-exact against the fp32 oracle (compiled with -ffp-contract=off:
+// no FMA contraction, IEEE divide).  fp32 + int32 only.
+//
+//   anchors_generate        <- utility/anchor_manipulator.py:163-198 (generate_anchors_by_offset, center2point)
+//   iou_matrix              <- utility/anchor_manipulator.py:24-52
+//   dual_max_match          <- utility/anchor_manipulator.py:54-105
+//   small_mining_match      <- cpp/ExtraLib/small_mining_match.cc:68-222 (SmallMiningMatch custom op)
+//   encode_anchors          <- utility/anchor_manipulator.py:294-326 / :358-387 (tail after matching)
+//   decode_anchors          <- utility/anchor_manipulator.py:389-424
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ anchors
+// one thread per anchor of one level; order (y, x, depth); out = 4 separate arrays at offset `off`
+__global__ void anchors_generate_kernel(float* ymin, float* xmin, float* ymax, float* xmax, const float* __restrict__ ah,
+                                        const float* __restrict__ aw, int depth, int lh, int lw, float stride, float offset_h, float offset_w,
+                                        int off) {
+  const int total = lh * lw * depth;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int d = i % depth, cell = i / depth;
+    const int x = cell % lw, y = cell / lw;
+    const float cy = ((float)y + offset_h) * stride;
+    const float cx = ((float)x + offset_w) * stride;
+    const float hh = (ah[d] - 1.f) / 2.f, hw = (aw[d] - 1.f) / 2.f;
+    ymin[off + i] = cy - hh;
+    xmin[off + i] = cx - hw;
+    ymax[off + i] = cy + hh;
+    xmax[off + i] = cx + hw;
+  }
+}
+
+// ------------------------------------------------------------------ IoU matrix [A,G] (+1 box convention), x inside_mask
+__global__ void iou_matrix_kernel(const float* __restrict__ ymin, const float* __restrict__ xmin, const float* __restrict__ ymax,
+                                  const float* __restrict__ xmax, const unsigned char* __restrict__ inside, const float* __restrict__ gt,
+                                  float* __restrict__ ov, int A, int G) {
+  const long total = (long)A * G;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(idx / G), g = (int)(idx % G);
+    const float ay0 = ymin[a], ax0 = xmin[a], ay1 = ymax[a], ax1 = xmax[a];
+    const float gy0 = gt[g * 4], gx0 = gt[g * 4 + 1], gy1 = gt[g * 4 + 2], gx1 = gt[g * 4 + 3];
+    const float h = fmaxf(fminf(ay1, gy1) - fmaxf(ay0, gy0) + 1.f, 0.f);
+    const float w = fmaxf(fminf(ax1, gx1) - fmaxf(ax0, gx0) + 1.f, 0.f);
+    const float inter = h * w;
+    const float area_a = (ax1 - ax0 + 1.f) * (ay1 - ay0 + 1.f);
+    const float area_g = (gx1 - gx0 + 1.f) * (gy1 - gy0 + 1.f);
+    const float uni = area_a + area_g - inter;
+    float v = (uni == 0.f) ? 0.f : inter / uni;
+    if (inside) v = v * (inside[a] ? 1.f : 0.f);
+    ov[idx] = v;
+  }
+}
+
+// order-preserving float <-> int key (for atomicMax on floats of any sign)
+__device__ __forceinline__ int fkey(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// column maxima colmax[g] = max_a ov[a,g]   (ws_colkey must be pre-set to INT_MIN)
+__global__ void colmax_kernel(const float* __restrict__ ov, int* __restrict__ colkey, int A, int G) {
+  extern __shared__ int sk[];
+  for (int g = threadIdx.x; g < G; g += blockDim.x) sk[g] = INT_MIN;
+  __syncthreads();
+  const long total = (long)A * G;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+    atomicMax(&sk[idx % G], fkey(ov[idx]));
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) atomicMax(&colkey[g], sk[g]);
+}
+
+// ------------------------------------------------------------------ dual-max matching (one thread per anchor)
+__global__ void dual_max_match_kernel(const float* __restrict__ ov, const int* __restrict__ colkey, int* __restrict__ midx,
+                                      float* __restrict__ mscore, int A, int G, float low, float high, int ignore_between) {
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
+    const float* row = ov + (long)a * G;
+    int best = 0;
+    float bv = row[0];
+    for (int g = 1; g < G; ++g) if (row[g] > bv) { bv = row[g]; best = g; }      // tf.argmax: first maximum
+    const bool less = bv < low, between = (bv < high) && (bv >= low);
+    const bool neg = ignore_between ? less : between, ign = ignore_between ? between : less;
+    int idx = neg ? -1 : best;
+    if (ign) idx = -2;
+    // gt side: every anchor that equals a column maximum is forced to the highest-IoU such gt
+    bool any = false;
+    int pick = 0;
+    float pv = 0.f;
+    bool first = true;
+    for (int g = 0; g < G; ++g) {
+      const bool tie = row[g] == fkey_inv(colkey[g]);
+      any = any || tie;
+      const float v = row[g] * (tie ? 1.f : 0.f);
+      if (first || v > pv) { pv = v; pick = g; first = false; }
+    }
+    if (any) { midx[a] = pick; mscore[a] = row[pick]; }
+    else { midx[a] = idx; mscore[a] = row[best]; }
+  }
+}
+
+// ------------------------------------------------------------------ small-mining matching
+// phase 1 + 2 (one thread per anchor; per-gt counters via atomics: increments commute, so the totals equal the
+// reference's sequential loop)
+__global__ void smm_phase12_kernel(const float* __restrict__ ov, const int* __restrict__ colkey, int* __restrict__ midx,
+                                   float* __restrict__ mscore, int* __restrict__ cnt, int A, int G, float neg_low, float neg_high,
+                                   float pos_thres) {
+  const float eps = 1.1920928955078125e-07f;  // std::numeric_limits<float>::epsilon()
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
+    const float* row = ov + (long)a * G;
+    int best = 0;
+    float bs = -3.4028234663852886e+38f;
+    for (int g = 0; g < G; ++g) if (row[g] > bs) { best = g; bs = row[g]; }
+    float sc = bs;
+    int idx;
+    if (bs >= neg_low && bs < neg_high) idx = -1;
+    else if (bs >= pos_thres) idx = best;
+    else idx = -2;
+    // phase 2, restricted to this anchor's row: gts in ascending order, later gts overwrite earlier ones.
+    // candidate <=> |ov - colmax| < eps (the running-max pre-filter of the reference is implied by this test)
+    for (int g = 0; g < G; ++g) {
+      const float s = row[g];
+      if (fabsf(s - fkey_inv(colkey[g])) < eps) { sc = s; idx = g; }
+    }
+    // net effect of phase 1's increment and phase 2's decrement/increment pairs: the final gt counts this anchor once
+    if (idx > -1) atomicAdd(&cnt[idx], 1);
+    midx[a] = idx;
+    mscore[a] = sc;
+  }
+}
+
+// phase 3 (hard-face compensation): ONE workgroup, gts processed in order because each gt's picks remove anchors from
+// the later gts' candidate sets.  Candidates are compacted in ascending anchor order and pushed/popped through a binary
+// max-heap with exactly libstdc++'s std::push_heap / std::pop_heap element moves (comparator: a < b <=> b.dist > a.dist),
+// so equal-IoU candidates come out in the same order as the reference's std::priority_queue.
+struct HeapItem { int anchor; float dist; };
+__device__ __forceinline__ bool heap_less(const HeapItem& a, const HeapItem& b) { return b.dist > a.dist; }
+__device__ void heap_push(HeapItem* h, int len_after, HeapItem v) {     // element already counted in len_after
+  int hole = len_after - 1;
+  int parent = (hole - 1) / 2;
+  while (hole > 0 && heap_less(h[parent], v)) { h[hole] = h[parent]; hole = parent; parent = (hole - 1) / 2; }
+  h[hole] = v;
+}
+__device__ void heap_pop(HeapItem* h, int len_before) {                  // removes the top; heap shrinks by one
+  const int len = len_before - 1;
+  if (len <= 0) return;
+  const HeapItem v = h[len];
+  int hole = 0, child = 0;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (heap_less(h[child], h[child - 1])) --child;
+    h[hole] = h[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    h[hole] = h[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;                                            // __push_heap(first, hole, 0, v)
+  while (hole > 0 && heap_less(h[parent], v)) { h[hole] = h[parent]; hole = parent; parent = (hole - 1) / 2; }
+  h[hole] = v;
+}
+
+__global__ void smm_phase3_kernel(const float* __restrict__ ov, int* __restrict__ midx, float* __restrict__ mscore, int* __restrict__ cnt,
+                                  HeapItem* __restrict__ heap, int A, int G, int min_match, float stop_pos) {
+  __shared__ int s_scan[1024];
+  __shared__ int s_total;
+  const int T = blockDim.x;
+  const int per = (A + T - 1) / T;
+  const int a0 = threadIdx.x * per, a1 = min(A, a0 + per);
+  for (int g = 0; g < G; ++g) {
+    __syncthreads();
+    if (cnt[g] >= min_match) continue;                     // uniform: cnt[g] is only written by thread 0 below, behind a barrier
+    int n = 0;
+    for (int a = a0; a < a1; ++a) n += (midx[a] < 0 && ov[(long)a * G + g] > stop_pos);
+    s_scan[threadIdx.x] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {                                 // exclusive scan (T <= 1024 ints; serial is fine here)
+      int run = 0;
+      for (int t = 0; t < T; ++t) { const int v = s_scan[t]; s_scan[t] = run; run += v; }
+      s_total = run;
+    }
+    __syncthreads();
+    int w = s_scan[threadIdx.x];
+    for (int a = a0; a < a1; ++a) {
+      const float s = ov[(long)a * G + g];
+      if (midx[a] < 0 && s > stop_pos) { heap[w].anchor = a; heap[w].dist = s; ++w; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int ncand = s_total;
+      // build by successive pushes in ascending anchor order (the list is reused in place as the heap)
+      for (int i = 1; i <= ncand; ++i) { const HeapItem v = heap[i - 1]; heap_push(heap, i, v); }
+      int len = ncand, c = cnt[g];
+      while (len > 0 && c < min_match) {
+        const HeapItem top = heap[0];
+        ++c;
+        mscore[top.anchor] = top.dist;
+        midx[top.anchor] = g;
+        heap_pop(heap, len);
+        --len;
+      }
+      cnt[g] = c;
+    }
+    __threadfence_block();
+  }
+}
+
+// ------------------------------------------------------------------ encode / decode
+__global__ void encode_anchors_kernel(const float* __restrict__ ymin, const float* __restrict__ xmin, const float* __restrict__ ymax,
+                                      const float* __restrict__ xmax, const float* __restrict__ gt, const int* __restrict__ midx,
+                                      float* __restrict__ targets, int* __restrict__ labels, float* __restrict__ matched, int A, float ps0,
+                                      float ps1, float ps2, float ps3, float scale) {
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
+    const int m = midx[a];
+    const bool pos = m > -1;
+    const int mi = pos ? m : 0;
+    labels[a] = (pos ? 1 : 0) + (m < -1 ? -1 : 0);
+    const float gy0 = gt[mi * 4], gx0 = gt[mi * 4 + 1], gy1 = gt[mi * 4 + 2], gx1 = gt[mi * 4 + 3];
+    const float gh = gy1 - gy0 + 1.f, gw = gx1 - gx0 + 1.f;
+    const float gcy = (gy0 + gy1) / 2.f, gcx = (gx0 + gx1) / 2.f;
+    const float ah = ymax[a] - ymin[a] + 1.f, aw = xmax[a] - xmin[a] + 1.f;
+    const float acy = (ymin[a] + ymax[a]) / 2.f, acx = (xmin[a] + xmax[a]) / 2.f;
+    const float t0 = (gcy - acy) / ah / ps0;
+    const float t1 = (gcx - acx) / aw / ps1;
+    const float t2 = logf(gh * scale / ah) / ps2;
+    const float t3 = logf(gw * scale / aw) / ps3;
+    const float f = pos ? 1.f : 0.f;
+    *reinterpret_cast<float4*>(targets + (long)a * 4) = make_float4(f * t0, f * t1, f * t2, f * t3);
+    if (matched) *reinterpret_cast<float4*>(matched + (long)a * 4) = make_float4(gy0 * f, gx0 * f, gy1 * f, gx1 * f);
+  }
+}
+
+__global__ void decode_anchors_kernel(const float* __restrict__ pred, const float* __restrict__ ymin, const float* __restrict__ xmin,
+                                      const float* __restrict__ ymax, const float* __restrict__ xmax, float* __restrict__ out, int B, int A,
+                                      float ps0, float ps1, float ps2, float ps3) {
+  const long total = (long)B * A;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const float4 p = *reinterpret_cast<const float4*>(pred + i * 4);
+    const float ah = ymax[a] - ymin[a] + 1.f, aw = xmax[a] - xmin[a] + 1.f;
+    const float acy = (ymin[a] + ymax[a]) / 2.f, acx = (xmin[a] + xmax[a]) / 2.f;
+    const float ph = expf(p.z * ps2) * ah;
+    const float pw = expf(p.w * ps3) * aw;
+    const float pcy = p.x * ps0 * ah + acy;
+    const float pcx = p.y * ps1 * aw + acx;
+    *reinterpret_cast<float4*>(out + i * 4) =
+        make_float4(pcy - (ph - 1.f) / 2.f, pcx - (pw - 1.f) / 2.f, pcy + (ph - 1.f) / 2.f, pcx + (pw - 1.f) / 2.f);
+  }
+}
+
+__global__ void fill_int_kernel(int* p, int v, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline int grid_for(long total, int block, int cap = 2048) {
+  long b = (total + block - 1) / block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int danhip_anchors_generate(float* ymin, float* xmin, float* ymax, float* xmax, const float* anchor_h, const float* anchor_w,
+                                       int32_t depth, int32_t layer_h, int32_t layer_w, float stride, float offset_h, float offset_w,
+                                       int32_t out_offset, void* stream) {
+  DH_REQUIRE(ymin && xmin && ymax && xmax && anchor_h && anchor_w && depth > 0 && layer_h > 0 && layer_w > 0 && out_offset >= 0, DANHIP_EINVAL,
+             "anchors_generate: bad arguments");
+  hipLaunchKernelGGL(anchors_generate_kernel, dim3(grid_for((long)layer_h * layer_w * depth, 256)), dim3(256), 0, (hipStream_t)stream, ymin, xmin,
+                     ymax, xmax, anchor_h, anchor_w, depth, layer_h, layer_w, stride, offset_h, offset_w, out_offset);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_iou_matrix(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const uint8_t* inside_mask,
+                                 const float* gt_boxes, float* overlaps, int32_t A, int32_t G, void* stream) {
+  DH_REQUIRE(ymin && xmin && ymax && xmax && gt_boxes && overlaps && A > 0 && G > 0, DANHIP_EINVAL, "iou_matrix: bad arguments");
+  hipLaunchKernelGGL(iou_matrix_kernel, dim3(grid_for((long)A * G, 256, 4096)), dim3(256), 0, (hipStream_t)stream, ymin, xmin, ymax, xmax,
+                     inside_mask, gt_boxes, overlaps, A, G);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" size_t danhip_match_workspace_bytes(int32_t A, int32_t G) { return sizeof(int) * (size_t)(2 * G + 16) + sizeof(HeapItem) * (size_t)A; }
+
+static int prep_colmax(const float* ov, int* colkey, int A, int G, hipStream_t s) {
+  hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(G, 256)), dim3(256), 0, s, colkey, INT_MIN, G);
+  hipLaunchKernelGGL(colmax_kernel, dim3(grid_for((long)A * G, 256, 512)), dim3(256), sizeof(int) * G, s, ov, colkey, A, G);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_dual_max_match(const float* overlaps, int32_t A, int32_t G, float low_thres, float high_thres, int ignore_between,
+                                     int32_t* match_indices, float* match_scores, void* workspace, size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(overlaps && match_indices && match_scores && workspace && A > 0 && G > 0, DANHIP_EINVAL, "dual_max_match: bad arguments");
+  DH_REQUIRE(G <= 8192, DANHIP_EINVAL, "dual_max_match: G=%d > 8192", G);
+  DH_REQUIRE(workspace_bytes >= danhip_match_workspace_bytes(A, G), DANHIP_EWORKSPACE, "dual_max_match: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int* colkey = reinterpret_cast<int*>(workspace);
+  int rc = prep_colmax(overlaps, colkey, A, G, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dual_max_match_kernel, dim3(grid_for(A, 128)), dim3(128), 0, s, overlaps, colkey, match_indices, match_scores, A, G, low_thres,
+                     high_thres, ignore_between);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+// SmallMiningMatch op: same inputs/attrs/outputs as cpp/ExtraLib/small_mining_match.cc:31-54.
+extern "C" int danhip_small_mining_match(const float* overlaps, int32_t A, int32_t G, float negative_low_thres, float negative_high_thres,
+                                         float positive_thres, int32_t min_match, float stop_positive_thres, int32_t* match_indices,
+                                         float* match_scores, void* workspace, size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(overlaps && match_indices && match_scores && workspace && A > 0 && G > 0, DANHIP_EINVAL, "small_mining_match: bad arguments");
+  // attribute validation as in SmallMiningMatchOp's constructor (small_mining_match.cc:291-306)
+  DH_REQUIRE(negative_low_thres >= 0.f && negative_low_thres < 1.f, DANHIP_EINVAL, "small_mining_match: negative_low_thres must be in [0,1)");
+  DH_REQUIRE(negative_high_thres > 0.f && negative_high_thres < 1.f, DANHIP_EINVAL, "small_mining_match: negative_high_thres must be in (0,1)");
+  DH_REQUIRE(positive_thres > 0.f && positive_thres < 1.f, DANHIP_EINVAL, "small_mining_match: positive_thres must be in (0,1)");
+  DH_REQUIRE(stop_positive_thres >= 0.f && stop_positive_thres < 1.f, DANHIP_EINVAL, "small_mining_match: stop_positive_thres must be in [0,1)");
+  DH_REQUIRE(min_match >= 0, DANHIP_EINVAL, "small_mining_match: min_match must be >= 0");
+  DH_REQUIRE(G <= 8192, DANHIP_EINVAL, "small_mining_match: G=%d > 8192", G);
+  DH_REQUIRE(workspace_bytes >= danhip_match_workspace_bytes(A, G), DANHIP_EWORKSPACE, "small_mining_match: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int* colkey = reinterpret_cast<int*>(workspace);
+  int* cnt = colkey + G;
+  HeapItem* heap = reinterpret_cast<HeapItem*>(colkey + 2 * G + 16 - ((2 * G) % 2));
+  int rc = prep_colmax(overlaps, colkey, A, G, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fill_int_kernel, dim3(grid_for(G, 256)), dim3(256), 0, s, cnt, 0, G);
+  hipLaunchKernelGGL(smm_phase12_kernel, dim3(grid_for(A, 128)), dim3(128), 0, s, overlaps, colkey, match_indices, match_scores, cnt, A, G,
+                     negative_low_thres, negative_high_thres, positive_thres);
+  DH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(smm_phase3_kernel, dim3(1), dim3(1024), 0, s, overlaps, match_indices, match_scores, cnt, heap, A, G, min_match,
+                     stop_positive_thres);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_encode_anchors(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const float* gt_boxes,
+                                     const int32_t* match_indices, float* targets, int32_t* labels, float* matched_gt, int32_t A,
+                                     float ps0, float ps1, float ps2, float ps3, float scale, void* stream) {
+  DH_REQUIRE(ymin && xmin && ymax && xmax && gt_boxes && match_indices && targets && labels && A > 0, DANHIP_EINVAL,
+             "encode_anchors: bad arguments");
+  hipLaunchKernelGGL(encode_anchors_kernel, dim3(grid_for(A, 256)), dim3(256), 0, (hipStream_t)stream, ymin, xmin, ymax, xmax, gt_boxes,
+                     match_indices, targets, labels, matched_gt, A, ps0, ps1, ps2, ps3, scale);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmin, const float* ymax, const float* xmax, float* boxes,
+                                     int32_t B, int32_t A, float ps0, float ps1, float ps2, float ps3, void* stream) {
+  DH_REQUIRE(pred && ymin && xmin && ymax && xmax && boxes && B > 0 && A > 0, DANHIP_EINVAL, "decode_anchors: bad arguments");
+  hipLaunchKernelGGL(decode_anchors_kernel, dim3(grid_for((long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, pred, ymin, xmin, ymax, xmax, boxes,
+                     B, A, ps0, ps1, ps2, ps3);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}

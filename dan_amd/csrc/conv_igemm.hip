@@ -335,6 +335,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
 }
 }  // namespace
 
+// Label of the kernel instance a forward (which=0) / data-gradient (which=1) call of this descriptor launches
+// (matches the demangled name rocprofv3 reports) — used by bench.py to attribute measured time.
+extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which) {
+  if (!d) return "";
+  const int cin = which == 0 ? d->Cin : round_up(d->Cout, 8);
+  const int cout = which == 0 ? d->Cout : d->Cin;
+  if (which == 1 && d->stride != 1) return "conv_bwd_data_strided_kernel";
+  const bool fast = cin % 64 == 0;
+  switch (pick_bn(cout)) {
+    case 128: return fast ? "conv_igemm_kernel<128, 128, 2, true>" : "conv_igemm_kernel<128, 128, 2, false>";
+    case 64: return fast ? "conv_igemm_kernel<256, 64, 1, true>" : "conv_igemm_kernel<256, 64, 1, false>";
+    case 32: return fast ? "conv_igemm_kernel<256, 32, 1, true>" : "conv_igemm_kernel<256, 32, 1, false>";
+    default: return fast ? "conv_igemm_kernel<256, 16, 1, true>" : "conv_igemm_kernel<256, 16, 1, false>";
+  }
+}
+
 extern "C" int danhip_pack_conv_weight(const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real, uint16_t* wf_packed,
                                        uint16_t* wb_packed, void* stream) {
   int rc = check_desc(d);

@@ -39,16 +39,16 @@ __global__ void head_split_fwd_kernel(const float* __restrict__ h, float* __rest
   }
 }
 
-// gradient of reduce_max is shared equally between tied maxima (TF / torch.amax semantics); dy bf16 [B*HW, Ch8]
+// gradient of reduce_max is shared equally between tied maxima (TF / torch.amax semantics); dy fp32 [B*HW, Ch]
 __global__ void head_split_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dloc, const float* __restrict__ dcls,
-                                      bf16_t* __restrict__ dy, int B, int HW, int Ch, int Ch8, int nneg, int npos, int A, int off) {
+                                      float* __restrict__ dy, int B, int HW, int Ch, int nneg, int npos, int A, int off) {
   const long total = (long)B * HW;
   for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long)gridDim.x * blockDim.x) {
     const int b = (int)(m / HW), p = (int)(m % HW);
     const float* r = h + m * Ch;
     const long a = (long)b * A + off + p;
-    bf16_t* o = dy + m * Ch8;
-    for (int i = 0; i < 4; ++i) o[i] = f2bf(dloc[a * 4 + i]);
+    float* o = dy + m * Ch;
+    for (int i = 0; i < 4; ++i) o[i] = dloc[a * 4 + i];
     for (int grp = 0; grp < 2; ++grp) {
       const int s = grp == 0 ? 4 : 4 + nneg, n = grp == 0 ? nneg : npos;
       float mx = r[s];
@@ -56,9 +56,8 @@ __global__ void head_split_bwd_kernel(const float* __restrict__ h, const float* 
       int cnt = 0;
       for (int i = 0; i < n; ++i) cnt += (r[s + i] == mx);
       const float g = dcls[a * 2 + grp] / (float)cnt;
-      for (int i = 0; i < n; ++i) o[s + i] = f2bf(r[s + i] == mx ? g : 0.f);
+      for (int i = 0; i < n; ++i) o[s + i] = r[s + i] == mx ? g : 0.f;
     }
-    for (int i = 4 + nneg + npos; i < Ch8; ++i) o[i] = 0;
   }
 }
 
@@ -245,13 +244,13 @@ extern "C" int danhip_head_split_fwd(const float* h, float* loc, float* cls, int
   return DANHIP_OK;
 }
 
-extern "C" int danhip_head_split_bwd(const float* h, const float* dloc, const float* dcls, uint16_t* dy, int32_t B, int32_t HW, int32_t Ch,
+extern "C" int danhip_head_split_bwd(const float* h, const float* dloc, const float* dcls, float* dy, int32_t B, int32_t HW, int32_t Ch,
                                      int32_t nneg, int32_t npos, int32_t A, int32_t anchor_offset, void* stream) {
   DH_REQUIRE(h && dloc && dcls && dy && B > 0 && HW > 0 && nneg >= 1 && npos >= 1 && Ch == 4 + nneg + npos, DANHIP_EINVAL,
              "head_split_bwd: bad arguments");
   DH_REQUIRE(anchor_offset >= 0 && anchor_offset + HW <= A, DANHIP_EINVAL, "head_split_bwd: anchor range out of bounds");
   hipLaunchKernelGGL(head_split_bwd_kernel, dim3(grid_for((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, h, dloc, dcls, dy, B, HW, Ch,
-                     (Ch + 7) / 8 * 8, nneg, npos, A, anchor_offset);
+                     nneg, npos, A, anchor_offset);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

@@ -43,6 +43,35 @@ def _grad_sink(p):
     return getattr(p, "_danhip_grad", None)
 
 
+# Optional per-kernel timing (bench.py): when PROFILE is a dict, every conv forward / stride-1 data-gradient launch is
+# bracketed by events on the launch stream and recorded under its kernel-instance label with its algorithmic FLOPs.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(torch.cuda.current_stream())
+    return e
+
+
+def _prof_end(e0, d, which):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record(torch.cuda.current_stream())
+    label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), which).decode()
+    cin = d.Cin if which == 0 else d.Cin   # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
+    flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
+    PROFILE.setdefault(label, []).append((e0, e1, flops))
+
+
+# Optional callback(param) invoked right after a layer's weight/bias gradients have been produced in backward
+# (the data-parallel trainer uses it to launch the bucketed gradient all-reduce while backward continues).
+GRAD_READY_HOOK = None
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
@@ -56,8 +85,10 @@ class _Conv2d(torch.autograd.Function):
         need_bwd = w.requires_grad or x.requires_grad
         wf, wb = pack_conv_weight(d, w.detach(), need_bwd=need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        e0 = _prof_begin()
         call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
              F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
+        _prof_end(e0, d, 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
         ctx.has_res = residual is not None
         ctx.w_param, ctx.b_param = w_param, b_param
@@ -99,7 +130,9 @@ class _Conv2d(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            e0 = _prof_begin()
             call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
+            _prof_end(e0, d, 1)
         dw = None
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(wp) if wp is not None else None
@@ -109,6 +142,8 @@ class _Conv2d(torch.autograd.Function):
                 dw = None
         if db_sink is not None:
             db = None
+        if GRAD_READY_HOOK is not None and wp is not None:
+            GRAD_READY_HOOK(wp)
         return dx, dw, db, None, None, None, dres, None, None
 
 
@@ -189,8 +224,7 @@ class _HeadSplit(torch.autograd.Function):
         (h,) = ctx.saved_tensors
         nneg, npos, off, A = ctx.cfg
         B, H, W, Ch = h.shape
-        ch8 = (Ch + 7) // 8 * 8
-        dy = torch.empty((B, H, W, ch8), dtype=torch.bfloat16, device=h.device)
+        dy = torch.empty((B, H, W, Ch), dtype=torch.float32, device=h.device)
         call("danhip_head_split_bwd", ptr(h), ptr(dloc.contiguous()), ptr(dcls.contiguous()), ptr(dy), B, H * W, Ch, nneg, npos, A, off, stream())
         return dy, dloc, dcls, None, None, None
 

@@ -1,0 +1,119 @@
+"""S3FD training / inference graph on libdanhip — the MI355X equivalent of the reference's train_sfd.py
+(input_pipeline anchor configuration :171-222 and sfd_model_fn :261-467) and eval_sfd.py's inference graph (:232-283).
+"""
+import torch
+
+from . import ops
+from .net import sfd_net
+from .net.variables import VariableStore
+from .trainer import FlatParams, GradBuckets, lr_schedule
+from .utility import anchor_manipulator
+
+ALL_ANCHOR_SCALES = [(16.,), (32.,), (64.,), (128.,), (256.,), (512.,)]
+ALL_EXTRA_SCALES = [(), (), (), (), (), ()]
+ALL_ANCHOR_RATIOS = [(1.,), (1.,), (1.,), (1.,), (1.,), (1.,)]
+ALL_LAYER_STRIDES = [4, 8, 16, 32, 64, 128]
+
+
+def layer_shapes(height, width):
+    """Feature pyramid sizes: stride-4 map after two SAME pools, then SAME pool / stride-2 convs (ceil division)."""
+    shapes = []
+    h, w = -(-height // 4), -(-width // 4)
+    for _ in range(6):
+        shapes.append((h, w))
+        h, w = -(-h // 2), -(-w // 2)
+    return shapes
+
+
+class AnchorConfig(object):
+    """train_sfd.py:173-203: encoder thresholds 0.4/0.4 (flags :88-90), prior scaling (0.1,0.1,0.2,0.2), border = image size."""
+
+    def __init__(self, height, width, device, match_threshold=0.4, neg_threshold=0.4, ratios=ALL_ANCHOR_RATIOS):
+        self.enc = anchor_manipulator.AnchorEncoder(match_threshold, neg_threshold, [0.1, 0.1, 0.2, 0.2], device=device)
+        self.shapes = layer_shapes(height, width)
+        hs, ws, ds = [], [], []
+        for i in range(6):
+            h, w, d = self.enc.get_anchors_width_height(ALL_ANCHOR_SCALES[i], ALL_EXTRA_SCALES[i], ratios[i])
+            hs.append(h); ws.append(w); ds.append(d)
+        self.depth = ds
+        self.anchors = self.enc.get_all_anchors((height, width), hs, ws, ds, [0.5] * 6, self.shapes, ALL_LAYER_STRIDES,
+                                                [float(height)] * 6, [False] * 6)
+        self.num_anchors_per_layer = [s[0] * s[1] * d for s, d in zip(self.shapes, ds)]
+        self.num_anchors = sum(self.num_anchors_per_layer)
+
+    def encode_batch(self, gt_boxes_list, match_mining=True):
+        """anchor_encoder_fn of train_sfd.py:206 applied per image -> loc_targets [B,A,4], cls_targets [B,A] int32, match_scores [B,A]."""
+        ymin, xmin, ymax, xmax, inside = self.anchors
+        loc, cls, sc = [], [], []
+        for b in gt_boxes_list:
+            t, l, s, _ = self.enc.encode_anchors(b.to(ymin.device), ymin, xmin, ymax, xmax, inside, match_mining=match_mining)
+            loc.append(t); cls.append(l); sc.append(s)
+        return torch.stack(loc), torch.stack(cls), torch.stack(sc)
+
+
+class SFDModel(object):
+    def __init__(self, device="cuda", seed=20180817):
+        self.vs = VariableStore(device=device, seed=seed)
+        self.backbone = sfd_net.VGG16Backbone("channels_last", variables=self.vs)
+
+    def forward(self, images_u8):
+        """train_sfd.py:286-304: returns (location_pred [B,A,4], cls_pred [B,A,2]) fp32."""
+        x = sfd_net.prepare_input(images_u8)
+        feats = self.backbone.get_featmaps(x, training=True)
+        return self.backbone.multibox_head(feats, [1] * 6, [3] + [1] * 5, [1] * 6)
+
+    @torch.no_grad()
+    def predict(self, images_u8, anchors):
+        """eval_sfd.py:262-283: (bboxes_pred [B,A,4], face scores [B,A])."""
+        loc, cls = self.forward(images_u8)
+        boxes = anchors.enc.batch_decode_anchors(loc, *anchors.anchors[:4])
+        return boxes, torch.softmax(cls, dim=-1)[..., 1]
+
+
+class SFDTrainer(object):
+    """sfd_model_fn (train_sfd.py:261-467) + Momentum optimizer; `world` ranks each see batch/world images."""
+
+    def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64)):
+        self.model = model
+        self.world = world
+        self.negative_ratio = negative_ratio
+        self.momentum = momentum
+        self.base_lr = base_lr
+        dev = model.vs.device
+        with torch.no_grad():       # create every variable (shapes do not depend on the image size)
+            model.forward(torch.zeros((1, init_hw[0], init_hw[1], 3), dtype=torch.uint8, device=dev))
+        self.flat = FlatParams(model.vs, weight_decay)
+        self.buckets = GradBuckets(self.flat)
+        self.param_name = {id(p): n for n, p in model.vs.named()}
+        self.step_no = 0
+        self.last = None
+
+    def _hook(self, p):
+        n = self.param_name.get(id(p))
+        if n is not None:
+            self.buckets.ready(n)
+
+    def train_step(self, images_u8, loc_targets, cls_targets):
+        """One optimisation step on this rank's shard.  Returns the device 4-vector [ce_sum, n_sel, loc_sum, n_pos]."""
+        self.flat.zero_grad()
+        self.buckets.begin_step()
+        ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
+        loc, cls = self.model.forward(images_u8)
+        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=1.0 / self.world)
+        acc.backward(torch.ones_like(acc))
+        ops.GRAD_READY_HOOK = None
+        self.buckets.finish()
+        lr = lr_schedule(self.step_no, self.base_lr)
+        # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
+        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0)
+        self.step_no += 1
+        self.last = acc
+        return acc
+
+    def losses(self):
+        """(cross_entropy, loc_loss, l2_loss, total) as python floats (synchronises)."""
+        ce_sum, n_sel, loc_sum, n_pos = [float(v) for v in self.last.tolist()]
+        ce = (self.negative_ratio + 1.0) * ce_sum / max(n_sel, 1.0)
+        loc = loc_sum / max(n_pos, 1.0)
+        l2 = float(self.flat.l2.item())
+        return ce, loc, l2, ce + loc + l2

@@ -1,0 +1,148 @@
+"""Training harness shared by the S3FD / PyramidBox / DAN model_fns: flat fp32 parameter / gradient / momentum
+buffers, fused momentum-SGD (+L2 term, bias-gradient x2) and data-parallel gradient all-reduce over RCCL.
+
+Replaces (semantics only) tf_replicate_model_fn.py:297-343,458-498,615-645 of the reference: each rank computes the
+gradient of loss_rank / N on its contiguous shard of the global batch; gradients are summed across ranks (one
+all-reduce per bucket of the flat gradient buffer, launched on a side stream as soon as the bucket's last gradient
+has been produced so it overlaps the remaining backward kernels); the update is applied identically on every rank.
+"""
+import ctypes
+import os
+
+import torch
+import torch.distributed as dist
+
+from ._lib import call, ptr, stream
+
+
+def lr_schedule(step, base_lr=1e-3, boundaries=(1000, 80000, 100000), factors=(0.1, 1.0, 0.1, 0.01), end_lr=1e-6):
+    """tf.train.piecewise_constant + floor — train_sfd.py:429-434 (flags :98-109)."""
+    i = 0
+    while i < len(boundaries) and step > boundaries[i]:
+        i += 1
+    return max(base_lr * factors[i], end_lr)
+
+
+class FlatParams(object):
+    """Packs every variable of a VariableStore into one contiguous fp32 buffer (same for gradients and momenta) and
+    re-points the nn.Parameters (and their .grad / gradient sinks) at views of it."""
+
+    def __init__(self, vs, weight_decay=5e-4):
+        named = vs.named()
+        dev = named[0][1].device
+        sizes = [p.numel() for _, p in named]
+        # every segment starts on a 64-element (256-byte) boundary so views stay 16-byte aligned
+        starts, off = [], 0
+        for n in sizes:
+            starts.append(off)
+            off += (n + 63) // 64 * 64
+        self.total = off
+        self.w = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        gm, wd = [], []
+        self.names, self.starts, self.sizes = [], starts, sizes
+        for (name, p), s, n in zip(named, starts, sizes):
+            self.w[s:s + n].copy_(p.data.reshape(-1))
+            p.data = self.w[s:s + n].view(p.shape)
+            p.grad = self.g[s:s + n].view(p.shape)
+            p._danhip_grad = p.grad
+            # gradient multipliers (train_sfd.py:436-439) and the L2 term (train_sfd.py:419-427)
+            gm.append(2.0 if "/bias" in name else 1.0)
+            if "bn" in name:                           # train_sfd.py:421 ('bn' not in trainable_var.name)
+                wd.append(0.0)
+            elif "l2_norm_layer" in name:
+                wd.append(0.2 * weight_decay)
+            elif "/bias" in name:
+                wd.append(0.0)
+            else:
+                wd.append(weight_decay)
+            self.names.append(name)
+        self.seg = torch.tensor(starts + [self.total], dtype=torch.int64, device=dev)
+        self.gmult = torch.tensor(gm, dtype=torch.float32, device=dev)
+        self.wdc = torch.tensor(wd, dtype=torch.float32, device=dev)
+        self.l2 = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def sgd_step(self, lr, momentum=0.9, grad_scale=1.0):
+        self.l2.zero_()
+        call("danhip_sgd_momentum_flat", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc), len(self.names),
+             self.total, float(lr), float(momentum), float(grad_scale), ptr(self.l2), stream())
+
+
+class GradBuckets(object):
+    """Bucketed all-reduce of the flat gradient buffer, overlapped with backward.
+
+    Variables are laid out in forward (creation) order, so backward completes them from the END of the buffer towards
+    the start; bucket b is reduced once backward has produced every gradient at or after its start offset.  The
+    trainer calls `ready(name)` from per-layer autograd hooks; reductions run on a dedicated side stream."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20):
+        self.flat = flat
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        per = max(1, bucket_bytes // 4)
+        self.bounds = []
+        end = flat.total
+        # walk segments backwards, closing a bucket once it holds >= per elements
+        cur_end = end
+        for s in reversed(flat.starts):
+            if cur_end - s >= per:
+                self.bounds.append((s, cur_end))
+                cur_end = s
+        if cur_end > 0:
+            self.bounds.append((0, cur_end))
+        self.comm_stream = torch.cuda.Stream() if self.enabled else None
+        self.pending = []
+        self.next_bucket = 0
+        self.start_of = {n: s for n, s in zip(flat.names, flat.starts)}
+        self.done_upto = flat.total
+
+    def begin_step(self):
+        self.next_bucket = 0
+        self.pending = []
+        self.done_upto = self.flat.total
+
+    def ready(self, name):
+        """Gradient of `name` (and of everything created after it) is final."""
+        if not self.enabled:
+            return
+        self.done_upto = min(self.done_upto, self.start_of[name])
+        self._launch_ready()
+
+    def _launch_ready(self):
+        while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][0] >= self.done_upto:
+            s, e = self.bounds[self.next_bucket]
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            self.next_bucket += 1
+
+    def finish(self):
+        if not self.enabled:
+            return
+        self.done_upto = 0
+        self._launch_ready()
+        for w in self.pending:
+            w.wait()
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+
+def init_distributed():
+    """One process per GPU (torchrun); backend 'nccl' is RCCL on ROCm.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local

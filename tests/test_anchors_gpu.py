@@ -1,0 +1,127 @@
+"""Bit-exact parity of the HIP anchor / matching / encode / decode kernels (through the C ABI) with the numpy + C++ oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import anchors as OA
+from oracle import extra_lib as OE
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(h, w, ratio):
+    from dan_amd.train_sfd import ALL_ANCHOR_SCALES, ALL_LAYER_STRIDES, layer_shapes
+    shapes = layer_shapes(h, w)
+    hs, ws, ds = [], [], []
+    for i in range(6):
+        a, b, d = OA.get_anchors_width_height(ALL_ANCHOR_SCALES[i], (), (ratio,))
+        hs.append(a); ws.append(b); ds.append(d)
+    return OA.get_all_anchors((h, w), hs, ws, ds, [0.5] * 6, shapes, ALL_LAYER_STRIDES, [float(h)] * 6, [False] * 6)
+
+
+def _gt(n, h, w, seed):
+    rng = np.random.RandomState(seed)
+    side = np.exp(rng.uniform(np.log(8), np.log(min(h, w) * 0.6), n))
+    cy, cx = rng.uniform(0, h, n), rng.uniform(0, w, n)
+    b = np.stack([cy - side / 2, cx - side / 2, cy + side / 2, cx + side / 2], -1)
+    b = np.round(np.clip(b, 0, [h - 1, w - 1, h - 1, w - 1])).astype(np.float32)
+    return b[(b[:, 2] - b[:, 0] > 3) & (b[:, 3] - b[:, 1] > 3)]
+
+
+@pytest.mark.parametrize("hw,ratio", [((640, 640), 1.0), ((640, 640), 0.8), ((320, 448), 1.0), ((101, 75), 0.8)])
+def test_anchor_generation_bit_exact(hw, ratio, dev):
+    from dan_amd.train_sfd import AnchorConfig
+    ref = _cfg(hw[0], hw[1], ratio)
+    cfg = AnchorConfig(hw[0], hw[1], dev, ratios=[(ratio,)] * 6)
+    for got, want in zip(cfg.anchors[:4], ref[:4]):
+        assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(cfg.anchors[4].cpu().numpy(), ref[4])
+    if hw == (640, 640):
+        assert cfg.num_anchors == 34125
+        if ratio == 1.0:   # KAT
+            assert [float(a[0]) for a in cfg.anchors[:4]] == [-5.5, -5.5, 9.5, 9.5]
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (1, 7), (2, 40), (3, 3)])
+def test_iou_and_matching_bit_exact(seed, n, dev):
+    from dan_amd.train_sfd import AnchorConfig
+    from dan_amd.utility import anchor_manipulator as AM
+    h = w = 320
+    ref = _cfg(h, w, 1.0)
+    cfg = AnchorConfig(h, w, dev)
+    gt = _gt(n, h, w, seed)
+    if gt.shape[0] == 0:
+        gt = np.asarray([[0, 0, 1, 1]], np.float32)
+    all_a = np.stack(ref[:4], -1)
+    ov_ref = OA.iou_matrix(all_a, gt) * ref[4].astype(np.float32)[:, None]
+    ov = AM.iou_matrix(cfg.anchors[:4], torch.from_numpy(gt).to(dev), cfg.anchors[4])
+    assert np.array_equal(ov.cpu().numpy(), ov_ref)
+    # small-mining match (S3FD / PB face): thresholds of train_sfd.py
+    i_ref, s_ref = OE.small_mining_match(ov_ref, 0., 0.4, 0.4, 6, 0.3)
+    i_got, s_got = AM.small_mining_match(ov, 0., 0.4, 0.4, 6, 0.3)
+    assert np.array_equal(i_got.cpu().numpy(), i_ref)
+    assert np.array_equal(s_got.cpu().numpy(), s_ref)
+    # dual-max match (DAN): 0.35 / 0.35
+    d_ref, ds_ref = OA.do_dual_max_match(ov_ref, 0.35, 0.35)
+    d_got, ds_got = AM.do_dual_max_match(ov, 0.35, 0.35)
+    assert np.array_equal(d_got.cpu().numpy().astype(np.int64), d_ref)
+    assert np.array_equal(ds_got.cpu().numpy(), ds_ref)
+
+
+def test_small_mining_match_kats_and_ties(dev):
+    """KAT 1 of SURVEY 8(c) (inputs from cpp/ExtraLib/test_op.py:41,56) + tie-heavy random matrices that exercise the
+    priority-queue order of the hard-face compensation phase."""
+    from dan_amd.utility import anchor_manipulator as AM
+    ov = np.array([[0.1, 0.4, 0.6, 0.2, 0.7], [0.5, 0.14, 0.76, 0.32, 0.47], [0.21, 0.94, 0.66, 0.22, 0.57],
+                   [0.91, 0.14, 0.26, 0.42, 0.67], [0.11, 0.84, 0.26, 0.42, 0.57]], np.float32)
+    for args in ((0., 0.6, 0.6, 5, 0.1), (0., 0.5, 0.5, 2, 0.1)):
+        i, s = AM.small_mining_match(torch.from_numpy(ov).to(dev), *args)
+        assert i.cpu().tolist() == [4, 2, 1, 3, 3]
+        assert np.array_equal(s.cpu().numpy(), np.array([0.7, 0.76, 0.94, 0.42, 0.42], np.float32))
+    rng = np.random.RandomState(11)
+    for trial in range(12):
+        A, G = int(rng.randint(50, 3000)), int(rng.randint(1, 30))
+        levels = np.asarray([0.0, 0.05, 0.31, 0.32, 0.35, 0.38, 0.41, 0.5, 0.7], np.float32)
+        ovr = levels[rng.randint(0, len(levels), (A, G))]          # many exact ties
+        ovr[rng.rand(A, G) < 0.7] = 0.0
+        i_ref, s_ref = OE.small_mining_match(ovr, 0., 0.4, 0.4, 6, 0.3)
+        i_got, s_got = AM.small_mining_match(torch.from_numpy(ovr).to(dev), 0., 0.4, 0.4, 6, 0.3)
+        assert np.array_equal(i_got.cpu().numpy(), i_ref), trial
+        assert np.array_equal(s_got.cpu().numpy(), s_ref), trial
+
+
+def test_dual_max_zero_column_quirk(dev):
+    """A gt overlapping no anchor (column max == 0) force-matches every zero-overlap anchor."""
+    from dan_amd.utility import anchor_manipulator as AM
+    ov = np.zeros((64, 3), np.float32)
+    ov[5, 0] = 0.5; ov[9, 2] = 0.7; ov[9, 0] = 0.2
+    r_i, r_s = OA.do_dual_max_match(ov, 0.35, 0.35)
+    g_i, g_s = AM.do_dual_max_match(torch.from_numpy(ov).to(dev), 0.35, 0.35)
+    assert np.array_equal(g_i.cpu().numpy().astype(np.int64), r_i) and np.array_equal(g_s.cpu().numpy(), r_s)
+
+
+@pytest.mark.parametrize("mining", [True, False])
+def test_encode_decode(mining, dev):
+    from dan_amd.train_sfd import AnchorConfig
+    h = w = 320
+    ref = _cfg(h, w, 1.0)
+    cfg = AnchorConfig(h, w, dev, match_threshold=0.4 if mining else 0.35, neg_threshold=0.4 if mining else 0.35)
+    gt = _gt(12, h, w, 5)
+    mf = (lambda ov: OE.small_mining_match(ov, 0., 0.4, 0.4, 6, 0.3)) if mining else (lambda ov: OA.do_dual_max_match(ov, 0.35, 0.35))
+    t_ref, l_ref, s_ref, m_ref = OA.encode_anchors(gt, ref[:4], ref[4], 0.4, 0.4, [0.1, 0.1, 0.2, 0.2], mf)
+    t, l, s, m = cfg.enc.encode_anchors(torch.from_numpy(gt).to(dev), *cfg.anchors, match_mining=mining)
+    assert np.array_equal(l.cpu().numpy().astype(np.int64), l_ref)
+    assert np.array_equal(s.cpu().numpy(), s_ref)
+    assert np.array_equal(m.cpu().numpy(), m_ref)
+    tg = t.cpu().numpy()
+    assert np.array_equal(tg[:, :2], t_ref[:, :2])                     # centre offsets: +,-,/ only -> bit exact
+    # log(): device logf vs numpy logf may differ in the last ulp; declared tolerance 2 ulp of the log value / 0.2
+    assert np.allclose(tg[:, 2:], t_ref[:, 2:], rtol=0, atol=4 * np.finfo(np.float32).eps * 5 * 4)
+    # decode: zero offsets return the anchors themselves (exp(0) = 1 exactly)
+    z = torch.zeros((2, cfg.num_anchors, 4), device=dev)
+    d0 = cfg.enc.batch_decode_anchors(z, *cfg.anchors[:4]).cpu().numpy()
+    assert np.array_equal(d0[0], OA.decode_anchors(np.zeros((cfg.num_anchors, 4), np.float32), ref[:4], [0.1, 0.1, 0.2, 0.2]))
+    p = (np.random.RandomState(3).randn(2, cfg.num_anchors, 4) * 0.5).astype(np.float32)
+    d_ref = OA.decode_anchors(p, ref[:4], [0.1, 0.1, 0.2, 0.2])
+    d = cfg.enc.batch_decode_anchors(torch.from_numpy(p).to(dev), *cfg.anchors[:4]).cpu().numpy()
+    assert np.allclose(d, d_ref, rtol=3e-7, atol=2e-4)               # expf last-ulp differences scaled by anchor size
