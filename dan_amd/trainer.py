@@ -93,7 +93,8 @@ class GradBuckets(object):
                 cur_end = s
         if cur_end > 0:
             self.bounds.append((0, cur_end))
-        self.comm_stream = torch.cuda.Stream() if self.enabled else None
+        self.on_gpu = flat.g.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.pending = []
         self.next_bucket = 0
         self.start_of = {n: s for n, s in zip(flat.names, flat.starts)}
@@ -114,10 +115,13 @@ class GradBuckets(object):
     def _launch_ready(self):
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][0] >= self.done_upto:
             s, e = self.bounds[self.next_bucket]
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+            if self.on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+            else:                                    # gloo / CPU tensors (unit tests)
                 self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
             self.next_bucket += 1
 
@@ -128,7 +132,8 @@ class GradBuckets(object):
         self._launch_ready()
         for w in self.pending:
             w.wait()
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
 def init_distributed():

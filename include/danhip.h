@@ -79,6 +79,84 @@ int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const
  * dy bf16 [M, C]; y bf16 [M, C] or NULL; db fp32 [C] or NULL. */
 int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_t M, int32_t C, void* stream);
 
+/* Kernel-instance label a forward (which=0) / data-gradient (which=1) call of this descriptor launches (the demangled
+ * name rocprofv3 reports) — lets bench.py attribute measured time to a kernel. */
+const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
+
+/* ------------------------------------------------------------------------------------------------
+ * HBM-bound layer kernels (bf16 NHWC, 16-byte vectors, wave reductions).
+ * ------------------------------------------------------------------------------------------------ */
+/* tf.layers.max_pooling2d([2,2],[2,2],'same') — net/sfd_net.py:132.  y [N,ceil(H/2),ceil(W/2),C]; C % 8 == 0.
+ * Backward: the gradient goes to the FIRST maximal element in window order (TF CPU kernel). */
+int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                          void* stream);
+/* VGG16Backbone.l2_normalize — net/sfd_net.py:68-79: y = x * rsqrt(max(sum_c x^2, 1e-10)) * gamma_c.
+ * x,y bf16 [M,C], gamma fp32 [C], C in {64,128,256,512,1024}.  bwd: dgamma += (atomic fp32), dx (=|+= if accumulate). */
+int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t* y, int64_t M, int32_t C, void* stream);
+int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const uint16_t* dy, uint16_t* dx, float* dgamma, int64_t M,
+                      int32_t C, int accumulate, void* stream);
+/* preprocess_for_eval arithmetic (preprocessing/dan_preprocessing.py:55-57,755-758): uint8 RGB [npix,3] ->
+ * bf16 [npix,8] = (B-103.94, G-116.78, R-123.68, 0,0,0,0,0). */
+int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64_t npix, void* stream);
+/* fp32 [rows,c_src] -> bf16 [rows,c_dst] zero padded (gradient of the fp32 head outputs). */
+int danhip_cast_pad_f32_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Detection heads glue, hard-negative mining, losses, optimizer (fp32 / int32).
+ * ------------------------------------------------------------------------------------------------ */
+/* Max-out + reshape_pred for one level with one anchor per cell (net/sfd_net.py:175-216; train_sfd.py:293-304):
+ * h fp32 [B*HW, Ch], channels [loc(4) | neg(nneg) | pos(npos)] -> loc [B,A,4], cls [B,A,2] rows [off, off+HW). */
+int danhip_head_split_fwd(const float* h, float* loc, float* cls, int32_t B, int32_t HW, int32_t Ch, int32_t nneg, int32_t npos,
+                          int32_t A, int32_t anchor_offset, void* stream);
+int danhip_head_split_bwd(const float* h, const float* dloc, const float* dcls, float* dy, int32_t B, int32_t HW, int32_t Ch,
+                          int32_t nneg, int32_t npos, int32_t A, int32_t anchor_offset, void* stream);
+/* Per-image hard-negative mining (train_sfd.py:350-384, train_dan.py:286-324): score = label==0 ? -softmax(cls)[0] : -1;
+ * k = min(int(ratio*n_pos), n_neg) (at_least_one: max(k,1)); thr[b] = exact k-th largest score of row b (radix select),
+ * +inf when k == 0.  cls fp32 [B,A,2], labels int32 [B,A] in {1,0,-1}; score [B,A], counts int32 [B,2], thr [B], k_out [B]. */
+int danhip_hard_neg_select(const float* cls, const int32_t* labels, float* score, int32_t* counts, float* thr, int32_t* k_out,
+                           int32_t B, int32_t A, float negative_ratio, int at_least_one, void* stream);
+/* acc4 = [sum CE over selected, #selected, sum smooth-L1 over positives, #positives]; sel uint8 [B,A] (0/1 neg/2 pos)
+ * (train_sfd.py:386-417).  bwd: dcls = (softmax-onehot)*ce_scale/#selected, dloc = dSmoothL1*loc_scale/#positives. */
+int danhip_detection_loss_fwd(const float* cls, const float* loc, const int32_t* labels, const float* loc_targets,
+                              const float* score, const float* thr, uint8_t* sel, float* acc4, int32_t B, int32_t A,
+                              void* stream);
+int danhip_detection_loss_bwd(const float* cls, const float* loc, const float* loc_targets, const uint8_t* sel,
+                              const float* acc4, float* dcls, float* dloc, float ce_scale, float loc_scale, int32_t B,
+                              int32_t A, void* stream);
+/* Fused multi-tensor momentum SGD over flat fp32 buffers (train_sfd.py:419-447): for element i of segment s
+ * (seg_starts[s] <= i < seg_starts[s+1]): g' = (g*grad_scale + wd_coef[s]*w) * gmult[s]; v = m*v + g'; w -= lr*v.
+ * l2_out (optional) += sum 0.5*wd_coef[s]*w^2 (the L2 loss term at the pre-update weights). */
+int danhip_sgd_momentum_flat(float* w, const float* g, float* v, const int64_t* seg_starts, const float* gmult,
+                             const float* wd_coef, int32_t nseg, int64_t total, float lr, float momentum, float grad_scale,
+                             float* l2_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anchor / box index-compare kernels (fp32 + int32, bit-exact vs the oracle; utility/anchor_manipulator.py).
+ * ------------------------------------------------------------------------------------------------ */
+/* generate_anchors_by_offset + center2point (anchor_manipulator.py:125-127,163-198) for one level, order (y,x,depth). */
+int danhip_anchors_generate(float* ymin, float* xmin, float* ymax, float* xmax, const float* anchor_h, const float* anchor_w,
+                            int32_t depth, int32_t layer_h, int32_t layer_w, float stride, float offset_h, float offset_w,
+                            int32_t out_offset, void* stream);
+/* iou_matrix (anchor_manipulator.py:24-52), optionally multiplied by inside_mask[a] (encode_anchors :287). [A,G]. */
+int danhip_iou_matrix(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const uint8_t* inside_mask,
+                      const float* gt_boxes, float* overlaps, int32_t A, int32_t G, void* stream);
+size_t danhip_match_workspace_bytes(int32_t A, int32_t G);
+/* do_dual_max_match (anchor_manipulator.py:54-105, gt_max_first=True). */
+int danhip_dual_max_match(const float* overlaps, int32_t A, int32_t G, float low_thres, float high_thres, int ignore_between,
+                          int32_t* match_indices, float* match_scores, void* workspace, size_t workspace_bytes, void* stream);
+/* SmallMiningMatch custom op (cpp/ExtraLib/small_mining_match.cc:31-54,68-222): same inputs, attrs, outputs. */
+int danhip_small_mining_match(const float* overlaps, int32_t A, int32_t G, float negative_low_thres, float negative_high_thres,
+                              float positive_thres, int32_t min_match, float stop_positive_thres, int32_t* match_indices,
+                              float* match_scores, void* workspace, size_t workspace_bytes, void* stream);
+/* Tail of encode_anchors / encode_pa_anchors after matching (anchor_manipulator.py:294-326, :358-387). */
+int danhip_encode_anchors(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const float* gt_boxes,
+                          const int32_t* match_indices, float* targets, int32_t* labels, float* matched_gt, int32_t A,
+                          float ps0, float ps1, float ps2, float ps3, float scale, void* stream);
+/* batch_decode_anchors / decode_anchors (anchor_manipulator.py:389-424). pred [B,A,4] -> boxes [B,A,4]. */
+int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmin, const float* ymax, const float* xmax,
+                          float* boxes, int32_t B, int32_t A, float ps0, float ps1, float ps2, float ps3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,10 @@ from .deform import deform_conv_forward
 
 
 class Params:
-    def __init__(self, tensors=None, create=False, seed=20180817, dtype=torch.float32):
+    def __init__(self, tensors=None, create=False, seed=20180817, dtype=torch.float32, emulate_bf16=False):
+        # emulate_bf16: round conv weights (straight-through), stored activations and their gradients to bf16, as the
+        # MI355X build stores them (fp32 accumulate everywhere) — used only to tighten parity tolerances.
+        self.emulate_bf16 = emulate_bf16
         self.t = dict(tensors or {})
         self.create = create
         self.gen = torch.Generator().manual_seed(seed)
@@ -48,6 +51,15 @@ def conv(P, x, filters, ksize, stride, scope, relu, init="glorot"):
     kh, kw = ksize
     w = P.get(scope + "/kernel", (kh, kw, x.shape[-1], filters), init)
     b = P.get(scope + "/bias", (filters,), "zeros")
+    if P.emulate_bf16:
+        w = T.round_bf16(w, True, False)                      # bf16 packed weights, fp32 master gradient
+        head = scope.rsplit("/", 1)[-1].startswith(("loc_", "cls_"))
+        y = T.conv2d_same(x, w, b, stride=stride, relu=False)
+        if head:                                              # head convs emit fp32; their incoming gradient is cast to bf16
+            return T.round_bf16(y, False, True)
+        y = T.round_bf16(y, False, True) if relu else y       # gradient w.r.t. the pre-activation is stored in bf16
+        y = torch.relu(y) if relu else y
+        return T.round_bf16(y, True, not relu)                # stored activation is bf16
     return T.conv2d_same(x, w, b, stride=stride, relu=relu)
 
 
@@ -71,13 +83,14 @@ def get_featmaps(P, x):
     x = conv_block(P, x, 2, 128, "conv2")
     x = T.max_pool_2x2_same(x)
     x = conv_block(P, x, 3, 256, "conv3")
-    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_3/weight", (256,), 10.0)))
+    l2n = (lambda a, g: T.round_bf16(T.l2_normalize(a, g), True, True)) if P.emulate_bf16 else T.l2_normalize
+    feats.append(l2n(x, P.get("l2_norm_layer_3/weight", (256,), 10.0)))
     x = T.max_pool_2x2_same(x)
     x = conv_block(P, x, 3, 512, "conv4")
-    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_4/weight", (512,), 8.0)))
+    feats.append(l2n(x, P.get("l2_norm_layer_4/weight", (512,), 8.0)))
     x = T.max_pool_2x2_same(x)
     x = conv_block(P, x, 3, 512, "conv5")
-    feats.append(T.l2_normalize(x, P.get("l2_norm_layer_5/weight", (512,), 5.0)))
+    feats.append(l2n(x, P.get("l2_norm_layer_5/weight", (512,), 5.0)))
     x = T.max_pool_2x2_same(x)
     x = conv_relu(P, x, 1024, (3, 3), 1, "fc6")
     x = conv_relu(P, x, 1024, (1, 1), 1, "fc7")

@@ -48,8 +48,8 @@ def test_sfd_train_step_parity(dev):
     tr = SFDTrainer(model, world=1)
     # ---- oracle loss + gradients (fp32)
     params = {n: v.clone().requires_grad_(True) for n, v in P.t.items()}
-    PO = ON.Params(params)
-    loc_ref, cls_ref = ON.sfd_forward(PO, x)
+    PO = ON.Params(params, emulate_bf16=True)          # same storage precision as the HIP path (bf16 weights/activations)
+    loc_ref, cls_ref = ON.sfd_forward(PO, x.to(torch.bfloat16).float())
     ce, locl, _ = OT.detection_loss(cls_ref, loc_ref, cls_t.cpu().long(), loc_t.cpu())
     (ce + locl).backward()
     w_before = {n: p.detach().clone().cpu() for n, p in model.vs.named()}
