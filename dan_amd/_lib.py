@@ -29,12 +29,12 @@ SIGNATURES = {
     "danhip_pack_conv_weight": [DESC, P, I32, P, P, P],
     "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
-    "danhip_conv2d_bwd_weight": [DESC, P, P, P, I32, P],
+    "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
-    "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, P],
+    "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
     "danhip_l2norm_fwd": [P, P, P, I64, I32, P],
-    "danhip_l2norm_bwd": [P, P, P, P, P, I64, I32, ctypes.c_int, P],
+    "danhip_l2norm_bwd": [P, P, P, P, P, I64, I32, ctypes.c_int, ctypes.c_int, P],
     "danhip_preprocess_u8": [P, P, I64, P],
     "danhip_cast_pad_f32_to_bf16": [P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],

@@ -31,6 +31,8 @@ struct ConvArgs {
   int M, Kpad, ktiles, taps, cpt;
   FastDiv div_wo, div_howo, div_c, div_kw;
   int relu, out_f32, accumulate;
+  int dshift;    // log2(dstride)
+  int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
 };
 
 template <int BM, int BN, int WN_WAVES, bool FAST>
@@ -93,8 +95,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (FAST) {
 #pragma unroll
       for (int j = 0; j < RA; ++j) {
-        const int hi = rh[j] + ti, wi = rw[j] + tj;
-        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        int hi = rh[j] + ti, wi = rw[j] + tj;
+        bool ok = true;
+        if (a.dstride > 1) {                            // transposed (fractionally strided) gather
+          ok = ((hi | wi) & (a.dstride - 1)) == 0 && hi >= 0 && wi >= 0;
+          hi >>= a.dshift; wi >>= a.dshift;
+        }
+        ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
         const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + c0 + schunk * 8) : zero;
         glds16(src, sA + (j * 32 + wave * 8) * 128);
       }
@@ -107,8 +114,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const bool tapok = (int)tap < a.taps;
 #pragma unroll
       for (int j = 0; j < RA; ++j) {
-        const int hi = rh[j] + i, wi = rw[j] + jj;
-        const bool ok = tapok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        int hi = rh[j] + i, wi = rw[j] + jj;
+        bool ok = tapok;
+        if (a.dstride > 1) {
+          ok = ok && ((hi | wi) & (a.dstride - 1)) == 0 && hi >= 0 && wi >= 0;
+          hi >>= a.dshift; wi >>= a.dshift;
+        }
+        ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
         const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + cc) : zero;
         glds16(src, sA + (j * 32 + wave * 8) * 128);
       }
@@ -341,7 +353,7 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
   if (!d) return "";
   const int cin = which == 0 ? d->Cin : round_up(d->Cout, 8);
   const int cout = which == 0 ? d->Cout : d->Cin;
-  if (which == 1 && d->stride != 1) return "conv_bwd_data_strided_kernel";
+  if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
   const bool fast = cin % 64 == 0;
   switch (pick_bn(cout)) {
     case 128: return fast ? "conv_igemm_kernel<128, 128, 2, true>" : "conv_igemm_kernel<128, 128, 2, false>";
@@ -388,7 +400,7 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   a.ktiles = a.Kpad / 64;
   a.cpt = a.C / 64;
   a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
-  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
+  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0; a.dstride = 1; a.dshift = 0;
   return launch_conv(a, (hipStream_t)stream);
 }
 
@@ -445,7 +457,8 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
   const int co8 = round_up(d->Cout, 8);
   const int taps = d->kh * d->kw;
   const int pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride), pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
-  if (d->stride != 1) {
+  const bool pow2 = (d->stride & (d->stride - 1)) == 0;
+  if (d->stride != 1 && !pow2) {
     const long total = (long)d->N * d->H * d->W * (d->Cin / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
@@ -460,6 +473,8 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
   a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = co8; a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin;
   a.kh = d->kh; a.kw = d->kw; a.stride = 1;
   a.pad_t = d->kh - 1 - pad_t; a.pad_l = d->kw - 1 - pad_l;
+  a.dstride = d->stride; a.dshift = 0;
+  while ((1 << a.dshift) < d->stride) ++a.dshift;
   a.M = d->N * d->H * d->W;
   a.taps = taps;
   a.Kpad = round_up(taps * co8, 64);

@@ -14,6 +14,7 @@ struct WgradArgs {
   const bf16_t* x;     // [N,H,W,C]
   const bf16_t* dy;    // [N,Ho,Wo,Co8]
   float* dw;           // [kh,kw,cin_real,Cout]
+  float* db;           // [Cout] bias gradient (column sums of dy) or null
   int N, H, W, C, Ho, Wo, Co8, Cout, cin_real;
   int kh, kw, stride, pad_t, pad_l;
   int M, ktiles, kt_per_split;
@@ -109,6 +110,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
 
+  // Bias gradient db[co] = sum_m dy[m][co] rides along as one extra MFMA row of ones (no extra pass over dy): done by
+  // the wci == 0 waves of the blocks that own tap 0 / input-channel tile 0.
+  const bool do_bias = a.db != nullptr && blockIdx.y == 0 && ci_tile == 0 && wci == 0;
+  f32x4 accb[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
   stage(kt_begin, 0);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int buf = (kt - kt_begin) & 1;
@@ -151,6 +162,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int o = 0; o < NO; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[o], acc[i][o], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) accb[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[o], accb[o], 0, 0, 0);
+      }
+    }
+  }
+  if (do_bias && g == 0) {                                // every row of accb holds the column sums; take row 0
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const int co = co0 + wco * TCO + o * 16 + (lane & 15);
+      if (co < a.Cout) atomicAdd(a.db + co, accb[o][0]);
     }
   }
 
@@ -196,15 +218,15 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, int32_t cin_real,
-                                        void* stream) {
+extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                        int32_t cin_real, void* stream) {
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
   DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
              "conv2d_bwd_weight: Ho/Wo mismatch");
   WgradArgs a{};
-  a.x = x; a.dy = dy; a.dw = dw_hwio;
+  a.x = x; a.dy = dy; a.dw = dw_hwio; a.db = db;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Co8 = (d->Cout + 7) / 8 * 8;
   a.cin_real = cin_real;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;

@@ -93,7 +93,7 @@ __global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
 
 // backward: the gradient goes to the FIRST maximal element in window order (0,0),(0,1),(1,0),(1,1)
 __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H, int W,
-                                   int C, int Ho, int Wo) {
+                                   int C, int Ho, int Wo, int accumulate) {
   const int cg = C / 8;
   const long total = (long)N * Ho * Wo * cg;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -128,7 +128,16 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* _
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int h = ho * 2 + (t >> 1), w = wo * 2 + (t & 1);
-      if (in[t]) *reinterpret_cast<uint4*>(dx + (((long)n * H + h) * W + w) * C + g * 8) = pack8(o[t]);
+      if (in[t]) {
+        uint4* dst = reinterpret_cast<uint4*>(dx + (((long)n * H + h) * W + w) * C + g * 8);
+        if (accumulate) {
+          float old[8];
+          unpack8(*dst, old);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[t][i] += old[i];
+        }
+        *dst = pack8(o[t]);
+      }
     }
   }
 }
@@ -158,7 +167,7 @@ __global__ void l2norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __r
 // dgamma[c] += sum_pix dy*x*inv.  dx is ACCUMULATED into (the tapped map also feeds the next conv block).
 template <int CPL>
 __global__ void l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const bf16_t* __restrict__ dy,
-                                  bf16_t* __restrict__ dx, float* __restrict__ dgamma, long M, int C, int accumulate) {
+                                  bf16_t* __restrict__ dx, float* __restrict__ dgamma, long M, int C, int accumulate, int relu_mask) {
   extern __shared__ float sg[];                           // [waves][C] partial dgamma
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float dg[CPL];
@@ -179,6 +188,7 @@ __global__ void l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __r
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       float v = gamma[lane * CPL + i] * inv * g[i] - f[i] * k;
+      if (relu_mask && !(f[i] > 0.f)) v = 0.f;            // x is a ReLU output: fold the producer's ReLU backward in
       if (accumulate) v += bf2f(dx[o + i]);
       dx[o + i] = f2bf(v);
       dg[i] += g[i] * f[i] * inv;
@@ -247,11 +257,11 @@ extern "C" int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, 
 }
 
 extern "C" int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
-                                     void* stream) {
+                                     int accumulate, void* stream) {
   DH_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool2x2_bwd: bad arguments (C%%8)");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const long total = (long)N * Ho * Wo * (C / 8);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo, accumulate);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -273,7 +283,7 @@ extern "C" int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t
 }
 
 extern "C" int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const uint16_t* dy, uint16_t* dx, float* dgamma, int64_t M,
-                                 int32_t C, int accumulate, void* stream) {
+                                 int32_t C, int accumulate, int relu_mask, void* stream) {
   DH_REQUIRE(x && gamma && dy && dx && dgamma && M > 0, DANHIP_EINVAL, "l2norm_bwd: bad arguments");
   DH_REQUIRE(C == 256 || C == 512 || C == 1024 || C == 128 || C == 64, DANHIP_EINVAL, "l2norm_bwd: C=%d unsupported", C);
   long blocks = (M + 3) / 4;
@@ -281,11 +291,11 @@ extern "C" int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const ui
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = 4 * (size_t)C * sizeof(float);
   switch (C / 64) {
-    case 1: hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
-    case 2: hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
-    case 4: hipLaunchKernelGGL(l2norm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
-    case 8: hipLaunchKernelGGL(l2norm_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
-    default: hipLaunchKernelGGL(l2norm_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate); break;
+    case 1: hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 2: hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 4: hipLaunchKernelGGL(l2norm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 8: hipLaunchKernelGGL(l2norm_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    default: hipLaunchKernelGGL(l2norm_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
   }
   DH_LAUNCH_CHECK();
   return DANHIP_OK;

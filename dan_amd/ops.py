@@ -72,11 +72,52 @@ def _prof_end(e0, d, which):
 GRAD_READY_HOOK = None
 
 
+
+class GradSlot(object):
+    """Direct gradient hand-off between this package's ops, bypassing autograd's per-edge tensors.
+
+    Every activation produced here carries a slot.  In backward, a consumer that knows the slot writes (first delivery)
+    or accumulates (later deliveries) its input-gradient contribution straight into the slot's buffer — already
+    multiplied by (x > 0) when x is a ReLU output, which folds the producer's ReLU backward into the consumer's
+    epilogue — and returns None to autograd.  The producer's backward then takes the buffer.  Consumers that do not
+    know about slots (plain torch ops) still work: their gradient arrives through autograd and is merged in."""
+
+    __slots__ = ("shape", "dtype", "device", "is_relu", "buf", "count")
+
+    def __init__(self, t, is_relu):
+        self.shape, self.dtype, self.device, self.is_relu = t.shape, t.dtype, t.device, is_relu
+        self.buf, self.count = None, 0
+
+    def target(self):
+        """-> (buffer, accumulate flag) for the next delivery."""
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+            self.count = 0
+        acc = 1 if self.count > 0 else 0
+        self.count += 1
+        return self.buf, acc
+
+    def take(self):
+        b, n = self.buf, self.count
+        self.buf, self.count = None, 0
+        return b if n > 0 else None
+
+
+def _slot_of(t):
+    return getattr(t, "_dh_slot", None)
+
+
+def _attach_slot(t, is_relu):
+    s = GradSlot(t, is_relu)
+    t._dh_slot = s
+    return s
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == torch.bfloat16 and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
@@ -90,6 +131,8 @@ class _Conv2d(torch.autograd.Function):
              F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
         _prof_end(e0, d, 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
+        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.set_materialize_grads(False)
         ctx.has_res = residual is not None
         ctx.w_param, ctx.b_param = w_param, b_param
         ctx.save_for_backward(x, wb, y if relu else None)
@@ -102,106 +145,175 @@ class _Conv2d(torch.autograd.Function):
         d = ctx.d
         co8 = (d.Cout + 7) // 8 * 8
         M = d.N * d.Ho * d.Wo
-        if dy.dtype != torch.bfloat16 or dy.shape[-1] != co8:
-            # fp32 / unpadded upstream gradient (head convs): cast + pad channels to a multiple of 8
-            src = dy.contiguous().to(torch.float32)
-            dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=torch.bfloat16, device=dy.device)
-            call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(dyp), M, d.Cout, co8, stream())
-            dy = dyp
-            owned = True
-        else:
-            dy = dy.contiguous()
-            owned = False
-        dres = dy if ctx.has_res else None          # residual is added after the activation
         wp, bp = ctx.w_param, ctx.b_param
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        db = None
         db_sink = _grad_sink(bp) if bp is not None else None
+        db = None
         if need_db:
-            db = db_sink if db_sink is not None else torch.zeros(d.Cout, dtype=torch.float32, device=dy.device)
-        if ctx.relu or need_db:
-            if ctx.relu and not owned:
-                dy = dy.clone()                      # the incoming gradient tensor may be shared with other consumers
-            call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y) if ctx.relu else None, ptr(db) if (need_db and co8 == d.Cout) else None,
-                 M, co8, stream())
-            if need_db and co8 != d.Cout:            # padded head gradient: reduce the real channels with torch (tiny)
-                s = dy.view(M, co8)[:, :d.Cout].to(torch.float32).sum(0)
-                db.add_(s)
+            db = db_sink if db_sink is not None else torch.zeros(d.Cout, dtype=torch.float32, device=x.device)
+        # ---- gather the output gradient: slot deliveries (already ReLU-masked) and/or the autograd tensor
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        dres = None
+        if dy is not None:
+            if ctx.has_res:
+                dres = dy                                # residual is added after the activation
+            if dy.dtype != torch.bfloat16 or dy.shape[-1] != co8:
+                # fp32 / unpadded upstream gradient (head convs): cast + pad channels to a multiple of 8
+                src = dy.contiguous().to(torch.float32)
+                dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=torch.bfloat16, device=dy.device)
+                call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(dyp), M, d.Cout, co8, stream())
+                dy, owned = dyp, True
+            else:
+                dy, owned = dy.contiguous(), False
+            if ctx.relu:
+                if not owned:
+                    dy = dy.clone()                      # the incoming gradient tensor may be shared with other consumers
+                call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
+            g = dy if g is None else g.add_(dy)
+        if g is None:                                    # no gradient reached this layer
+            return (None,) * 11
+        db_in_wgrad = need_db and ctx.needs_input_grad[1]       # the weight-gradient kernel also emits the bias gradient
+        if need_db and not db_in_wgrad:
+            if co8 == d.Cout:
+                call("danhip_relu_bwd_bias_grad", ptr(g), None, ptr(db), M, co8, stream())
+            else:
+                db.add_(g.view(M, co8)[:, :d.Cout].to(torch.float32).sum(0))
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            e0 = _prof_begin()
-            call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
-            _prof_end(e0, d, 1)
+            xs = ctx.xslot
+            if xs is not None:                           # deliver straight into the producer's slot (+ its ReLU backward)
+                buf, acc = xs.target()
+                e0 = _prof_begin()
+                call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, stream())
+                _prof_end(e0, d, 1)
+            else:
+                dx = torch.empty_like(x)
+                e0 = _prof_begin()
+                call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, stream())
+                _prof_end(e0, d, 1)
         dw = None
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(wp) if wp is not None else None
-            dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=dy.device)
-            call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ctx.cin_real, stream())
+            dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
+            call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real, stream())
             if sink is not None:
                 dw = None
         if db_sink is not None:
             db = None
         if GRAD_READY_HOOK is not None and wp is not None:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None
 
 
 def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None):
     wp = w if isinstance(w, torch.nn.Parameter) else None
     bp = b if isinstance(b, torch.nn.Parameter) else None
-    return _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp)
+    track = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    if track and relu and residual is not None:
+        raise NotImplementedError("relu + fused residual needs a separate ReLU mask in backward (y > 0 is not the mask)")
+    yslot = GradSlot.__new__(GradSlot) if (track and not out_f32) else None
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot)
+    if yslot is not None:
+        yslot.__init__(y, relu)
+        y._dh_slot = yslot
+    return y
 
 
 class _MaxPool(torch.autograd.Function):
     """tf.layers.max_pooling2d([2,2],[2,2],'same') — net/sfd_net.py:132."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, xslot, yslot):
         N, H, W, C = x.shape
         y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
         call("danhip_maxpool2x2_fwd", ptr(x), ptr(y), N, H, W, C, stream())
         ctx.save_for_backward(x)
+        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         N, H, W, C = x.shape
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return None, None, None
+        if ctx.xslot is not None:
+            # the pooled maximum is > 0 exactly where its source is, so a gradient masked at the pooled level scatters to
+            # an already ReLU-masked gradient; an unmasked one (autograd path) is masked by the producer's own backward
+            buf, acc = ctx.xslot.target() if _pool_deliver_ok(ctx, dy) else (None, 0)
+            if buf is not None:
+                call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(buf), N, H, W, C, acc, stream())
+                return None, None, None
         dx = torch.empty_like(x)
-        call("danhip_maxpool2x2_bwd", ptr(x), ptr(dy.contiguous()), ptr(dx), N, H, W, C, stream())
-        return dx
+        call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(dx), N, H, W, C, 0, stream())
+        return dx, None, None
+
+
+def _pool_deliver_ok(ctx, dy):
+    # direct delivery into a ReLU slot requires every contribution to be masked already, i.e. no raw autograd gradient
+    return not (ctx.xslot.is_relu and dy is not None)
 
 
 def max_pool_2x2(x):
-    return _MaxPool.apply(x)
+    track = torch.is_grad_enabled() and x.requires_grad
+    xs = _slot_of(x) if track else None
+    yslot = GradSlot.__new__(GradSlot) if track else None
+    y = _MaxPool.apply(x, xs, yslot)
+    if yslot is not None:
+        # consumers may mask by (pooled > 0) when the source is a ReLU output
+        yslot.__init__(y, xs.is_relu if xs is not None else False)
+        y._dh_slot = yslot
+    return y
 
 
 class _L2Norm(torch.autograd.Function):
     """VGG16Backbone.l2_normalize — net/sfd_net.py:68-79."""
 
     @staticmethod
-    def forward(ctx, x, gamma, g_param):
+    def forward(ctx, x, gamma, g_param, xslot, yslot):
         y = torch.empty_like(x)
         M = x.numel() // x.shape[-1]
         call("danhip_l2norm_fwd", ptr(x), ptr(gamma.detach()), ptr(y), M, x.shape[-1], stream())
         ctx.save_for_backward(x, gamma.detach())
         ctx.g_param = g_param
+        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.set_materialize_grads(False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
         M = x.numel() // x.shape[-1]
-        dx = torch.empty_like(x)
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return None, None, None, None, None
         sink = _grad_sink(ctx.g_param) if ctx.g_param is not None else None
         dg = sink if sink is not None else torch.zeros_like(gamma)
-        call("danhip_l2norm_bwd", ptr(x), ptr(gamma), ptr(dy.contiguous()), ptr(dx), ptr(dg), M, x.shape[-1], 0, stream())
-        return dx, (None if sink is not None else dg), None
+        xs = ctx.xslot
+        if xs is not None:
+            buf, acc = xs.target()
+            call("danhip_l2norm_bwd", ptr(x), ptr(gamma), ptr(g), ptr(buf), ptr(dg), M, x.shape[-1], acc, 1 if xs.is_relu else 0, stream())
+            dx = None
+        else:
+            dx = torch.empty_like(x)
+            call("danhip_l2norm_bwd", ptr(x), ptr(gamma), ptr(g), ptr(dx), ptr(dg), M, x.shape[-1], 0, 0, stream())
+        return dx, (None if sink is not None else dg), None, None, None
 
 
 def l2_normalize(x, gamma):
-    return _L2Norm.apply(x, gamma, gamma if isinstance(gamma, torch.nn.Parameter) else None)
+    track = torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad)
+    yslot = GradSlot.__new__(GradSlot) if track else None
+    y = _L2Norm.apply(x, gamma, gamma if isinstance(gamma, torch.nn.Parameter) else None, _slot_of(x) if track else None, yslot)
+    if yslot is not None:
+        yslot.__init__(y, False)
+        y._dh_slot = yslot
+    return y
 
 
 class _HeadSplit(torch.autograd.Function):

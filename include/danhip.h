@@ -71,8 +71,9 @@ int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const 
                            const uint16_t* relu_mask, uint16_t* dx, int accumulate, void* stream);
 
 /* dw_hwio fp32 [kh,kw,Cin,Cout] += sum_pixels x (x) dy   (atomic fp32 accumulation: zero it first).
+ * db (optional) fp32 [Cout] += sum_pixels dy  (bias gradient, computed by the same kernel: no extra pass over dy).
  * cin_real: number of leading input channels that exist in dw (dw is [kh,kw,cin_real,Cout]). */
-int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio,
+int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
                              int32_t cin_real, void* stream);
 
 /* In place: dy *= (y > 0) (ReLU backward) when y != NULL; db[c] += sum over pixels of the masked dy.
@@ -90,12 +91,13 @@ const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
  * Backward: the gradient goes to the FIRST maximal element in window order (TF CPU kernel). */
 int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
-                          void* stream);
+                          int accumulate, void* stream);
 /* VGG16Backbone.l2_normalize — net/sfd_net.py:68-79: y = x * rsqrt(max(sum_c x^2, 1e-10)) * gamma_c.
- * x,y bf16 [M,C], gamma fp32 [C], C in {64,128,256,512,1024}.  bwd: dgamma += (atomic fp32), dx (=|+= if accumulate). */
+ * x,y bf16 [M,C], gamma fp32 [C], C in {64,128,256,512,1024}.  bwd: dgamma += (atomic fp32), dx (=|+= if accumulate);
+ * relu_mask: x is a ReLU output, so dx is also multiplied by (x > 0) (the producer's ReLU backward folded in). */
 int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t* y, int64_t M, int32_t C, void* stream);
 int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const uint16_t* dy, uint16_t* dx, float* dgamma, int64_t M,
-                      int32_t C, int accumulate, void* stream);
+                      int32_t C, int accumulate, int relu_mask, void* stream);
 /* preprocess_for_eval arithmetic (preprocessing/dan_preprocessing.py:55-57,755-758): uint8 RGB [npix,3] ->
  * bf16 [npix,8] = (B-103.94, G-116.78, R-123.68, 0,0,0,0,0). */
 int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64_t npix, void* stream);
