@@ -1,0 +1,88 @@
+// Shared between the convolution kernels (conv_igemm.hip: flat-M implicit GEMM; conv_halo.hip: halo-reuse 3x3).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  const bf16_t* mask;
+  const bf16_t* resid;
+  void* y;
+  int N, H, W, C;
+  int Ho, Wo, Co;
+  int kh, kw, stride, pad_t, pad_l;
+  int M, Kpad, ktiles, taps, cpt;
+  FastDiv div_wo, div_howo, div_c, div_kw;
+  int relu, out_f32, accumulate;
+  int dshift;    // log2(dstride)
+  int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
+};
+
+// Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
+// eligible (caller falls back to the flat-M kernel), negative on a launch error.
+int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
+const char* danhip_conv_halo_label(const ConvArgs& a);   // kernel-instance label or nullptr when not eligible
+
+// Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
+__device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {
+  if (co >= a.Co) return;
+  const size_t o = m * (size_t)a.Co + co;
+  const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
+  if (a.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (co + r < a.Co) v[r] += a.bias[co + r];
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  }
+  if (a.out_f32) {
+    float* y = reinterpret_cast<float*>(a.y) + o;
+    if (full) {
+      float4 t = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.accumulate) { float4 u = *reinterpret_cast<float4*>(y); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      *reinterpret_cast<float4*>(y) = t;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (co + r < a.Co) y[r] = a.accumulate ? y[r] + v[r] : v[r];
+    }
+  } else {
+    bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
+    if (full) {
+      if (a.mask) {
+        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+        const bf16_t* mp = reinterpret_cast<const bf16_t*>(&mk);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+      }
+      if (a.resid) {
+        const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + o);
+        const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
+      }
+      if (a.accumulate) {
+        const uint2 old = *reinterpret_cast<const uint2*>(y);
+        const bf16_t* op = reinterpret_cast<const bf16_t*>(&old);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
+      }
+      uint2 t;
+      t.x = pack2bf(v[0], v[1]);
+      t.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(y) = t;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (co + r < a.Co) {
+          float t = v[r];
+          if (a.mask && !(bf2f(a.mask[o + r]) > 0.f)) t = 0.f;
+          if (a.resid) t += bf2f(a.resid[o + r]);
+          if (a.accumulate) t += bf2f(y[r]);
+          y[r] = f2bf(t);
+        }
+      }
+    }
+  }
+}

@@ -14,26 +14,10 @@
 //
 // Pipeline: two LDS stages; tile k+1's DMA is issued before tile k's MFMAs (one barrier per K tile);
 // two workgroups per CU overlap each other's barrier stalls.
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
-struct ConvArgs {
-  const bf16_t* x;
-  const bf16_t* w;
-  const float* bias;
-  const bf16_t* mask;
-  const bf16_t* resid;
-  void* y;
-  int N, H, W, C;
-  int Ho, Wo, Co;
-  int kh, kw, stride, pad_t, pad_l;
-  int M, Kpad, ktiles, taps, cpt;
-  FastDiv div_wo, div_howo, div_c, div_kw;
-  int relu, out_f32, accumulate;
-  int dshift;    // log2(dstride)
-  int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
-};
 
 template <int BM, int BN, int WN_WAVES, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
@@ -271,6 +255,8 @@ int launch_cfg(const ConvArgs& a, bool fast, hipStream_t s) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
+  const int hr = danhip_launch_conv_halo(a, s);        // 3x3 / stride-1 on large maps: halo-reuse kernel
+  if (hr <= 0) return hr;
   const bool fast = (a.C % 64 == 0);
   switch (pick_bn(a.Co)) {
     case 128: return launch_cfg<128, 128, 2>(a, fast, s);
@@ -347,6 +333,45 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
 }
 }  // namespace
 
+
+namespace {
+// ConvArgs of a forward call / of a stride-1 (or power-of-two strided) data-gradient call of descriptor d.
+ConvArgs fwd_args(const danhip_conv_desc* d) {
+  ConvArgs a{};
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Cout;
+  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
+  a.pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride);
+  a.pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
+  a.M = d->N * d->Ho * d->Wo;
+  a.taps = d->kh * d->kw;
+  a.Kpad = round_up(a.taps * a.C, 64);
+  a.ktiles = a.Kpad / 64;
+  a.cpt = a.C / 64;
+  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
+  a.dstride = 1; a.dshift = 0;
+  return a;
+}
+ConvArgs bwd_args(const danhip_conv_desc* d) {
+  ConvArgs a{};
+  const int co8 = round_up(d->Cout, 8);
+  const int taps = d->kh * d->kw;
+  const int pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride), pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
+  // a forward convolution of dy with the tap-flipped, transposed weights; pad' = k-1-pad
+  a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = co8; a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin;
+  a.kh = d->kh; a.kw = d->kw; a.stride = 1;
+  a.pad_t = d->kh - 1 - pad_t; a.pad_l = d->kw - 1 - pad_l;
+  a.dstride = d->stride; a.dshift = 0;
+  while ((1 << a.dshift) < d->stride) ++a.dshift;
+  a.M = d->N * d->H * d->W;
+  a.taps = taps;
+  a.Kpad = round_up(taps * co8, 64);
+  a.ktiles = a.Kpad / 64;
+  a.cpt = a.C / 64;
+  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
+  return a;
+}
+}  // namespace
+
 // Label of the kernel instance a forward (which=0) / data-gradient (which=1) call of this descriptor launches
 // (matches the demangled name rocprofv3 reports) — used by bench.py to attribute measured time.
 extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which) {
@@ -354,6 +379,11 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
   const int cin = which == 0 ? d->Cin : round_up(d->Cout, 8);
   const int cout = which == 0 ? d->Cout : d->Cin;
   if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
+  {
+    const ConvArgs a = which == 0 ? fwd_args(d) : bwd_args(d);
+    const char* hl = danhip_conv_halo_label(a);
+    if (hl) return hl;
+  }
   const bool fast = cin % 64 == 0;
   switch (pick_bn(cout)) {
     case 128: return fast ? "conv_igemm_kernel<128, 128, 2, true>" : "conv_igemm_kernel<128, 128, 2, false>";
@@ -388,19 +418,9 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd: null pointer");
   DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
   DH_REQUIRE(!(residual && out_dtype == DANHIP_F32), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
-  ConvArgs a{};
+  ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Cout;
-  a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
-  a.pad_t = same_pad_before(d->H, d->Ho, d->kh, d->stride);
-  a.pad_l = same_pad_before(d->W, d->Wo, d->kw, d->stride);
-  a.M = d->N * d->Ho * d->Wo;
-  a.taps = d->kh * d->kw;
-  a.Kpad = round_up(a.taps * a.C, 64);
-  a.ktiles = a.Kpad / 64;
-  a.cpt = a.C / 64;
-  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
-  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0; a.dstride = 1; a.dshift = 0;
+  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
   return launch_conv(a, (hipStream_t)stream);
 }
 
@@ -467,20 +487,8 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
     DH_LAUNCH_CHECK();
     return DANHIP_OK;
   }
-  // stride 1: a forward convolution of dy with the tap-flipped, transposed weights; pad' = k-1-pad
-  ConvArgs a{};
+  ConvArgs a = bwd_args(d);
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = relu_mask; a.resid = nullptr; a.y = dx;
-  a.N = d->N; a.H = d->Ho; a.W = d->Wo; a.C = co8; a.Ho = d->H; a.Wo = d->W; a.Co = d->Cin;
-  a.kh = d->kh; a.kw = d->kw; a.stride = 1;
-  a.pad_t = d->kh - 1 - pad_t; a.pad_l = d->kw - 1 - pad_l;
-  a.dstride = d->stride; a.dshift = 0;
-  while ((1 << a.dshift) < d->stride) ++a.dshift;
-  a.M = d->N * d->H * d->W;
-  a.taps = taps;
-  a.Kpad = round_up(taps * co8, 64);
-  a.ktiles = a.Kpad / 64;
-  a.cpt = a.C / 64;
-  a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
   return launch_conv(a, (hipStream_t)stream);
 }

@@ -16,6 +16,10 @@ SHAPES = [
     (1, 6, 6, 1024, 1024, 1, 1, 1), (1, 6, 6, 1024, 256, 1, 1, 1), (2, 20, 20, 256, 512, 3, 3, 2), (2, 10, 10, 128, 256, 3, 3, 2),
     (1, 5, 5, 128, 256, 3, 3, 2), (1, 9, 7, 64, 64, 3, 3, 1), (1, 33, 17, 8, 64, 3, 3, 1), (1, 8, 8, 256, 8, 3, 3, 1),
     (1, 8, 8, 512, 6, 3, 3, 1), (1, 12, 12, 64, 32, 3, 1, 1), (1, 12, 12, 64, 32, 1, 3, 1), (1, 7, 9, 72, 24, 3, 3, 1),
+    # shapes routed to the halo-reuse 3x3 kernel: full tiles, ragged edges, 16x16 tiles, several chunks, and enough
+    # items (> 256) that every persistent workgroup walks more than one (XCD-grouped mapping, NB = 2)
+    (1, 16, 32, 64, 128, 3, 3, 1), (2, 30, 62, 128, 64, 3, 3, 1), (1, 32, 48, 256, 256, 3, 3, 1), (8, 64, 128, 64, 256, 3, 3, 1),
+    (5, 56, 96, 128, 128, 3, 3, 1),
 ]
 
 

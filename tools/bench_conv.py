@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Per-layer microbenchmark of the libdanhip convolution kernels (through the C ABI), with a quick numerical check.
+
+    python tools/bench_conv.py [--set s3fd|pb|small] [--iters 20] [--check] [--which fwd,dgrad,wgrad]
+
+Reports, per shape, the mean launch duration (HIP events on the launch stream) and algorithmic TFLOP/s
+(2*N*Ho*Wo*Cin*Cout*kh*kw per launch).  Random N(0,1) bf16 data (never zeros: DVFS, cdna_hip_programming.md rule 25).
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from dan_amd import ops
+from dan_amd._lib import BF16, call, lib, ptr, stream
+
+# (name, N, H, W, Cin, Cout, k, stride)
+S3FD = [
+    ("conv1_2", 16, 640, 640, 64, 64, 3, 1), ("conv2_1", 16, 320, 320, 64, 128, 3, 1), ("conv2_2", 16, 320, 320, 128, 128, 3, 1),
+    ("conv3_1", 16, 160, 160, 128, 256, 3, 1), ("conv3_2", 16, 160, 160, 256, 256, 3, 1), ("conv4_1", 16, 80, 80, 256, 512, 3, 1),
+    ("conv4_2", 16, 80, 80, 512, 512, 3, 1), ("conv5_1", 16, 40, 40, 512, 512, 3, 1), ("fc6", 16, 20, 20, 512, 1024, 3, 1),
+    ("fc7", 16, 20, 20, 1024, 1024, 1, 1),
+]
+PB = [
+    ("cpm160_a", 4, 160, 160, 256, 1024, 3, 1), ("cpm160_b", 4, 160, 160, 1024, 256, 3, 1), ("cpm80_a", 4, 80, 80, 512, 1024, 3, 1),
+    ("lat160", 16, 160, 160, 256, 256, 1, 1),
+]
+SMALL = [("s64", 2, 32, 64, 64, 64, 3, 1), ("s128", 2, 24, 40, 128, 128, 3, 1), ("s256", 1, 48, 48, 256, 256, 3, 1)]
+
+
+def run(shape, iters, which, check):
+    name, N, H, W, Cin, Cout, k, s = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((k, k, Cin, Cout), generator=g) / (k * k * Cin) ** 0.5).to(torch.bfloat16).float().to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    d = ops._desc(N, H, W, Cin, Cout, k, k, s)
+    wf, wb = ops.pack_conv_weight(d, w, need_bwd=True)
+    y = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.bfloat16, device=dev)
+    dy = torch.randn((N, d.Ho, d.Wo, Cout), generator=g).to(torch.bfloat16).to(dev)
+    dx = torch.empty_like(x)
+    dw = torch.zeros((k, k, Cin, Cout), dtype=torch.float32, device=dev)
+    db = torch.zeros((Cout,), dtype=torch.float32, device=dev)
+    flops = 2.0 * N * d.Ho * d.Wo * Cin * Cout * k * k
+
+    def fwd():
+        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b), ptr(y), BF16, 1, None, stream())
+
+    def dgrad():
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 0, stream())
+
+    def wgrad():
+        call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, stream())
+
+    fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}
+    out = []
+    for wname in which:
+        fn = fns[wname]
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        label = ""
+        if wname != "wgrad":
+            label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else 1).decode()
+        out.append((wname, ms, flops / ms / 1e9, label))
+    errs = {}
+    if check:
+        import torch.nn.functional as F
+        pt = max((d.Ho - 1) * s + k - H, 0)
+        pl = max((d.Wo - 1) * s + k - W, 0)
+        xn = F.pad(x.float().permute(0, 3, 1, 2), (pl // 2, pl - pl // 2, pt // 2, pt - pt // 2))
+        xn.requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        ref = F.conv2d(xn, wr.permute(3, 2, 0, 1), b, stride=s)
+        refr = torch.relu(ref).permute(0, 2, 3, 1)
+        fwd()
+        errs["fwd"] = ((y.float() - refr).abs().max() / refr.abs().max()).item()
+        ref.backward(dy.float().permute(0, 3, 1, 2))
+        dgrad()
+        gx = xn.grad[:, :, pt // 2:pt // 2 + H, pl // 2:pl // 2 + W].permute(0, 2, 3, 1) * (x.float() > 0)
+        errs["dgrad"] = ((dx.float() - gx).abs().max() / gx.abs().max()).item()
+        dw.zero_(); db.zero_()
+        wgrad()
+        errs["wgrad"] = ((dw - wr.grad).abs().max() / wr.grad.abs().max()).item()
+        errs["db"] = ((db - dy.float().sum((0, 1, 2))).abs().max() / dy.float().sum((0, 1, 2)).abs().max()).item()
+    return out, errs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="s3fd")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--which", default="fwd,dgrad,wgrad")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL}[args.set]
+    if args.only:
+        shapes = [s for s in shapes if s[0] in args.only.split(",")]
+    which = args.which.split(",")
+    tot = {w: [0.0, 0.0] for w in which}
+    for sh in shapes:
+        res, errs = run(sh, args.iters, which, args.check)
+        for wname, ms, tf, label in res:
+            tot[wname][0] += ms
+            tot[wname][1] += tf * ms
+            e = ("  relerr=%.2e" % errs[wname]) if wname in errs else ""
+            print("%-10s %-6s %8.3f ms %8.1f TFLOP/s  %s%s" % (sh[0], wname, ms, tf, label, e), flush=True)
+        if "db" in errs:
+            print("%-10s db relerr=%.2e" % (sh[0], errs["db"]))
+    for wname, (ms, tfms) in tot.items():
+        print("TOTAL %-6s %8.3f ms  %8.1f TFLOP/s" % (wname, ms, tfms / max(ms, 1e-9)))
+
+
+if __name__ == "__main__":
+    main()
