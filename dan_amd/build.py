@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdanhip.so")
 OBJ = os.path.join(CSRC, "_obj")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = (["-DDANHIP_HALO_EXPERIMENTS"] if os.environ.get("DANHIP_HALO_EXPERIMENTS") else []) + ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(a, deps):

@@ -22,7 +22,7 @@ struct ConvArgs {
 // Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
 // eligible (caller falls back to the flat-M kernel), negative on a launch error.
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
-const char* danhip_conv_halo_label(const ConvArgs& a);   // kernel-instance label or nullptr when not eligible
+const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
 __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {

@@ -14,6 +14,8 @@
 //
 // MFMA: v_mfma_f32_16x16x32_bf16, weight fragment = A operand, pixel fragment = B operand -> a lane owns 4 consecutive
 // output channels of one pixel (8-byte bf16 / 16-byte fp32 stores into NHWC).
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -27,6 +29,7 @@ struct HaloGeom {
   int cch;                  // 64-channel chunks of the input (C / 64)
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
   FastDiv div_tx, div_txy, div_nb;
+  unsigned long long* dbg;   // diagnostic builds only (DBG & 4): per-wave cycle sums
 };
 
 template <int N>
@@ -36,58 +39,56 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 
 // Epilogue of the halo kernel for one lane's 4 consecutive channels (Co % 64 == 0: always a full, aligned quad).
-__device__ __forceinline__ void halo_store4(const ConvArgs& a, const f32x4& acc, size_t m, int co) {
+//   forward : v = acc + bias; relu?; (+ residual, bf16) -> bf16 or fp32
+//   dgrad   : v = acc; * (mask > 0)?; (+= old)?          -> bf16
+// Every read-modify input of the wave tile is issued before the first store (no load waits between stores).
+template <bool DGRAD>
+__device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc, const float4& b, const uint2& in0, const uint2& in1, size_t o) {
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  const size_t o = m * (size_t)a.Co + co;
-  if (a.bias) {
-    const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+  if (!DGRAD) {
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-  }
-  if (a.relu) {
+    if (a.relu) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-  }
-  if (a.out_f32) {
-    float* y = reinterpret_cast<float*>(a.y) + o;
-    float4 t = make_float4(v[0], v[1], v[2], v[3]);
-    if (a.accumulate) { const float4 u = *reinterpret_cast<const float4*>(y); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    *reinterpret_cast<float4*>(y) = t;
-    return;
-  }
-  bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
-  if (a.mask) {
-    const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
-    const bf16_t* mp = reinterpret_cast<const bf16_t*>(&mk);
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (a.out_f32) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
+      return;
+    }
+    if (a.resid) {
+      const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
-  }
-  if (a.resid) {
-    const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + o);
-    const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
+    }
+  } else {
+    if (a.mask) {
+      const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
-  }
-  if (a.accumulate) {
-    const uint2 old = *reinterpret_cast<const uint2*>(y);
-    const bf16_t* op = reinterpret_cast<const bf16_t*>(&old);
+      for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+    }
+    if (a.accumulate) {
+      const bf16_t* op = reinterpret_cast<const bf16_t*>(&in1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
+    }
   }
   uint2 t;
   t.x = pack2bf(v[0], v[1]);
   t.y = pack2bf(v[2], v[3]);
-  *reinterpret_cast<uint2*>(y) = t;
+  *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.y) + o) = t;
 }
 
-// Zeros for out-of-image halo pixels: LDS-DMA lanes keep a per-lane 64-bit source pointer that is bumped by 128 bytes
-// per 64-channel chunk, so the page must cover C*2 + 16 bytes (C <= 2048).
-__device__ __attribute__((aligned(64))) unsigned g_halo_zero[1056] = {0};
-
-__device__ __forceinline__ void glds16_so(const void* sbase, unsigned voff, void* lds_wave_base) {   // saddr + 32-bit voffset
-  __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(reinterpret_cast<const char*>(sbase) + voff), (LDS_AS void*)lds_wave_base, 16, 0, 0);
+// 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is
+// out of range (>= the descriptor's byte count, e.g. 0xFFFFFFFF) writes ZEROS to its LDS slot — that is how halo pixels
+// outside the image are padded, with no branch and no pointer select.
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
+template <int DBG = 0>
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+  if (DBG & 32) return;                            // timing experiment: no DMA at all
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW>
+template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int PW = TW + 2;                       // patch row pitch (pixels); even, so LDS row parity == column parity
   constexpr int PROWS = (TH + 2) * PW;             // patch pixels
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   // ---- item mapping --------------------------------------------------------------------------------------------
   const int G = gridDim.x;
-  auto decode = [&](int v, int& sp, int& nb) -> bool {     // v = round * G + block
+  auto decode = [&](int v, int& sp, int& nb) __attribute__((always_inline)) -> bool {     // v = round * G + block
     if (g.grouped) {
       const int r = v / G, b = v - r * G;
       const int xcd = b & 7, slot = b >> 3;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     return sp < g.sp_items;
   };
-  auto sp_coords = [&](int sp, int& n, int& y0, int& x0) {
+  auto sp_coords = [&](int sp, int& n, int& y0, int& x0) __attribute__((always_inline)) {
     n = (int)fdiv((unsigned)sp, g.div_txy);
     const int rem = sp - n * (g.tiles_x * g.tiles_y);
     const int ty = (int)fdiv((unsigned)rem, g.div_tx);
@@ -150,11 +151,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int hy = row / PW, hx = row - hy * PW;
     pgeo[k] = row < PROWS ? ((hy << 8) | hx) : -1;
   }
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (DBG & 16) ? 0 : (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (DBG & 8) ? 0 : (int)((unsigned)a.Co * (unsigned)a.Kpad * 2u), 0x00020000);
   int p_v = blockIdx.x, p_cc = 0, p_idx = 0;       // patch cursor: next chunk to load; p_idx selects the buffer
   int p_sp, p_nb;
   bool p_ok = decode(p_v, p_sp, p_nb);
-  const char* psrc[PL];                            // this lane's source pointer per piece for chunk p_cc
-  auto patch_item_setup = [&]() {
+  unsigned psrc[PL];                               // this lane's byte offset per piece (chunk 0), 0xFFFFFFFF = zero fill
+  auto patch_item_setup = [&]() __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(p_sp, n, y0, x0);
 #pragma unroll
@@ -163,17 +167,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int y = y0 - 1 + (pgeo[k] >> 8), x = x0 - 1 + hx;
       const bool ok = pgeo[k] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
       const unsigned off = (unsigned)(((n * a.H + y) * a.W + x) * a.C) * 2u + (unsigned)(((lane & 7) ^ (hx & 7)) << 4);
-      psrc[k] = ok ? reinterpret_cast<const char*>(a.x) + off : reinterpret_cast<const char*>(g_halo_zero);
+      psrc[k] = ok ? off : 0xFFFFFFFFu;
     }
   };
-  auto issue_patch = [&]() {                       // loads chunk (p_v, p_cc) into buffer p_idx & 1 and advances the cursor
+  auto issue_patch = [&]() __attribute__((always_inline)) {                       // loads chunk (p_v, p_cc) into buffer p_idx & 1 and advances the cursor
     char* dst = smem + (p_idx & 1) * PBYTES;
 #pragma unroll
     for (int k = 0; k < PL; ++k) {
       int piece = k * 8 + wave;
       if (piece > PPIECES - 1) piece = PPIECES - 1;
-      glds16(psrc[k], dst + piece * 1024);
-      psrc[k] += 128;
+      bufdma16<DBG>(rsrc_x, psrc[k], (unsigned)(p_cc * 128), dst + piece * 1024);
     }
     ++p_idx;
     if (++p_cc == g.cch) {
@@ -190,11 +193,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int w_sp, w_nb;
   bool w_ok = decode(w_v, w_sp, w_nb);
   const unsigned wlane = (unsigned)((wave * WL * 8 + srow) * a.Kpad) * 2u + (unsigned)(((lane & 7) ^ srow) << 4);   // + k*8 rows
-  auto issue_w = [&]() {
+  auto issue_w = [&]() __attribute__((always_inline)) {
     char* dst = smem + WRING + (w_idx & (NSW - 1)) * WBYTES;
-    const char* sbase = reinterpret_cast<const char*>(a.w) + ((size_t)(w_nb * BN) * a.Kpad + w_tap * a.C + w_cc * 64) * 2;   // uniform
+    const unsigned soff = (unsigned)((w_nb * BN) * a.Kpad + w_tap * a.C + w_cc * 64) * 2u;   // uniform
 #pragma unroll
-    for (int k = 0; k < WL; ++k) glds16_so(sbase, wlane + (unsigned)(k * 8 * a.Kpad) * 2u, dst + (wave * WL + k) * 1024);
+    for (int k = 0; k < WL; ++k) bufdma16<DBG>(rsrc_w, wlane + (unsigned)(k * 8 * a.Kpad) * 2u, soff, dst + (wave * WL + k) * 1024);
     ++w_idx;
     if (++w_tap == 9) {
       w_tap = 0;
@@ -224,10 +227,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  bool skip_reads = false;
   // Fragment loads of k-slice ks of the step at (weight stage base wbase, patch buffer offset pofs, tap TAP).
-  auto load_frags = [&](bf16x8 (&wf)[NCT], bf16x8 (&xf)[NPT], int wbase, int pofs, auto tapc, int ks) {
+  auto load_frags = [&](bf16x8 (&wf)[NCT], bf16x8 (&xf)[NPT], int wbase, int pofs, auto tapc, int ks) __attribute__((always_inline)) {
     constexpr int TAP = decltype(tapc)::value;
     constexpr int TI = TAP / 3, TJ = TAP % 3;
+    if ((DBG & 64) && skip_reads) return;          // timing experiment: no fragment reads in the main loop
     const int wb = ks ? (wbase ^ 64) : wbase;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(smem + wb + c * 2048);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       xf[p] = *reinterpret_cast<const bf16x8*>(smem + pa + TI * PW * 128);
     }
   };
-  auto mma = [&](const bf16x8 (&wf)[NCT], const bf16x8 (&xf)[NPT], auto c0c, auto c1c) {      // channel tiles [C0, C1)
+  auto mma = [&](const bf16x8 (&wf)[NCT], const bf16x8 (&xf)[NPT], auto c0c, auto c1c) __attribute__((always_inline)) {      // channel tiles [C0, C1)
 #pragma unroll
     for (int c = decltype(c0c)::value; c < decltype(c1c)::value; ++c)
 #pragma unroll
@@ -258,81 +263,185 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // Software pipeline over half-steps: while the 16 MFMAs of one 32-deep k-slice run, the fragments of the next slice are
-  // read from LDS — including the first slice of the NEXT step, whose weight tile became visible one step earlier
-  // (the hand-off at the end of a step waits for the tile of step + 2).  One step = one tap of one 64-channel chunk.
-  int chunk = 0, cc = 0;                           // running chunk number (patch buffer = chunk & 1; stage = (chunk + tap) & 3)
+  // ---- main loop: two phase-alternating wave groups -----------------------------------------------------------------
+  // One step (= cycle) = one tap of one 64-channel chunk.  Waves 0-3 (group A) and 4-7 (group B) sit one per SIMD each.
+  // Every cycle has two barriers; between them one group runs its 32 MFMAs with nothing else in its stream while the other
+  // does all its memory work (issues the DMAs of step c+3 / the next patch, reads its next fragments from LDS, runs the
+  // item epilogue), then they swap:
+  //     A:  mem(c)   | b1 | MFMA(c) | b2          B:  MFMA(c) | b1 | mem(c+1) | b2
+  // so the matrix pipe of each SIMD always has exactly one wave feeding it and DMA issue / LDS latency / barrier skew are
+  // covered by the partner's MFMA phase.  Hand-offs (all checked at b1 of cycle c, before B reads tile c+1):
+  //   * every wave has waited for its own pieces of weight tile c+1 (A issued them in cycle c-2, B in cycle c-2 too);
+  //   * stage (c+3)&3 == (c-1)&3 was last read by A in mem(c-1) and by B in mem of cycle c-2  -> free to overwrite in c;
+  //   * the patch of chunk q+1 is issued at tap 0 of chunk q and retired by the counted waits long before tap 8.
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // DBG & 4 only: in-kernel stamps (diagnostic build)
+  auto stamp = [&](int i) __attribute__((always_inline)) {
+    if (DBG & 4) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      tsum[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  stamp(4);
+  tsum[4] = 0;
+
   bf16x8 wf0[NCT], xf0[NPT], wf1[NCT], xf1[NPT];
-  load_frags(wf0, xf0, offW, 0, std::integral_constant<int, 0>{}, 0);
-  for (;;) {
-    const int pofs = (chunk & 1) * PBYTES;
-    bool patch_issued = false;
-    auto step_body = [&](auto tapc) {
-      constexpr int TAP = decltype(tapc)::value;
-      // -- prefetch: weights of step + D, and (at tap 0) the next chunk's patch
-      const bool more_w = w_ok;
-      if (more_w) issue_w();
-      if (TAP == 0 && p_ok) { issue_patch(); patch_issued = true; }
-      const int wbase = offW + ((chunk + TAP) & (NSW - 1)) * WBYTES;
-      // -- slice 1 fragment reads, then slice 0 MFMAs.  The slice-0 fragments were read one half-step (and a barrier)
-      //    ago: retire them explicitly so the compiler does not make the MFMAs below wait for the reads issued here.
-      __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
-      load_frags(wf1, xf1, wbase, pofs, tapc, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(wf0, xf0, I0{}, IN{});
-      __builtin_amdgcn_sched_barrier(0);
-      // -- slice 1 MFMAs; the next step's slice 0 fragment reads go in after the first channel tile so that the wait in
-      //    front of the first slice-1 MFMA covers only the (long finished) slice-1 reads
-      constexpr int NTAP = (TAP + 1) % 9;
-      const int nwbase = offW + ((chunk + TAP + 1) & (NSW - 1)) * WBYTES;
-      const int npofs = TAP == 8 ? (PBYTES - pofs) : pofs;
-      mma(wf1, xf1, I0{}, I1{});
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(wf0, xf0, nwbase, npofs, std::integral_constant<int, NTAP>{}, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(wf1, xf1, I1{}, IN{});
-      __builtin_amdgcn_sched_barrier(0);
-      // -- hand-off: the weight tile of step + 2 (and any patch issued before it) must have landed
-      if (!more_w) {
-        wait_vmcnt<0>();                           // tail of this block's work
-      } else if (TAP < 2 && patch_issued) {
-        wait_vmcnt<(D - 2) * WL + PL>();
-      } else {
-        wait_vmcnt<(D - 2) * WL>();
-      }
-      __builtin_amdgcn_s_barrier();
-    };
-    step_body(std::integral_constant<int, 0>{});
-    step_body(std::integral_constant<int, 1>{});
-    step_body(std::integral_constant<int, 2>{});
-    step_body(std::integral_constant<int, 3>{});
-    step_body(std::integral_constant<int, 4>{});
-    step_body(std::integral_constant<int, 5>{});
-    step_body(std::integral_constant<int, 6>{});
-    step_body(std::integral_constant<int, 7>{});
-    step_body(std::integral_constant<int, 8>{});
-    ++chunk;
-    if (++cc == g.cch) {
-      // ---- epilogue of this item ---------------------------------------------------------------------------------
-      cc = 0;
-      int n, y0, x0;
-      sp_coords(c_sp, n, y0, x0);
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    int n, y0, x0;
+    sp_coords(c_sp, n, y0, x0);
+    float4 biasv[NCT];                             // this lane's bias quads (one wait for all of them)
 #pragma unroll
-      for (int p = 0; p < NPT; ++p) {
-        const int t = wm * TP + p * 16 + frow;
-        const int y = y0 + t / TW, x = x0 + t % TW;
-        const bool ok = y < a.H && x < a.W;
-        const size_t m = (size_t)((n * a.H + y) * a.W + x);
+    for (int c = 0; c < NCT; ++c)
+      biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + c_nb * BN + wn * TC + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const int t = wm * TP + p * 16 + frow;
+      const int y = y0 + t / TW, x = x0 + t % TW;
+      const bool ok = y < a.H && x < a.W;
+      const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + (c_nb * BN + wn * TC + fq * 4);
+      uint2 in0[NCT], in1[NCT];
+      if (ok) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
-          if (ok) halo_store4(a, acc[c][p], m, c_nb * BN + wn * TC + c * 16 + fq * 4);
-          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!DGRAD) {
+            if (a.resid && !a.out_f32) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
+          } else {
+            if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
+            if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+          }
         }
       }
-      c_v += G;
-      c_ok = decode(c_v, c_sp, c_nb);
-      if (!c_ok) break;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        if (ok) halo_finish4<DGRAD>(a, acc[c][p], biasv[c], in0[c], in1[c], o0 + c * 16);
+        acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
+    c_v += G;
+    c_ok = decode(c_v, c_sp, c_nb);
+  };
+
+  int chunk = 0, cc = 0;                           // running chunk number (patch buffer = chunk & 1; stage = (chunk + tap) & 3)
+  int patch_age = 4;                               // cycles since this wave last issued a patch (>= 3: outside every wait window)
+  bool w_prev = true;                              // group B: did the previous cycle issue a weight tile
+
+  if (wave < 4) {
+    skip_reads = true;
+    // ================================================= group A =================================================
+    bool pending = false;                          // an item finished in the previous cycle: its epilogue runs in this mem phase
+    for (;;) {
+      const int pofs = (chunk & 1) * PBYTES;
+      auto cycle = [&](auto tapc) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        // ---- mem phase
+        // fragment reads first: their LDS latency runs under the epilogue / DMA issue below
+        const int wbase = offW + ((chunk + TAP) & (NSW - 1)) * WBYTES;
+        load_frags(wf0, xf0, wbase, pofs, tapc, 0);
+        load_frags(wf1, xf1, wbase, pofs, tapc, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pending) { epilogue(); pending = false; }
+        const bool more_w = w_ok;
+        if (more_w) issue_w();
+        if (TAP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        stamp(5);
+        // A's queue: [W(c+1)] [patch?] [W(c+2)] [patch?] [W(c+3)] [patch?]; tile c+1 must be done before b1 (B reads it
+        // right after); a patch issued in this or the two previous mem phases (age <= 2) is younger than it.
+        if (!more_w) wait_vmcnt<0>();
+        else if (patch_age <= 2) wait_vmcnt<2 * WL + PL>();
+        else wait_vmcnt<2 * WL>();
+        ++patch_age;
+        __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): fragments are in registers before the MFMA phase starts
+        stamp(0);
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b1
+        stamp(1);
+        // ---- MFMA phase
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wf0, xf0, I0{}, IN{});
+        mma(wf1, xf1, I0{}, IN{});
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(2);
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b2
+        stamp(3);
+      };
+      cycle(std::integral_constant<int, 0>{});
+      cycle(std::integral_constant<int, 1>{});
+      cycle(std::integral_constant<int, 2>{});
+      cycle(std::integral_constant<int, 3>{});
+      cycle(std::integral_constant<int, 4>{});
+      cycle(std::integral_constant<int, 5>{});
+      cycle(std::integral_constant<int, 6>{});
+      cycle(std::integral_constant<int, 7>{});
+      cycle(std::integral_constant<int, 8>{});
+      ++chunk;
+      if (++cc == g.cch) {
+        cc = 0;
+        // peek: is this the block's last item?  (the epilogue itself advances the cursor)
+        int nsp, nnb;
+        if (!decode(c_v + G, nsp, nnb)) { epilogue(); break; }
+        pending = true;
+      }
+    }
+  } else {
+    // ================================================= group B =================================================
+    load_frags(wf0, xf0, offW, 0, std::integral_constant<int, 0>{}, 0);
+    load_frags(wf1, xf1, offW, 0, std::integral_constant<int, 0>{}, 1);
+    skip_reads = true;
+    for (;;) {
+      const int pofs = (chunk & 1) * PBYTES;
+      bool last = false;                           // set when the block's last item has been finished
+      auto cycle = [&](auto tapc) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tapc)::value;
+        // ---- MFMA phase (step c)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(wf0, xf0, I0{}, IN{});
+        mma(wf1, xf1, I0{}, IN{});
+        __builtin_amdgcn_sched_barrier(0);
+        // B's queue at this point: [W(c+1)] [patch?] [W(c+2)] [patch?]; tile c+1 (issued two mem phases ago) must be
+        // done.  A patch issued in one of the last two mem phases (age 0 or 1) is younger than it and may stay in flight.
+        if (!w_prev) wait_vmcnt<0>();
+        else if (patch_age <= 1) wait_vmcnt<WL + PL>();
+        else wait_vmcnt<WL>();
+        stamp(2);
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b1
+        stamp(3);
+        // ---- mem phase (for step c+1)
+        constexpr int NTAP = (TAP + 1) % 9;
+        const int nwbase = offW + ((chunk + TAP + 1) & (NSW - 1)) * WBYTES;
+        const int npofs = TAP == 8 ? (PBYTES - pofs) : pofs;
+        load_frags(wf0, xf0, nwbase, npofs, std::integral_constant<int, NTAP>{}, 0);   // reads first (see group A)
+        load_frags(wf1, xf1, nwbase, npofs, std::integral_constant<int, NTAP>{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAP == 8 && cc + 1 == g.cch) {         // the item ended with this step
+          epilogue();
+          if (!c_ok) last = true;
+        }
+        const bool more_w = w_ok;
+        if (more_w) issue_w();
+        w_prev = more_w;
+        ++patch_age;
+        if (TAP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        stamp(0);
+        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b2
+        stamp(1);
+      };
+      cycle(std::integral_constant<int, 0>{});
+      cycle(std::integral_constant<int, 1>{});
+      cycle(std::integral_constant<int, 2>{});
+      cycle(std::integral_constant<int, 3>{});
+      cycle(std::integral_constant<int, 4>{});
+      cycle(std::integral_constant<int, 5>{});
+      cycle(std::integral_constant<int, 6>{});
+      cycle(std::integral_constant<int, 7>{});
+      cycle(std::integral_constant<int, 8>{});
+      ++chunk;
+      if (++cc == g.cch) cc = 0;
+      if (last) break;
+    }
+  }
+  if ((DBG & 4) && g.dbg && lane == 0) {
+    for (int i = 0; i < 8; ++i) g.dbg[(blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
   }
 }
 
@@ -367,12 +476,12 @@ int cu_count() {
   return n;
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW>
+template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
   constexpr int LDS = 2 * PPIECES * 1024 + NSW * BN * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   HaloGeom g{};
@@ -389,27 +498,78 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.grouped = 0;
   if (items >= G && (G % 8) == 0 && ((G / 8) % g.NB) == 0 && g.NB > 1) g.grouped = 1;
   if (items < G) G = (int)items;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW>), dim3(G), dim3(512), LDS, s, a, g);
+#ifdef DANHIP_HALO_EXPERIMENTS
+  if (DBG & 4) {
+    static unsigned long long* dbgbuf = nullptr;
+    if (!dbgbuf) hipMalloc(&dbgbuf, 256 * 8 * 8 * sizeof(unsigned long long));
+    g.dbg = dbgbuf;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>), dim3(G), dim3(512), LDS, s, a, g);
+    hipStreamSynchronize(s);
+    static unsigned long long host[256 * 8 * 8];
+    hipMemcpy(host, dbgbuf, sizeof(host), hipMemcpyDeviceToHost);
+    const double steps = (double)items / G * g.cch * 9;
+    for (int grp = 0; grp < 2; ++grp) {
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < G; ++b) for (int w = grp * 4; w < grp * 4 + 4; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)host[(b * 8 + w) * 8 + i];
+      fprintf(stderr, "[halo stamps grp %c] cycles/step: s0=%.0f s1=%.0f s2=%.0f s3=%.0f s4=%.0f s5=%.0f s6=%.0f s7=%.0f | steps/block=%.0f\n", 'A' + grp,
+              sum[0] / (G * 4) / steps, sum[1] / (G * 4) / steps, sum[2] / (G * 4) / steps, sum[3] / (G * 4) / steps, sum[4] / (G * 4) / steps,
+              sum[5] / (G * 4) / steps, sum[6] / (G * 4) / steps, sum[7] / (G * 4) / steps, steps);
+    }
+    return DANHIP_OK;
+  }
+#endif
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
 
 }  // namespace
 
+namespace {
+template <bool DGRAD>
+int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
+  if (p.th == 8) {
+#ifdef DANHIP_HALO_EXPERIMENTS
+    if (p.bn == 128 && !DGRAD) {
+      const char* e = getenv("DANHIP_HALO_DBG");
+      const int dbg = e ? atoi(e) : 0;
+      if (dbg == 4) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 4>(a, s);
+      if (dbg == 8) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 8>(a, s);
+      if (dbg == 16) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 16>(a, s);
+      if (dbg == 24) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 24>(a, s);
+      if (dbg == 28) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 28>(a, s);
+      if (dbg == 36) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 36>(a, s);
+      if (dbg == 32) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 32>(a, s);
+      if (dbg == 64) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 64>(a, s);
+      if (dbg == 96) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 96>(a, s);
+      if (dbg == 98) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 98>(a, s);
+    }
+#endif
+    if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 4, DGRAD>(a, s);
+    return launch_halo_cfg<8, 32, 64, 8, 1, 4, DGRAD>(a, s);
+  }
+  if (p.bn == 128) return launch_halo_cfg<16, 16, 128, 4, 2, 4, DGRAD>(a, s);
+  return launch_halo_cfg<16, 16, 64, 8, 1, 4, DGRAD>(a, s);
+}
+}  // namespace
+
+// dgrad mode = no bias / relu / residual / fp32 output requested (the data-gradient call); forward otherwise.
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return 1;
-  if (p.th == 8) {
-    if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 4>(a, s);
-    return launch_halo_cfg<8, 32, 64, 8, 1, 4>(a, s);
-  }
-  if (p.bn == 128) return launch_halo_cfg<16, 16, 128, 4, 2, 4>(a, s);
-  return launch_halo_cfg<16, 16, 64, 8, 1, 4>(a, s);
+  const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32;
+  if (!dgrad && a.accumulate) return 1;
+  if (!dgrad && a.mask) return 1;
+  return dgrad ? launch_halo<true>(a, p, s) : launch_halo<false>(a, p, s);
 }
 
-const char* danhip_conv_halo_label(const ConvArgs& a) {
+const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return nullptr;
-  if (p.th == 8) return p.bn == 128 ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4>";
-  return p.bn == 128 ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4>";
+  if (p.th == 8) {
+    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, false, 0>";
+    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0>";
+  }
+  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, false, 0>";
+  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0>";
 }

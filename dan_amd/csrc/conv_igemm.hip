@@ -381,7 +381,7 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
   if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
   {
     const ConvArgs a = which == 0 ? fwd_args(d) : bwd_args(d);
-    const char* hl = danhip_conv_halo_label(a);
+    const char* hl = danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
   }
   const bool fast = cin % 64 == 0;
