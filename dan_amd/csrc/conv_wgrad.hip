@@ -6,7 +6,7 @@
 // (a 4-pixel x 16-channel block per 16-lane group), so nothing is ever transposed in registers or through HBM.
 // The reduction over pixels is split across workgroups (grid.z); partial tiles are combined with fp32 atomics
 // straight into the HWIO gradient (zeroed by the caller once per step).
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -225,6 +225,10 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
   DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
              "conv2d_bwd_weight: Ho/Wo mismatch");
+  {
+    const int hr = danhip_launch_wgrad_halo(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
+    if (hr <= 0) return hr;
+  }
   WgradArgs a{};
   a.x = x; a.dy = dy; a.dw = dw_hwio; a.db = db;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Co8 = (d->Cout + 7) / 8 * 8;

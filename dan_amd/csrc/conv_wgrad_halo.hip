@@ -1,0 +1,360 @@
+// Weight gradient of 3x3 / stride-1 convolutions on MFMA for gfx950 — halo-reuse, register-resident 9-tap accumulation.
+//
+//   dW[tap][ci][co] = sum over pixels  X[pixel + tap][ci] * dY[pixel][co]         (tf.layers.conv2d backward w.r.t. the
+//   kernel variable of net/sfd_net.py:81-89 and every 3x3 conv of net/*.py; bias gradient db[co] = sum dY rides along)
+//
+// The reduction runs over PIXELS, the strided axis of both NHWC operands, so both tiles are staged exactly as they lie in
+// HBM ([pixel][channel] rows, 16-byte LDS-DMA pieces) and MFMA fragments come from ds_read_b64_tr_b16 (a 4-pixel x
+// 16-channel block per 16-lane group): nothing is transposed in registers or through HBM.
+//
+// A persistent 512-thread workgroup owns a (64 ci) x (COT co) x (9 taps) gradient tile IN REGISTERS (wave tile 16 ci x
+// 64 co x 9 taps = 144 accumulator VGPRs) and sweeps its share of 4 x 32 pixel tiles.  Per pixel tile the X halo patch
+// (6 x 34 pixels x 64 ci) and the dY tile (128 pixels x COT co) are DMA'd once; every K-step (one 32-pixel row) reads the dY
+// fragments once and reuses them for all nine taps, whose X fragments are the same patch at shifted row/column offsets
+// (the LDS swizzle is keyed on the patch COLUMN so a tap's row shift is a pure immediate offset).  Compared with the
+// per-tap split-K kernel (conv_wgrad.hip) this moves ~5.6x fewer bytes L2->LDS per MAC and reads 0.7 fragments per MFMA.
+//
+// Two wave groups alternate phases exactly as in conv_halo.hip: while one group issues its 36 MFMAs with nothing else in
+// its stream, the other does its LDS reads / DMA issue; two barriers per cycle swap the roles.
+// Partial gradients are combined with fp32 atomics into the HWIO tensor (zeroed by the caller once per step).
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+struct WgHaloArgs {
+  const bf16_t* x;     // [N,H,W,C]
+  const bf16_t* dy;    // [N,H,W,Co8]
+  float* dw;           // [3,3,cin_real,Cout]
+  float* db;           // [Cout] or null
+  int N, H, W, C, Co8, Cout, cin_real;
+  int tiles_x, tiles_y, total_tiles, tiles_per_split;
+  int ci_tiles, co_tiles;
+  FastDiv div_tx, div_txy, div_ci, div_pairs;
+};
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ int f128(int pc) { return ((pc >> 1) & 1) | (((pc >> 3) & 1) << 1); }      // 32-byte-slot swizzles
+__device__ __forceinline__ int f256(int px) { return (px & 3) | (((px >> 3) & 1) << 2); }
+
+// COT: output-channel tile (128: waves = 4 ci-groups x 2 co-halves, every wave sees every K-step;
+//                           64: waves = 4 ci-groups x 2 K-groups, group A takes the even rows, group B the odd ones)
+template <int COT>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
+  constexpr int TH = 4, TW = 32, PW = TW + 2;
+  constexpr int XPIX = (TH + 2) * PW;                 // 204 patch pixels, 128-byte rows (64 ci)
+  constexpr int XPIECES = (XPIX + 7) / 8;             // 26
+  constexpr int XBYTES = XPIECES * 1024;
+  constexpr int RBY = COT * 2;                        // dY row bytes
+  constexpr int YBYTES = TH * TW * RBY;
+  constexpr int YPIECES = YBYTES / 1024;              // 32 / 16
+  constexpr int YROWS_PER_PIECE = 1024 / RBY;         // 4 / 8
+  constexpr int BUF = XBYTES + YBYTES;
+  constexpr int KPC = COT == 128 ? 1 : 2;             // K-steps (pixel rows) per cycle: one per group when the groups split K
+  constexpr int CPT = TH / KPC;                       // cycles per pixel tile
+  constexpr int NX = (XPIECES + 7) / 8, NY = YPIECES / 8;
+  constexpr int NDMA = NX + NY;                       // DMA instructions per wave per tile
+  constexpr int PER = (NDMA + (CPT - 1) - 1) / (CPT - 1);   // issued per cycle in cycles 0 .. CPT-2
+  constexpr int NO = 4;                               // co fragments per wave (64 co)
+  static_assert(2 * BUF <= 160 * 1024, "LDS budget");
+  static_assert(5 * PW * 128 + BUF < 65536 + BUF, "imm offsets");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lane_ = lane;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wci = wave & 3;
+  const int grp = wave >> 2;                          // phase group: 0 = A, 1 = B
+  const int wco = COT == 128 ? grp : 0;
+
+  // ---- block -> (ci tile, co tile, pixel split)
+  const int pairs = a.ci_tiles * a.co_tiles;
+  const int split = (int)fdiv(blockIdx.x, a.div_pairs);
+  const int pair = (int)blockIdx.x - split * pairs;
+  const int co_tile = (int)fdiv((unsigned)pair, a.div_ci);
+  const int ci_tile = pair - co_tile * a.ci_tiles;
+  const int ci0 = ci_tile * 64, co0 = co_tile * COT;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.total_tiles, t_begin + a.tiles_per_split);
+  if (t_begin >= t_end) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_y =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dy), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co8 * 2u), 0x00020000);
+
+  // ---- DMA geometry: slot s < NX is X piece (s*8 + wave, clamped), else dY piece ((s-NX)*8 + wave)
+  auto tile_coords = [&](int t, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+    n = (int)fdiv((unsigned)t, a.div_txy);
+    const int rem = t - n * (a.tiles_x * a.tiles_y);
+    const int ty = (int)fdiv((unsigned)rem, a.div_tx);
+    y0 = ty * TH;
+    x0 = (rem - ty * a.tiles_x) * TW;
+  };
+  int dn = 0, dy0 = 0, dx0 = 0;                        // coordinates of the tile whose pieces are being issued (uniform)
+  auto dma_setup = [&](int t) __attribute__((always_inline)) { tile_coords(t, dn, dy0, dx0); };
+  auto dma_issue = [&](int bufoff, auto s0c, auto s1c) __attribute__((always_inline)) {      // slots [S0, S1)
+    int lane = lane_;                                 // opaque copy: keeps the per-slot geometry from being hoisted out of the
+    asm volatile("" : "+v"(lane));                    // tile loop into ~24 long-lived VGPRs (it is ~15 VALU per DMA to recompute)
+#pragma unroll
+    for (int s = decltype(s0c)::value; s < decltype(s1c)::value && s < NDMA; ++s) {
+      if (s < NX) {
+        int piece = s * 8 + wave;
+        if (piece > XPIECES - 1) piece = XPIECES - 1;
+        const int px = piece * 8 + (lane >> 3);        // patch pixel
+        const int prow = px / PW, pcol = px - prow * PW;
+        const int y = dy0 - 1 + prow, x = dx0 - 1 + pcol;
+        const bool ok = px < XPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const int chunk = (lane & 7) ^ (f128(pcol) << 1);
+        const unsigned voff = ok ? (unsigned)(((dn * a.H + y) * a.W + x) * a.C + ci0 + chunk * 8) * 2u : 0xFFFFFFFFu;
+        wg_dma16(rsrc_x, voff, smem + bufoff + piece * 1024);
+      } else {
+        const int piece = (s - NX) * 8 + wave;
+        const int px = piece * YROWS_PER_PIECE + lane / (RBY / 16);   // tile pixel r*32 + c
+        const int y = dy0 + (px >> 5), x = dx0 + (px & 31);
+        const int cpos = lane % (RBY / 16);
+        const int chunk = cpos ^ ((COT == 128 ? f256(px) : f128(px)) << 1);
+        const int cc = co0 + chunk * 8;
+        const bool ok = y < a.H && x < a.W && cc < a.Co8;
+        const unsigned voff = ok ? (unsigned)(((dn * a.H + y) * a.W + x) * a.Co8 + cc) * 2u : 0xFFFFFFFFu;
+        wg_dma16(rsrc_y, voff, smem + bufoff + XBYTES + piece * 1024);
+      }
+    }
+  };
+
+  // ---- fragment addresses (buffer 0; flipped in place per tile)
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  int xaddr[3][2];                                    // [tap column j][half h]: X fragment base, row offset is an immediate
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pcol = j + 8 * g + 4 * h + q;
+      const int ch = (wci * 2 + (p >> 1)) ^ (f128(pcol) << 1);
+      xaddr[j][h] = pcol * 128 + (ch << 4) + (p & 1) * 8;
+    }
+  int yaddr[NO][2];                                   // [co fragment][half]: dY fragment base of row 0
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int px = 8 * g + 4 * h + q;                // + r*32 (does not change the swizzle bits 0,1,3)
+      const int ch = ((wco * 4 + o) * 2 + (p >> 1)) ^ ((COT == 128 ? f256(px) : f128(px)) << 1);
+      yaddr[o][h] = XBYTES + px * RBY + (ch << 4) + (p & 1) * 8;
+    }
+
+  f32x4 acc[9][NO];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[t][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.db != nullptr && ci_tile == 0 && wci == 0;     // wave-uniform
+  float dbsum[NO] = {0.f, 0.f, 0.f, 0.f};
+
+  // Register budget: the X fragments of taps 0..5 are read in the mem phase; taps 6..8 are read at the start of the MFMA
+  // phase into the registers of taps 0..2 once their MFMAs have been issued (their LDS latency hides under taps 3..5).
+  bf16x8 xf[6], yf[NO];
+  auto read_x = [&](bf16x8& dst, int tap, int R) __attribute__((always_inline)) {
+    const int i = tap / 3, j = tap % 3;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][0] + (R + i) * PW * 128));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][1] + (R + i) * PW * 128));
+    dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  auto read_frags = [&](auto rc) __attribute__((always_inline)) {        // K-step R of the current tile (addresses hold the buffer)
+    constexpr int R = decltype(rc)::value;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o][0] + R * 32 * RBY));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o][1] + R * 32 * RBY));
+      yf[o] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) read_x(xf[t], t, R);
+  };
+  auto mma_tap = [&](int t, const bf16x8& x) __attribute__((always_inline)) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[t][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, yf[o], acc[t][o], 0, 0, 0);
+  };
+  auto mma = [&](auto rc) __attribute__((always_inline)) {              // MFMA phase of K-step R
+    constexpr int R = decltype(rc)::value;
+    mma_tap(0, xf[0]); mma_tap(1, xf[1]); mma_tap(2, xf[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(xf[0], 6, R); read_x(xf[1], 7, R); read_x(xf[2], 8, R);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(3, xf[3]); mma_tap(4, xf[4]); mma_tap(5, xf[5]);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(6, xf[0]); mma_tap(7, xf[1]); mma_tap(8, xf[2]);
+    if (do_bias) {                                    // db += column sums of this K-step's dY fragments (VALU, beside the MFMAs)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)yf[o][e];
+        dbsum[o] += s;
+      }
+    }
+  };
+  auto flip_buffers = [&](int dir) __attribute__((always_inline)) {     // dir = +BUF or -BUF
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { xaddr[j][0] += dir; xaddr[j][1] += dir; }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { yaddr[o][0] += dir; yaddr[o][1] += dir; }
+  };
+
+  // ---- prologue: tile t_begin into buffer 0
+  dma_setup(t_begin);
+  dma_issue(0, std::integral_constant<int, 0>{}, std::integral_constant<int, NDMA>{});
+  wg_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // Cycle c of a tile: group A works on K-step c*KPC, group B on K-step c*KPC + KPC-1.
+  //   A:  mem(c) | b1 | MFMA(c) | b2          B:  MFMA(c) | b1 | mem(c+1) | b2
+  // Next tile's DMA (other buffer) is issued in cycles 0..CPT-2 and retired (vmcnt(0)) before b1 of the last cycle, after
+  // which B reads the next tile's first fragments.
+  if (grp == 0) {
+    for (int t = t_begin; t < t_end; ++t) {
+      const int cur = (t - t_begin) & 1;
+      const bool has_next = t + 1 < t_end;
+      auto cycle = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int CYC = decltype(cc)::value;
+        read_frags(std::integral_constant<int, CYC * KPC>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+          if (CYC == 0) dma_setup(t + 1);
+          if (CYC < CPT - 1) dma_issue((cur ^ 1) * BUF, std::integral_constant<int, CYC * PER>{}, std::integral_constant<int, (CYC + 1) * PER>{});
+        }
+        if (CYC == CPT - 1) wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();                // b1
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, CYC * KPC>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // b2
+      };
+      cycle(I0{});
+      if constexpr (CPT > 1) cycle(I1{});
+      if constexpr (CPT > 2) { cycle(I2{}); cycle(I3{}); }
+      flip_buffers(cur == 0 ? BUF : -BUF);
+    }
+  } else {
+    read_frags(std::integral_constant<int, KPC - 1>{});
+    for (int t = t_begin; t < t_end; ++t) {
+      const int cur = (t - t_begin) & 1;
+      const bool has_next = t + 1 < t_end;
+      auto cycle = [&](auto cc) __attribute__((always_inline)) {
+        constexpr int CYC = decltype(cc)::value;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(std::integral_constant<int, CYC * KPC + KPC - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (CYC == CPT - 1) wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                // b1
+        if (CYC == CPT - 1) {
+          flip_buffers(cur == 0 ? BUF : -BUF);       // next tile's first fragments come from the other buffer
+          read_frags(std::integral_constant<int, KPC - 1>{});
+        } else {
+          read_frags(std::integral_constant<int, (CYC + 1) * KPC + KPC - 1 < TH ? (CYC + 1) * KPC + KPC - 1 : 0>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+          if (CYC == 0) dma_setup(t + 1);
+          if (CYC < CPT - 1) dma_issue((cur ^ 1) * BUF, std::integral_constant<int, CYC * PER>{}, std::integral_constant<int, (CYC + 1) * PER>{});
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                // b2
+      };
+      cycle(I0{});
+      if constexpr (CPT > 1) cycle(I1{});
+      if constexpr (CPT > 2) { cycle(I2{}); cycle(I3{}); }
+    }
+  }
+
+  // ---- epilogue: lane holds dW[tap][ci = ci0 + wci*16 + g*4 + r][co = co0 + wco*64 + o*16 + (lane & 15)]
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + wci * 16 + g * 4 + r;
+      if (ci >= a.cin_real) continue;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const int co = co0 + wco * 64 + o * 16 + (lane & 15);
+        if (co < a.Cout) atomicAdd(a.dw + ((size_t)(t * a.cin_real + ci) * a.Cout + co), acc[t][o][r]);
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float s = dbsum[o];                             // lanes l, l+16, l+32, l+48 hold the four k-groups of column l & 15
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const int co = co0 + wco * 64 + o * 16 + (lane & 15);
+      if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, s);
+    }
+  }
+}
+
+int wg_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+template <int COT>
+int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
+  constexpr int XB = ((6 * 34 + 7) / 8) * 1024, YB = 128 * COT * 2;
+  constexpr int LDS = 2 * (XB + YB);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<COT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)attr_ok;
+  a.ci_tiles = a.C / 64;
+  a.co_tiles = (a.Co8 + COT - 1) / COT;
+  const int pairs = a.ci_tiles * a.co_tiles;
+  int splits = wg_cu_count() / pairs;
+  if (splits < 1) splits = 1;
+  if (splits > a.total_tiles) splits = a.total_tiles;
+  a.tiles_per_split = (a.total_tiles + splits - 1) / splits;
+  splits = (a.total_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
+  a.div_ci = make_fastdiv(a.ci_tiles);
+  a.div_pairs = make_fastdiv(pairs);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+}  // namespace
+
+// Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
+int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s) {
+  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1)) return 1;
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  if (d->Cin % 64 != 0 || co8 % 64 != 0) return 1;
+  const int th = 4, tw = 32;
+  const double util = (double)d->H * d->W / ((double)((d->H + th - 1) / th * th) * (double)((d->W + tw - 1) / tw * tw));
+  if (util < 0.78) return 1;
+  WgHaloArgs a{};
+  a.x = x; a.dy = dy; a.dw = dw; a.db = db;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Co8 = co8; a.Cout = d->Cout; a.cin_real = cin_real;
+  a.tiles_x = (d->W + tw - 1) / tw;
+  a.tiles_y = (d->H + th - 1) / th;
+  a.total_tiles = d->N * a.tiles_x * a.tiles_y;
+  a.div_tx = make_fastdiv(a.tiles_x);
+  a.div_txy = make_fastdiv(a.tiles_x * a.tiles_y);
+  return co8 % 128 == 0 ? launch_wg_halo<128>(a, s) : launch_wg_halo<64>(a, s);
+}
