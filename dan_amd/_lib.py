@@ -71,6 +71,8 @@ def lib():
         L.danhip_match_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_conv_kernel_label.restype = ctypes.c_char_p
         L.danhip_conv_kernel_label.argtypes = [DESC, ctypes.c_int]
+        L.danhip_conv_wgrad_kernel_label.restype = ctypes.c_char_p
+        L.danhip_conv_wgrad_kernel_label.argtypes = [DESC]
         L.danhip_match_workspace_bytes.argtypes = [I32, I32]
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is missing

@@ -25,6 +25,7 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
 const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible
 
 // Halo-reuse 3x3/stride-1 weight gradient (conv_wgrad_halo.hip): DANHIP_OK when launched, 1 when not eligible.
+const char* danhip_wgrad_halo_label(const danhip_conv_desc* d);
 int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).

@@ -218,6 +218,19 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d) {
+  if (!d) return "";
+  const char* hl = danhip_wgrad_halo_label(d);
+  if (hl) return hl;
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  if (d->Cin == 8 && d->kh * d->kw <= 16) return co8 > 64 ? "conv_wgrad_kernel<128, 128, 2>" : "conv_wgrad_kernel<128, 64, 2>";
+  const bool ci_small = d->Cin <= 64, co_small = co8 <= 64;
+  if (ci_small && co_small) return "conv_wgrad_kernel<64, 64, 2>";
+  if (ci_small) return "conv_wgrad_kernel<64, 128, 2>";
+  if (co_small) return "conv_wgrad_kernel<128, 64, 2>";
+  return "conv_wgrad_kernel<128, 128, 2>";
+}
+
 extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
                                         int32_t cin_real, void* stream) {
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");

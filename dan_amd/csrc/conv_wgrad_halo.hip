@@ -340,14 +340,25 @@ int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
-int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s) {
-  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1)) return 1;
+static bool wg_halo_eligible(const danhip_conv_desc* d) {
+  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1)) return false;
   const int co8 = (d->Cout + 7) / 8 * 8;
-  if (d->Cin % 64 != 0 || co8 % 64 != 0) return 1;
+  if (d->Cin % 64 != 0 || co8 % 64 != 0) return false;
   const int th = 4, tw = 32;
   const double util = (double)d->H * d->W / ((double)((d->H + th - 1) / th * th) * (double)((d->W + tw - 1) / tw * tw));
-  if (util < 0.78) return 1;
+  return util >= 0.78;
+}
+
+const char* danhip_wgrad_halo_label(const danhip_conv_desc* d) {
+  if (!wg_halo_eligible(d)) return nullptr;
+  return ((d->Cout + 7) / 8 * 8) % 128 == 0 ? "conv_wgrad_halo_kernel<128>" : "conv_wgrad_halo_kernel<64>";
+}
+
+// Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
+int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s) {
+  if (!wg_halo_eligible(d)) return 1;
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  const int th = 4, tw = 32;
   WgHaloArgs a{};
   a.x = x; a.dy = dy; a.dw = dw; a.db = db;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Co8 = co8; a.Cout = d->Cout; a.cin_real = cin_real;

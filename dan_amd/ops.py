@@ -61,7 +61,10 @@ def _prof_end(e0, d, which):
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record(torch.cuda.current_stream())
-    label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), which).decode()
+    if which == 2:
+        label = _lib.lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode()
+    else:
+        label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), which).decode()
     cin = d.Cin if which == 0 else d.Cin   # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
     flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
     PROFILE.setdefault(label, []).append((e0, e1, flops))
@@ -195,7 +198,9 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(wp) if wp is not None else None
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
+            e0 = _prof_begin()
             call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real, stream())
+            _prof_end(e0, d, 2)
             if sink is not None:
                 dw = None
         if db_sink is not None:

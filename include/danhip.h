@@ -83,6 +83,8 @@ int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_
 /* Kernel-instance label a forward (which=0) / data-gradient (which=1) call of this descriptor launches (the demangled
  * name rocprofv3 reports) — lets bench.py attribute measured time to a kernel. */
 const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
+/* Same for the weight-gradient call of this descriptor. */
+const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound layer kernels (bf16 NHWC, 16-byte vectors, wave reductions).
