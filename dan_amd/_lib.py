@@ -36,6 +36,17 @@ SIGNATURES = {
     "danhip_l2norm_fwd": [P, P, P, I64, I32, P],
     "danhip_l2norm_bwd": [P, P, P, P, P, I64, I32, ctypes.c_int, ctypes.c_int, P],
     "danhip_preprocess_u8": [P, P, I64, P],
+    "danhip_resize_bilinear_add_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, P],
+    "danhip_resize_bilinear_add_bwd": [P, P, I32, I32, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_avgpool2x2s1_same_fwd": [P, P, I32, I32, I32, I32, P],
+    "danhip_avgpool2x2s1_same_bwd": [P, P, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_batchnorm_fwd_train": [P, P, P, P, P, P, P, P, I64, I32, FL, FL, ctypes.c_int, P, P],
+    "danhip_batchnorm_fwd_infer": [P, P, P, P, P, P, I64, I32, ctypes.c_int, P],
+    "danhip_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I32, P],
+    "danhip_dynamic_anchor_routing_eval": [P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, ctypes.c_size_t, P],
+    "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P,
+                                            ctypes.c_size_t, P],
+    "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
     "danhip_cast_pad_f32_to_bf16": [P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
@@ -74,6 +85,8 @@ def lib():
         L.danhip_conv_wgrad_kernel_label.restype = ctypes.c_char_p
         L.danhip_conv_wgrad_kernel_label.argtypes = [DESC]
         L.danhip_match_workspace_bytes.argtypes = [I32, I32]
+        L.danhip_routing_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_routing_workspace_bytes.argtypes = [I64, I32, ctypes.c_int]
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.restype = ctypes.c_int

@@ -405,3 +405,102 @@ def cast_pad(x_f32, c_dst):
     out = torch.empty(shp[:-1] + (c_dst,), dtype=torch.bfloat16, device=x_f32.device)
     call("danhip_cast_pad_f32_to_bf16", ptr(x_f32.contiguous()), ptr(out), rows, shp[-1], c_dst, stream())
     return out
+
+
+class _ResizeAdd(torch.autograd.Function):
+    """out = lateral + tf.image.resize_bilinear(up, size(lateral)) (TF1 legacy mapping) — the LFPN merge of
+    net/pb_net.py:209-217 / net/danet.py:363-371.  lateral may be None (plain resize to `size`)."""
+
+    @staticmethod
+    def forward(ctx, up, lateral, size):
+        N, Hi, Wi, C = up.shape
+        Ho, Wo = (lateral.shape[1], lateral.shape[2]) if lateral is not None else size
+        assert up.dtype == torch.bfloat16 and up.is_contiguous() and C % 8 == 0
+        out = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=up.device)
+        call("danhip_resize_bilinear_add_fwd", ptr(up), ptr(lateral.contiguous()) if lateral is not None else None, ptr(out), N, Hi, Wi, Ho, Wo, C, stream())
+        ctx.dims = (N, Hi, Wi, Ho, Wo, C)
+        ctx.has_lat = lateral is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, Hi, Wi, Ho, Wo, C = ctx.dims
+        dout = dout.contiguous()
+        dup = None
+        if ctx.needs_input_grad[0]:
+            dup = torch.empty((N, Hi, Wi, C), dtype=torch.bfloat16, device=dout.device)
+            call("danhip_resize_bilinear_add_bwd", ptr(dout), ptr(dup), N, Hi, Wi, Ho, Wo, C, 0, stream())
+        return dup, (dout if ctx.has_lat else None), None
+
+
+def resize_bilinear_add(up, lateral=None, size=None):
+    return _ResizeAdd.apply(up, lateral, size)
+
+
+class _AvgPool2x2S1(torch.autograd.Function):
+    """tf.layers.average_pooling2d((2,2), 1, 'same') — net/danet.py:854."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        call("danhip_avgpool2x2s1_same_fwd", ptr(x), ptr(y), N, H, W, C, stream())
+        ctx.dims = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.dims
+        dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+        call("danhip_avgpool2x2s1_same_bwd", ptr(dy.contiguous()), ptr(dx), N, H, W, C, 0, stream())
+        return dx
+
+
+def avg_pool_2x2_s1(x):
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 8 == 0
+    return _AvgPool2x2S1.apply(x)
+
+
+class _BatchNorm(torch.autograd.Function):
+    """tf.layers.batch_normalization(training=True) (+ optional ReLU) over NHWC bf16 — net/sfd_net.py:91-119."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu):
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        call("danhip_batchnorm_fwd_train", ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(y), ptr(mean), ptr(rstd), ptr(moving_mean), ptr(moving_var),
+             M, C, float(eps), float(momentum), int(relu), ptr(ws), stream())
+        ctx.save_for_backward(x, gamma.detach(), mean, rstd, y if relu else None)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, y = ctx.saved_tensors
+        C = x.shape[-1]
+        M = x.numel() // C
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy.clone()
+            call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, C, stream())
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        call("danhip_batchnorm_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), M, C, stream())
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, moving_mean=None, moving_var=None, eps=1e-5, momentum=0.997, relu=False):
+    return _BatchNorm.apply(x, gamma, beta, moving_mean, moving_var, eps, momentum, relu)
+
+
+def batch_norm_infer(x, gamma, beta, moving_mean, moving_var, eps=1e-5, relu=False):
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    rstd = torch.rsqrt(moving_var + eps)
+    call("danhip_batchnorm_fwd_infer", ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(moving_mean), ptr(rstd), ptr(y), x.numel() // C, C, int(relu), stream())
+    return y

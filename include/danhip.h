@@ -100,6 +100,29 @@ int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, i
 int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t* y, int64_t M, int32_t C, void* stream);
 int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const uint16_t* dy, uint16_t* dx, float* dgamma, int64_t M,
                       int32_t C, int accumulate, int relu_mask, void* stream);
+/* tf.image.resize_bilinear(up, size(lateral)) (TF1 legacy mapping src = dst*(in/out), align_corners=False) fused with the
+ * LFPN lateral add: out = lateral + resize(up) (lateral may be NULL) — net/pb_net.py:209-217, net/danet.py:363-371.
+ * up bf16 [N,Hi,Wi,C], lateral/out bf16 [N,Ho,Wo,C], C % 8 == 0.  bwd: d_up (=|+= if accumulate) from d_out (the lateral's
+ * gradient is d_out itself). */
+int danhip_resize_bilinear_add_fwd(const uint16_t* up, const uint16_t* lateral, uint16_t* out, int32_t N, int32_t Hi, int32_t Wi,
+                                   int32_t Ho, int32_t Wo, int32_t C, void* stream);
+int danhip_resize_bilinear_add_bwd(const uint16_t* dout, uint16_t* dup, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo,
+                                   int32_t C, int accumulate, void* stream);
+/* tf.layers.average_pooling2d((2,2), 1, 'same') — net/danet.py:854: pad (0,1), divisor = number of valid taps. */
+int danhip_avgpool2x2s1_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C, int accumulate,
+                                 void* stream);
+/* tf.layers.batch_normalization over the channel axis of [M,C] (M = N*H*W) — the conv_bn_relu / bn_relu / conv_bn surface of
+ * net/sfd_net.py:91-119 (momentum 0.997, eps 1e-5).  Training: batch statistics (biased variance), optional moving-average
+ * update, optional fused ReLU; workspace = 2*C floats.  Inference: caller passes mean and rstd = rsqrt(var + eps).
+ * Backward: dgamma, dbeta are overwritten. */
+int danhip_batchnorm_fwd_train(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* save_mean,
+                               float* save_rstd, float* moving_mean, float* moving_var, int64_t M, int32_t C, float eps,
+                               float momentum, int relu, float* workspace, void* stream);
+int danhip_batchnorm_fwd_infer(const uint16_t* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               uint16_t* y, int64_t M, int32_t C, int relu, void* stream);
+int danhip_batchnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* save_mean, const float* save_rstd,
+                         uint16_t* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, void* stream);
 /* preprocess_for_eval arithmetic (preprocessing/dan_preprocessing.py:55-57,755-758): uint8 RGB [npix,3] ->
  * bf16 [npix,8] = (B-103.94, G-116.78, R-123.68, 0,0,0,0,0). */
 int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64_t npix, void* stream);
@@ -160,6 +183,32 @@ int danhip_encode_anchors(const float* ymin, const float* xmin, const float* yma
 /* batch_decode_anchors / decode_anchors (anchor_manipulator.py:389-424). pred [B,A,4] -> boxes [B,A,4]. */
 int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmin, const float* ymax, const float* xmax,
                           float* boxes, int32_t B, int32_t A, float ps0, float ps1, float ps2, float ps3, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * DynamicAnchorRouting custom op (cpp/ExtraLib/dynamic_anchor_routing.cc:32-65 op def, :188-518 kernel; Python name
+ * utility/custom_op.py:52) — same tensors / scalars / attrs as the TF op, plus a leading batch B (the reference maps the op
+ * over the batch with tf.map_fn, train_dan.py:382): every array carries B images of N = feat_height*feat_width*anchor_depth
+ * rows.  img_height / img_width of the TF op are unused by its kernel and therefore not taken.
+ *   eval  (trainging=false, :328-408): mask_out in {0,1}, decode_out = stage-2 boxes decoded against the routed stage-1 box.
+ *   train (trainging=true,  :203-327): mask_out in {1,0,-1}, decode_out = stage-2 regression targets.  The reference draws
+ *          from std::mt19937(std::random_device) (not reproducible); here u(b,i) = splitmix64(seed, counter0 + b*N + i).
+ * ------------------------------------------------------------------------------------------------ */
+size_t danhip_routing_workspace_bytes(int64_t N, int32_t B, int training);
+int danhip_dynamic_anchor_routing_eval(const float* anchors, const float* gt_targets, const float* labels, const int32_t* mask_in,
+                                       int64_t N, int32_t feat_height, int32_t feat_width, int32_t anchor_depth, int32_t feat_strides,
+                                       int32_t B, int32_t* mask_out, float* decode_out, void* workspace, size_t workspace_bytes,
+                                       void* stream);
+int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_targets, const float* labels, const int32_t* mask_in,
+                                        int64_t N, int32_t feat_height, int32_t feat_width, int32_t anchor_depth, int32_t feat_strides,
+                                        int32_t B, float thres, float ignore_thres, uint64_t seed, uint64_t counter0, int32_t* mask_out,
+                                        float* decode_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* tf.image.non_max_suppression as used by utility/bbox_util.py:75-91: greedy over candidates already ordered by descending
+ * score (stable), suppress when IoU > iou_threshold (raw areas, no +1, corners normalised by min/max).
+ * boxes_sorted fp32 [B,K,4]; keep_idx int32 [B,max_out] = kept positions (-1 padded); num_keep int32 [B]. */
+int danhip_nms(const float* boxes_sorted, int32_t B, int32_t K, int32_t max_out, float iou_threshold, int32_t* keep_idx,
+               int32_t* num_keep, void* stream);
 
 #ifdef __cplusplus
 }
