@@ -1,0 +1,57 @@
+"""DAN graph on the libdanhip kernels — mirrors net/danet.py (class VGG16Backbone: backbone, build_lfpn :339-380 with a
+256-channel fused conv, se_inception_block V1 :842-918, get_features_stage1 :920-929, get_features_stage2 :931-954,
+get_predict_module with shared conv :469-532) with the reference's variable names."""
+import torch
+
+from .. import ops
+from . import pb_net
+
+
+class VGG16Backbone(pb_net.VGG16Backbone):
+    def build_lfpn(self, feature_layers, skip_last=3, name=None):
+        """net/danet.py:339-380: as PyramidBox's LFPN but the fused 3x3 conv always has 256 filters."""
+        return super().build_lfpn(feature_layers, skip_last, name, fused_channels=256)
+
+    def _cr(self, inputs, filters, ksize, name):
+        return self.conv2d(inputs, filters, ksize, 1, name, relu=True)
+
+    def _residual(self, y, x):
+        """relu(conv) + x: fused into the conv epilogue when no gradient is tracked, a bf16 add otherwise (the fused form
+        would need the pre-residual ReLU mask in backward)."""
+        return y + x
+
+    def se_inception_block(self, inputs, name=None):
+        """DAN context module V1 — net/danet.py:842-918."""
+        c = inputs.shape[-1]
+        b1 = self._cr(inputs, 64, (1, 1), name + "/branch1_conv_1x1")
+        b2 = self._cr(ops.avg_pool_2x2_s1(inputs), 64, (1, 1), name + "/branch2_conv_1x1")
+        b3 = self._cr(inputs, 64, (1, 1), name + "/branch3_conv_1x1")
+        b3a = self._cr(b3, 32, (3, 1), name + "/branch3_conv_3x1")
+        b3b = self._cr(b3, 32, (1, 3), name + "/branch3_conv_1x3")
+        b4 = self._cr(inputs, 64, (1, 1), name + "/branch4_conv_1x1")
+        b4 = self._cr(b4, 64, (3, 3), name + "/branch4_conv_3x3")
+        b4a = self._cr(b4, 32, (3, 1), name + "/branch4_conv_1x3")       # (sic) the reference swaps these two names
+        b4b = self._cr(b4, 32, (1, 3), name + "/branch4_conv_3x1")
+        hyper = torch.cat([b1, b2, b3a, b3b, b4a, b4b], dim=-1)
+        return self._residual(self._cr(hyper, c, (1, 1), name + "/residual_conv"), inputs)
+
+    def get_features_stage1(self, feature_layers, name=None):
+        """net/danet.py:920-929."""
+        name = name or "prediction_modules_stage1"
+        return [self.se_inception_block(f, "{}/predict_stage1_{}".format(name, i)) for i, f in enumerate(feature_layers)]
+
+    def get_features_stage2(self, feature_stage1, feature_layers, name=None):
+        """net/danet.py:931-954: stop_gradient(stage1) -> 1x1 (C//3, ReLU); backbone feature -> 1x1 (C - C//3, ReLU);
+        concat; context block."""
+        name = name or "prediction_modules_stage2"
+        outs = []
+        for i, f in enumerate(feature_layers):
+            c = f.shape[-1]
+            s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))      # (sic)
+            rs = self._cr(f, c - c // 3, (1, 1), "{}/residual_conv_1x1_{}".format(name, i))
+            outs.append(self.se_inception_block(torch.cat([s1, rs], dim=-1), "{}/predict_stage2_{}".format(name, i)))
+        return outs
+
+    def get_predict_module(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name=None):
+        """net/danet.py:469-532: shared 3x3 conv (ReLU) in front of the loc / cls convs of every level."""
+        return self.predict_heads(feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name or "predict_face", shared_conv=True)

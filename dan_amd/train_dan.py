@@ -1,0 +1,68 @@
+"""DAN / DAN-Deform training and inference graphs on libdanhip — the MI355X equivalent of the reference's
+train_dan.py / train_dan_deform.py (dan_model_fn :386-532) and eval_dan.py (:299-404)."""
+import torch
+
+from . import ops
+from .net import danet, sfd_net
+from .net.variables import VariableStore
+from .train_sfd import ALL_ANCHOR_SCALES, ALL_EXTRA_SCALES, ALL_LAYER_STRIDES, AnchorConfig
+from .utility import custom_op
+
+DAN_ANCHOR_RATIOS = [(0.8,)] * 6              # train_dan.py:183
+
+
+def dan_anchor_config(height, width, device):
+    """train_dan.py:181-203: ratio 0.8 anchors, dual-max matching 0.35/0.35 (match_mining=False)."""
+    return AnchorConfig(height, width, device, match_threshold=0.35, neg_threshold=0.35, ratios=DAN_ANCHOR_RATIOS)
+
+
+class DANModel(object):
+    def __init__(self, device="cuda", seed=20180817, deform=False):
+        self.vs = VariableStore(device=device, seed=seed)
+        if deform:
+            from .net import danet_deform
+            self.backbone = danet_deform.VGG16Backbone("channels_last", variables=self.vs)
+        else:
+            self.backbone = danet.VGG16Backbone("channels_last", variables=self.vs)
+
+    def forward(self, images_u8):
+        """train_dan.py:410-428 -> ((loc1 [B,A,4], cls1 [B,A,2]), (loc2, cls2), feature map sizes)."""
+        b = self.backbone
+        x = sfd_net.prepare_input(images_u8)
+        feats = b.get_featmaps(x, training=True)
+        feats = b.build_lfpn(feats, skip_last=3)
+        s1 = b.get_features_stage1(feats, name="prediction_modules_stage1")
+        s1 = b.build_lfpn(s1, skip_last=3, name="lfpn_stage1")
+        n = len(feats)
+        stage1 = b.get_predict_module(s1, [1] * n, [1] * n, [1] * n, name="predict_face")
+        s2 = b.get_features_stage2(s1, feats, name="prediction_modules_stage2")
+        s2 = b.build_lfpn(s2, skip_last=3, name="lfpn_stage2")
+        stage2 = b.get_predict_module(s2, [1] * n, [3] + [1] * (n - 1), [1] * n, name="predict_cascade")
+        return stage1, stage2, [(f.shape[1], f.shape[2]) for f in feats]
+
+    @torch.no_grad()
+    def predict(self, images_u8, anchors, select_thres=0.03):
+        """eval_dan.py:344-404: stage-1 boxes of levels 2.. plus the dynamically routed stage-2 boxes of every level.
+        Returns (bboxes_pred [B,A',4], cls_pred [B,A']) exactly as fetched at eval_dan.py:99."""
+        (loc1, cls1), (loc2, cls2), sizes = self.forward(images_u8)
+        enc = anchors.enc
+        score1 = torch.softmax(cls1, dim=-1)[..., -1]
+        score2 = torch.softmax(cls2, dim=-1)[..., -1]
+        boxes1 = enc.batch_decode_anchors(loc1, *anchors.anchors[:4])
+        scale = torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=loc2.device)       # eval_dan.py:384
+        out_boxes, out_scores = [], []
+        off = 0
+        per_level = anchors.num_anchors_per_layer
+        lvl_boxes, lvl_scores = [], []
+        for i, (nl, (fh, fw)) in enumerate(zip(per_level, sizes)):
+            sl = slice(off, off + nl)
+            mask_in = (score1[:, sl] > select_thres).to(torch.int32)
+            mo, do = custom_op.dynamic_anchor_routing(boxes1[:, sl].contiguous(), (loc2[:, sl] / scale).contiguous(), score2[:, sl].contiguous(), mask_in,
+                                                      fh, fw, anchors.depth[i], ALL_LAYER_STRIDES[i], images_u8.shape[1], images_u8.shape[2], False, 0.03, 0.0)
+            lvl_boxes.append(do)
+            lvl_scores.append(score2[:, sl] * mo.to(torch.float32))
+            off += nl
+        first = sum(per_level[:2])
+        out_boxes = [boxes1[:, first:]] + lvl_boxes               # eval_dan.py:401-404
+        out_scores = [score1[:, first:]] + lvl_scores
+        return torch.cat(out_boxes, dim=1), torch.cat(out_scores, dim=1)

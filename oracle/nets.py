@@ -132,6 +132,8 @@ def build_lfpn(P, feats, skip_last=3, name="lfpn", fused_channels=None):
         lat = conv(P, feats[ind - 1], down, (1, 1), 1, sc + "/lateral", relu=False)
         up = T.resize_bilinear_legacy(up, lat.shape[1], lat.shape[2])
         up = lat + up
+        if P.emulate_bf16:
+            up = T.round_bf16(up, True, True)                 # the merged map is a stored bf16 activation on the MI355X build
         outs.append(conv(P, up, fused_channels or down, (3, 3), 1, sc + "/fused_conv", relu=False))
     return list(reversed(outs)) + list(feats[skip_last:])
 
@@ -159,7 +161,10 @@ def se_inception_block_v1(P, x, name):
     c = x.shape[-1]
     cr = lambda inp, f, k, n: conv(P, inp, f, k, 1, name + "/" + n, relu=True)
     b1 = cr(x, 64, (1, 1), "branch1_conv_1x1")
-    b2 = cr(T.avg_pool_2x2_s1_same(x), 64, (1, 1), "branch2_conv_1x1")
+    ap = T.avg_pool_2x2_s1_same(x)
+    if P.emulate_bf16:
+        ap = T.round_bf16(ap, True, True)
+    b2 = cr(ap, 64, (1, 1), "branch2_conv_1x1")
     b3 = cr(x, 64, (1, 1), "branch3_conv_1x1")
     b3a = cr(b3, 32, (3, 1), "branch3_conv_3x1")
     b3b = cr(b3, 32, (1, 3), "branch3_conv_1x3")
@@ -168,7 +173,8 @@ def se_inception_block_v1(P, x, name):
     b4a = cr(b4, 32, (3, 1), "branch4_conv_1x3")      # (sic) names swapped in the reference
     b4b = cr(b4, 32, (1, 3), "branch4_conv_3x1")
     hyper = torch.cat([b1, b2, b3a, b3b, b4a, b4b], dim=-1)
-    return cr(hyper, c, (1, 1), "residual_conv") + x
+    out = cr(hyper, c, (1, 1), "residual_conv") + x
+    return T.round_bf16(out, True, True) if P.emulate_bf16 else out
 
 
 def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False):
