@@ -47,6 +47,8 @@ SIGNATURES = {
     "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P,
                                             ctypes.c_size_t, P],
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
+    "danhip_deform_sample_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
+    "danhip_deform_sample_bwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, P],
     "danhip_cast_pad_f32_to_bf16": [P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],

@@ -1,0 +1,226 @@
+// Deformable convolution sampling for gfx950 — the arithmetic of cpp/Deform/deform_conv.cu (deformable_im2col_bilinear
+// :91-126, deformable_im2col_gpu_kernel :229-275, deformable_col2im_coord_gpu_kernel :335-389 + get_coordinate_weight
+// :177-221, deformable_col2im_gpu_kernel :281-328 + get_gradient_weight :130-173) restated for NHWC bf16 tensors.
+//
+// DeformConvOp (cpp/Deform/deform_conv.cc:392-535) = per sample { deformable im2col ; GEMM with W[Cout, Cin*kh*kw] }.
+// Here the im2col is the batched kernel below writing S[pixel][tap*C + c] (bf16, K-contiguous), and the GEMM is the MFMA
+// convolution kernel run as a 1x1 convolution over S (forward, data gradient = dS, weight gradient) — see
+// dan_amd/ops.py:deform_conv_op.  DeformConvBackpropOp (:635-771): dS = dY * W (1x1 data gradient), then
+// deform_sample_bwd produces dOffset (gather over the group's channels) and dX (bilinear scatter, fp32 atomics as the
+// reference does with CudaAtomicAdd :314-326).
+//
+// Offsets: NHWC [B,Ho,Wo, dg*2*kh*kw], channel (g*kh*kw + t)*2 + {0: dh, 1: dw}  (deform_conv.cu:251-259).
+#include "common.h"
+
+namespace {
+
+struct DeformGeom {
+  int N, H, W, C, Ho, Wo, kh, kw, stride, dil, dg, pad_t, pad_l;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+  return u;
+}
+
+// one thread per (output pixel m, tap t, 8-channel chunk): S[m][t*C + 8*chunk .. +8]
+__global__ void deform_sample_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, bf16_t* __restrict__ S, DeformGeom g) {
+  const int taps = g.kh * g.kw, cch = g.C / 8, cpg8 = g.C / g.dg / 8;
+  const long total = (long)g.N * g.Ho * g.Wo * taps * cch;
+  const int offc = g.dg * 2 * taps;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(idx % cch);
+    long r = idx / cch;
+    const int t = (int)(r % taps);
+    const long m = r / taps;
+    const int wo = (int)(m % g.Wo);
+    const int ho = (int)((m / g.Wo) % g.Ho);
+    const int n = (int)(m / ((long)g.Wo * g.Ho));
+    const int grp = chunk / cpg8;
+    const int i = t / g.kw, j = t % g.kw;
+    const int h_in = ho * g.stride - g.pad_t, w_in = wo * g.stride - g.pad_l;
+    const bf16_t* op = offs + m * offc + (grp * taps + t) * 2;
+    const float off_h = bf2f(op[0]), off_w = bf2f(op[1]);
+    const float h_im = (float)(h_in + i * g.dil) + off_h;             // deform_conv.cu:261-262
+    const float w_im = (float)(w_in + j * g.dil) + off_w;
+    float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (h_im >= 0 && w_im >= 0 && h_im < g.H && w_im < g.W) {         // :263
+      float mh = (float)(i * g.dil) + off_h, mw = (float)(j * g.dil) + off_w;     // :264-265 (relative to (h_in, w_in))
+      const int cur_h = g.H - h_in, cur_w = g.W - w_in;               // :266-268
+      int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;       // deformable_im2col_bilinear :94-112
+      if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
+      if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
+      const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
+      const bf16_t* base = x + ((long)n * g.H * g.W) * g.C + chunk * 8;
+      float v1[8], v2[8], v3[8], v4[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_low) * g.W + (w_in + w_low)) * g.C), v1);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_low) * g.W + (w_in + w_high)) * g.C), v2);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_high) * g.W + (w_in + w_low)) * g.C), v3);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_high) * g.W + (w_in + w_high)) * g.C), v4);
+      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;         // :118-125
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+    }
+    *reinterpret_cast<uint4*>(S + (m * taps + t) * g.C + chunk * 8) = pack8(out);
+  }
+}
+
+// backward: dS [M][taps*C] -> dOffset [M][dg*2*taps] (bf16, written), dX fp32 [N,H,W,C] (atomic +=, zero it first)
+// thread = (m, t, 8-channel chunk); the chunks of one deformable group are consecutive lanes (cpg8 a power of two <= 32)
+__global__ void deform_sample_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                         float* __restrict__ dx, bf16_t* __restrict__ doffs, DeformGeom g) {
+  const int taps = g.kh * g.kw, cch = g.C / 8, cpg8 = g.C / g.dg / 8;
+  const long total = (long)g.N * g.Ho * g.Wo * taps * cch;
+  const int offc = g.dg * 2 * taps;
+  const long total_pad = (total + blockDim.x - 1) / blockDim.x * blockDim.x;        // keep whole waves alive for the shuffles
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_pad; idx += (long)gridDim.x * blockDim.x) {
+    const bool live = idx < total;
+    const long id = live ? idx : total - 1;
+    const int chunk = (int)(id % cch);
+    long r = id / cch;
+    const int t = (int)(r % taps);
+    const long m = r / taps;
+    const int wo = (int)(m % g.Wo);
+    const int ho = (int)((m / g.Wo) % g.Ho);
+    const int n = (int)(m / ((long)g.Wo * g.Ho));
+    const int grp = chunk / cpg8;
+    const int i = t / g.kw, j = t % g.kw;
+    const int h_in = ho * g.stride - g.pad_t, w_in = wo * g.stride - g.pad_l;
+    const bf16_t* op = offs + m * offc + (grp * taps + t) * 2;
+    const float inv_h = (float)(h_in + i * g.dil) + bf2f(op[0]);      // absolute sample coordinate (:365-366, :304-305)
+    const float inv_w = (float)(w_in + j * g.dil) + bf2f(op[1]);
+    float cg[8];
+    unpack8(*reinterpret_cast<const uint4*>(dS + (m * taps + t) * g.C + chunk * 8), cg);
+    const bf16_t* base = x + ((long)n * g.H * g.W) * g.C + chunk * 8;
+    const float Hf = (float)g.H, Wf = (float)g.W;
+    // ---- dOffset: get_coordinate_weight (:177-221); out-of-range samples give 0 (:371-373)
+    float s_h = 0.f, s_w = 0.f;
+    if (!(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf)) {
+      float ih = inv_h, iw = inv_w;
+      int h_low = (int)ih, w_low = (int)iw, h_high, w_high;           // (int) truncation as in the reference
+      if (h_low >= g.H - 1) { h_high = h_low = g.H - 1; ih = (float)h_low; } else h_high = h_low + 1;
+      if (w_low >= g.W - 1) { w_high = w_low = g.W - 1; iw = (float)w_low; } else w_high = w_low + 1;
+      float vll[8], vlh[8], vhl[8], vhh[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)h_low * g.W + w_low) * g.C), vll);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)h_low * g.W + w_high) * g.C), vlh);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)h_high * g.W + w_low) * g.C), vhl);
+      unpack8(*reinterpret_cast<const uint4*>(base + ((long)h_high * g.W + w_high) * g.C), vhh);
+      const float a_w = (float)(w_low + 1) - iw, b_w = iw - (float)w_low;
+      const float a_h = (float)(h_low + 1) - ih, b_h = ih - (float)h_low;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float wgt_h = -1.f * a_w * vll[e] + -1.f * b_w * vlh[e] + a_w * vhl[e] + b_w * vhh[e];
+        const float wgt_w = -1.f * a_h * vll[e] + a_h * vlh[e] + -1.f * b_h * vhl[e] + b_h * vhh[e];
+        s_h += wgt_h * cg[e];
+        s_w += wgt_w * cg[e];
+      }
+    }
+    if (!live) { s_h = 0.f; s_w = 0.f; }
+    for (int o = 1; o < cpg8; o <<= 1) { s_h += __shfl_xor(s_h, o); s_w += __shfl_xor(s_w, o); }
+    if (live && (chunk % cpg8) == 0) {
+      bf16_t* dp = doffs + m * offc + (grp * taps + t) * 2;
+      dp[0] = f2bf(s_h);
+      dp[1] = f2bf(s_w);
+    }
+    // ---- dX: get_gradient_weight (:130-173) scattered to the <= 4 corners (:311-326)
+    if (live && !(inv_h < 0 || inv_h > Hf || inv_w < 0 || inv_w > Wf)) {
+      float ah = fmaxf(inv_h, 0.f), aw = fmaxf(inv_w, 0.f);
+      int hl = (int)ah, wl = (int)aw, hh, wh;
+      const bool ch = hl >= g.H - 1, cw = wl >= g.W - 1;
+      if (ch) { hh = hl = g.H - 1; ah = (float)hl; } else hh = hl + 1;
+      if (cw) { wh = wl = g.W - 1; aw = (float)wl; } else wh = wl + 1;
+      const int rh[4] = {hl, hl, hh, hh}, rw[4] = {wl, wh, wl, wh};
+      const float wg[4] = {((float)(hl + 1) - ah) * ((float)(wl + 1) - aw), ((float)(hl + 1) - ah) * (aw + 1.f - (float)wh),
+                           (ah + 1.f - (float)hh) * ((float)(wl + 1) - aw), (ah + 1.f - (float)hh) * (aw + 1.f - (float)wh)};
+      const bool dup[4] = {false, cw, ch, ch || cw};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = !dup[k] && fabsf(inv_h - (float)rh[k]) < 1.f && fabsf(inv_w - (float)rw[k]) < 1.f && rh[k] >= 0 && rh[k] < g.H &&
+                        rw[k] >= 0 && rw[k] < g.W;
+        if (ok) {
+          float* dst = dx + (((long)n * g.H + rh[k]) * g.W + rw[k]) * g.C + chunk * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) atomicAdd(dst + e, wg[k] * cg[e]);
+        }
+      }
+    }
+  }
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+    float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (accumulate) {
+      float o[8];
+      unpack8(*reinterpret_cast<const uint4*>(dst + i * 8), o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += o[e];
+    }
+    *reinterpret_cast<uint4*>(dst + i * 8) = pack8(f);
+  }
+}
+
+int make_geom(DeformGeom* g, int N, int H, int W, int C, int kh, int kw, int stride, int dil, int dg, const char* what) {
+  DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && dg > 0, DANHIP_EINVAL, "%s: non-positive dims", what);
+  DH_REQUIRE(C % dg == 0 && (C / dg) % 8 == 0, DANHIP_EINVAL, "%s: C/deformable_group must be a multiple of 8", what);
+  const int cpg8 = C / dg / 8;
+  DH_REQUIRE((cpg8 & (cpg8 - 1)) == 0 && cpg8 <= 32, DANHIP_EINVAL, "%s: C/deformable_group/8 must be a power of two <= 32", what);
+  g->N = N; g->H = H; g->W = W; g->C = C; g->kh = kh; g->kw = kw; g->stride = stride; g->dil = dil; g->dg = dg;
+  g->Ho = (H + stride - 1) / stride;
+  g->Wo = (W + stride - 1) / stride;
+  // SAME pad_before from the UNDILATED kernel (deform_conv.cc:473-479)
+  int th = (g->Ho - 1) * stride + kh - H; if (th < 0) th = 0;
+  int tw = (g->Wo - 1) * stride + kw - W; if (tw < 0) tw = 0;
+  g->pad_t = th / 2; g->pad_l = tw / 2;
+  DH_REQUIRE((int64_t)N * g->Ho * g->Wo * kh * kw * C < (1ll << 40), DANHIP_EINVAL, "%s: tensor too large", what);
+  return DANHIP_OK;
+}
+
+inline int grid_for(long total, int block = 256, int cap = 16384) {
+  long b = (total + block - 1) / block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+/* S [N*Ho*Wo, kh*kw*C] bf16 = deformable im2col of x [N,H,W,C] under offsets [N,Ho,Wo,dg*2*kh*kw] (both bf16). */
+extern "C" int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offsets, uint16_t* S, int32_t N, int32_t H, int32_t W, int32_t C,
+                                        int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, void* stream) {
+  DH_REQUIRE(x && offsets && S, DANHIP_EINVAL, "deform_sample_fwd: null pointer");
+  DeformGeom g;
+  int rc = make_geom(&g, N, H, W, C, kh, kw, stride, dilation, deformable_group, "deform_sample_fwd");
+  if (rc) return rc;
+  const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
+  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, offsets, S, g);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+/* dS [N*Ho*Wo, kh*kw*C] -> d_offsets bf16 [N,Ho,Wo,dg*2*kh*kw] (overwritten) and dx bf16 [N,H,W,C] (=|+= if accumulate).
+ * workspace: N*H*W*C floats (fp32 scatter target), zeroed inside. */
+extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
+                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
+                                        int32_t deformable_group, int accumulate, float* workspace, void* stream) {
+  DH_REQUIRE(x && offsets && dS && dx && d_offsets && workspace, DANHIP_EINVAL, "deform_sample_bwd: null pointer");
+  DeformGeom g;
+  int rc = make_geom(&g, N, H, W, C, kh, kw, stride, dilation, deformable_group, "deform_sample_bwd");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const long nx = (long)N * H * W * C;
+  if (hipMemsetAsync(workspace, 0, sizeof(float) * nx, s) != hipSuccess) { danhip_set_error("deform_sample_bwd: memset failed"); return DANHIP_ELAUNCH; }
+  const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
+  hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+  DH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}

@@ -504,3 +504,36 @@ def batch_norm_infer(x, gamma, beta, moving_mean, moving_var, eps=1e-5, relu=Fal
     rstd = torch.rsqrt(moving_var + eps)
     call("danhip_batchnorm_fwd_infer", ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(moving_mean), ptr(rstd), ptr(y), x.numel() // C, C, int(relu), stream())
     return y
+
+
+class _DeformSample(torch.autograd.Function):
+    """Deformable im2col (cpp/Deform/deform_conv.cu:229-275) and its backward (col2im :281-328, col2im_coord :335-389):
+    x bf16 [N,H,W,C], offsets bf16 [N,Ho,Wo,dg*2*kh*kw] -> S bf16 [N,Ho,Wo,kh*kw*C] (k = tap*C + c)."""
+
+    @staticmethod
+    def forward(ctx, x, offsets, kh, kw, stride, dilation, dg):
+        N, H, W, C = x.shape
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        assert x.dtype == torch.bfloat16 and offsets.dtype == torch.bfloat16 and x.is_contiguous() and offsets.is_contiguous()
+        assert offsets.shape == (N, Ho, Wo, dg * 2 * kh * kw), (offsets.shape, (N, Ho, Wo, dg * 2 * kh * kw))
+        S = torch.empty((N, Ho, Wo, kh * kw * C), dtype=torch.bfloat16, device=x.device)
+        call("danhip_deform_sample_fwd", ptr(x), ptr(offsets), ptr(S), N, H, W, C, kh, kw, stride, dilation, dg, stream())
+        ctx.save_for_backward(x, offsets)
+        ctx.cfg = (kh, kw, stride, dilation, dg)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        x, offsets = ctx.saved_tensors
+        kh, kw, stride, dilation, dg = ctx.cfg
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        doff = torch.empty_like(offsets)
+        ws = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+        call("danhip_deform_sample_bwd", ptr(x), ptr(offsets), ptr(dS.contiguous()), ptr(dx), ptr(doff), N, H, W, C, kh, kw, stride, dilation, dg, 0,
+             ptr(ws), stream())
+        return dx, doff, None, None, None, None, None
+
+
+def deform_sample(x, offsets, kh, kw, stride=1, dilation=1, deformable_group=1):
+    return _DeformSample.apply(x, offsets, kh, kw, stride, dilation, deformable_group)

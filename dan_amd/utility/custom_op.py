@@ -38,3 +38,46 @@ def dynamic_anchor_routing(anchors, gt_targets, labels, mask_in, feat_height, fe
         call("danhip_dynamic_anchor_routing_eval", ptr(a), ptr(g), ptr(l), ptr(m), N, int(feat_height), int(feat_width), int(anchor_depth),
              int(feat_strides), B, ptr(mo), ptr(do), ptr(ws), nws, stream())
     return mo, do
+
+
+def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, deformable_group, bias=None, relu=False):
+    """custom_op.deform_conv_op (utility/custom_op.py:62; DeformConvOp cpp/Deform/deform_conv.cc:51-167) on NHWC tensors:
+    x bf16 [N,H,W,C], filter fp32 OIHW [Cout,C,kh,kw] (the reference's variable layout, custom_op.py:134), offset bf16
+    [N,Ho,Wo,dg*2*kh*kw].  rates / strides are the reference's 4-vectors [1,1,r,r] / [1,1,s,s].
+    = deformable im2col (HIP gather kernel) followed by the MFMA convolution kernel run as a 1x1 GEMM over the samples;
+    autograd composes DeformConvBackpropOp from the two backward kernels.  `bias` / `relu` fuse the Python-side bias add of
+    deform_conv_2d (custom_op.py:145) and the activation that follows it into the GEMM epilogue."""
+    from .. import ops
+    if padding != "SAME":
+        raise ValueError("only padding='SAME' is used by the reference graphs (net/danet_deform.py:279)")
+    if num_groups != 1:
+        raise ValueError("num_groups must be 1 (custom_op.py:141)")
+    if len(rates) != 4 or len(strides) != 4 or rates[2] != rates[3] or strides[2] != strides[3]:
+        raise ValueError("rates / strides must be [1, 1, r, r] / [1, 1, s, s] (deform_conv.cc:409-438)")
+    cout, cin, kh, kw = filter.shape
+    if x.shape[-1] != cin:
+        raise ValueError("filter expects %d input channels, input has %d" % (cin, x.shape[-1]))
+    if offset.shape[-1] != 2 * kh * kw * deformable_group:
+        raise ValueError("offset must have 2*kh*kw*deformable_group = %d channels (deform_conv.cc:116), got %d"
+                         % (2 * kh * kw * deformable_group, offset.shape[-1]))
+    S = ops.deform_sample(x, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group)
+    w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
+    return ops.conv2d(S, w1x1, bias, stride=1, relu=relu)
+
+
+def deform_conv_2d(inputs, num_outputs, kernel_size_h=3, kernel_size_w=3, stride=1, dilate_rate=1, deformable_group=1,
+                   data_format="channels_last", no_bias=True, kernel_initializer="glorot_oihw", name=None, variables=None, relu=False):
+    """custom_op.deform_conv_2d (utility/custom_op.py:128-146): zero-initialised offset conv (tf.layers default name
+    'conv2d'), OIHW kernel variable 'kernel', optional 'bias'.  `variables` is the VariableStore (tf.get_variable)."""
+    from .. import ops
+    if data_format != "channels_last":
+        raise ValueError("the MI355X build is NHWC-native")
+    name = name or "deform_conv"
+    cin = inputs.shape[-1]
+    noff = 2 * deformable_group * kernel_size_h * kernel_size_w
+    ow = variables.get(name + "/conv2d/kernel", (kernel_size_h, kernel_size_w, cin, noff), "zeros")
+    ob = variables.get(name + "/conv2d/bias", (noff,), "zeros")
+    offset = ops.conv2d(inputs, ow, ob, stride=stride, relu=False)
+    kernel = variables.get(name + "/kernel", (num_outputs, cin, kernel_size_h, kernel_size_w), kernel_initializer)
+    bias = None if no_bias else variables.get(name + "/bias", (num_outputs,), "zeros")
+    return deform_conv_op(inputs, kernel, offset, [1, 1, dilate_rate, dilate_rate], "SAME", [1, 1, stride, stride], 1, deformable_group, bias=bias, relu=relu)

@@ -186,6 +186,23 @@ int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmi
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Deformable convolution (cpp/Deform: DeformConvOp deform_conv.cc:51-167,392-535; DeformConvBackpropOp :170-189,635-771;
+ * Python names utility/custom_op.py:62-63).  The reference computes, per sample, deformable_im2col + GEMM; here the
+ * im2col is danhip_deform_sample_fwd (batched, NHWC bf16, sampling rules of deform_conv.cu:91-126,229-275) and the GEMM is
+ * danhip_conv2d_{fwd,bwd_data,bwd_weight} run as a 1x1 convolution over S [N,Ho,Wo,kh*kw*C] with the OIHW filter variable
+ * viewed as HWIO [1,1,kh*kw*C,Cout] (k = tap*C + c).  Backward: dS from danhip_conv2d_bwd_data, then
+ * danhip_deform_sample_bwd = deformable_col2im_coord (d_offsets) + deformable_col2im (dx; fp32 atomics as the reference).
+ * offsets: NHWC [N,Ho,Wo,dg*2*kh*kw], channel (g*kh*kw + tap)*2 + {0: dh, 1: dw} (deform_conv.cu:251-259) — the NHWC
+ * transpose of the reference's NCHW offset tensor.  SAME padding from the undilated kernel (deform_conv.cc:473-479).
+ * ------------------------------------------------------------------------------------------------ */
+int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offsets, uint16_t* S, int32_t N, int32_t H, int32_t W, int32_t C,
+                             int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, void* stream);
+/* workspace: N*H*W*C floats */
+int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
+                             int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
+                             int32_t deformable_group, int accumulate, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * DynamicAnchorRouting custom op (cpp/ExtraLib/dynamic_anchor_routing.cc:32-65 op def, :188-518 kernel; Python name
  * utility/custom_op.py:52) — same tensors / scalars / attrs as the TF op, plus a leading batch B (the reference maps the op
  * over the batch with tf.map_fn, train_dan.py:382): every array carries B images of N = feat_height*feat_width*anchor_depth

@@ -1,0 +1,55 @@
+"""Parity of the deformable convolution (deformable im2col HIP kernel + MFMA GEMM, through custom_op.deform_conv_op)
+against the oracle restatement of cpp/Deform (oracle/deform.py): forward, dX, dW, dOffset; the identity
+"zero offsets == SAME conv" (custom_op.py:132 initial state); samples outside the image; the high-edge clamp."""
+import pytest
+import torch
+
+from oracle import deform as OD
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, N, H, W, C, Cout, dg, off_scale):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((N, H, W, C), generator=g).to(torch.bfloat16)
+    w = (torch.randn((Cout, C, 3, 3), generator=g) / (9 * C) ** 0.5).to(torch.bfloat16).float()
+    off = (torch.randn((N, H, W, dg * 18), generator=g) * off_scale).to(torch.bfloat16)
+    return x, w, off
+
+
+@pytest.mark.parametrize("seed,N,H,W,C,Cout,dg,off_scale", [(0, 1, 8, 8, 64, 64, 4, 0.0), (1, 2, 9, 7, 64, 32, 4, 1.5), (2, 1, 12, 12, 128, 64, 2, 4.0),
+                                                            (3, 1, 6, 10, 256, 256, 4, 0.7)])
+def test_deform_conv_forward_backward(seed, N, H, W, C, Cout, dg, off_scale, dev):
+    from dan_amd.utility import custom_op
+    x, w, off = _case(seed, N, H, W, C, Cout, dg, off_scale)
+    xr, wr, offr = x.float(), w.clone(), off.float()
+    ref = OD.deform_conv_forward(xr.permute(0, 3, 1, 2), wr, offr.permute(0, 3, 1, 2), 1, 1, dg).permute(0, 2, 3, 1)
+    g = torch.Generator().manual_seed(100 + seed)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    dxr, dwr, doffr = OD.deform_conv_backward(xr.permute(0, 3, 1, 2), wr, offr.permute(0, 3, 1, 2), dy.float().permute(0, 3, 1, 2), 1, 1, dg)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    od = off.to(dev).requires_grad_(True)
+    y = custom_op.deform_conv_op(xd, wd, od, [1, 1, 1, 1], "SAME", [1, 1, 1, 1], 1, dg)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    # forward: S is rounded to bf16 before the GEMM and y once more: 2 bf16 roundings
+    assert (y.float().cpu() - ref).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item() + 1e-3
+    if off_scale == 0.0:                                # identity KAT: zero offsets == plain SAME convolution
+        plain = T.conv2d_same(xr, wr.permute(2, 3, 1, 0).contiguous(), None, stride=1)
+        assert (y.float().cpu() - plain).abs().max().item() <= 2.0 ** -7 * plain.abs().max().item() + 1e-3
+    for name, got, want in (("dx", xd.grad.float().cpu(), dxr.permute(0, 2, 3, 1)), ("dw", wd.grad.cpu(), dwr),
+                            ("doffset", od.grad.float().cpu(), doffr.permute(0, 2, 3, 1))):
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= 2.0 ** -5 * scale + 2e-3, (name, err, scale)      # dS (bf16) feeds both gradients: 3 roundings
+
+
+def test_deform_conv_rejects_bad_arguments(dev):
+    from dan_amd.utility import custom_op
+    x, w, off = _case(0, 1, 4, 4, 64, 64, 4, 0.0)
+    with pytest.raises(ValueError):
+        custom_op.deform_conv_op(x.to(dev), w.to(dev), off.to(dev)[..., :70].contiguous(), [1, 1, 1, 1], "SAME", [1, 1, 1, 1], 1, 4)
+    with pytest.raises(ValueError):
+        custom_op.deform_conv_op(x.to(dev), w.to(dev), off.to(dev), [1, 1, 1, 1], "VALID", [1, 1, 1, 1], 1, 4)
