@@ -66,3 +66,64 @@ class DANModel(object):
         out_boxes = [boxes1[:, first:]] + lvl_boxes               # eval_dan.py:401-404
         out_scores = [score1[:, first:]] + lvl_scores
         return torch.cat(out_boxes, dim=1), torch.cat(out_scores, dim=1)
+
+
+from .train_sfd import DetectorTrainer  # noqa: E402
+
+ROUTING_THRES = [0.4, 0.5, 0.6, 0.7, 0.8, 0.9]                 # train_dan.py:440
+ROUTING_IGNORE = [0.35, 0.4, 0.45, 0.5, 0.55, 0.6]
+
+
+def anchor_routing(decoded_bbox, gt_bboxes, gt_labels, easy_mask, feat_sizes, feat_strides, all_num_anchors_depth, num_anchors_per_layer,
+                   threshold_per_layer, ignore_threshold_per_layer, image_size, seed, counter0):
+    """train_dan.py:357-384: split per pyramid level, dynamic_anchor_routing(training) per level (batched over images),
+    concat.  -> (final_mask int32 [B,A], final_loc_targets fp32 [B,A,4]); no gradient."""
+    masks, targets = [], []
+    off = 0
+    B = decoded_bbox.shape[0]
+    for i, nl in enumerate(num_anchors_per_layer):
+        sl = slice(off, off + nl)
+        mo, do = custom_op.dynamic_anchor_routing(decoded_bbox[:, sl].contiguous(), gt_bboxes[:, sl].contiguous(), gt_labels[:, sl].contiguous(),
+                                                  easy_mask[:, sl].contiguous(), feat_sizes[i][0], feat_sizes[i][1], all_num_anchors_depth[i], feat_strides[i],
+                                                  image_size[0], image_size[1], True, threshold_per_layer[i], ignore_threshold_per_layer[i],
+                                                  seed=seed, counter0=counter0 + off * B)
+        masks.append(mo)
+        targets.append(do)
+        off += nl
+    return torch.cat(masks, dim=1), torch.cat(targets, dim=1)
+
+
+class DANTrainer(DetectorTrainer):
+    """dan_model_fn (train_dan.py:386-532): stage-1 loss against the encoded anchors, dynamic anchor routing of the decoded
+    stage-1 boxes into stage-2 targets (x [20,20,10,10], :452), stage-2 loss; mining keeps at least one negative (:302)."""
+
+    def __init__(self, model, anchors, routing_seed=20180817, **kw):
+        super().__init__(model, **kw)
+        self.anchors = anchors
+        self.routing_seed = routing_seed
+
+    def loss_terms(self, images_u8, loc_targets, cls_targets, matched_gt):
+        (loc1, cls1), (loc2, cls2), sizes = self.model.forward(images_u8)
+        a = self.anchors
+        with torch.no_grad():
+            bboxes_pred = a.enc.batch_decode_anchors(loc1.detach(), *a.anchors[:4])                       # :430
+            easy = (torch.softmax(cls1.detach(), dim=-1)[..., -1] > 0.03).to(torch.int32)                 # :438-439
+            B, A = cls_targets.shape
+            final_mask, final_loc = anchor_routing(bboxes_pred, matched_gt, (cls_targets > 0).to(torch.float32), easy, sizes, ALL_LAYER_STRIDES,
+                                                   a.depth, a.num_anchors_per_layer, ROUTING_THRES, ROUTING_IGNORE, images_u8.shape[1:3],
+                                                   self.routing_seed, self.step_no * B * A)
+            final_loc = final_loc * torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=final_loc.device)    # :452
+        acc1 = ops.detection_loss(cls1, loc1, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=True, scale=1.0 / self.world)
+        acc2 = ops.detection_loss(cls2, loc2, final_mask, final_loc, ratio=self.negative_ratio, at_least_one=True, scale=1.0 / self.world)
+        self.last_routing = (final_mask, final_loc)
+        return [("stage1", 1.0, acc1), ("stage2", 1.0, acc2)]
+
+
+def encode_batch_dan(anchors, gt_boxes_list):
+    """anchor_encoder_fn of train_dan.py:206 per image -> (loc_targets [B,A,4], cls_targets [B,A] int32, matched_gt [B,A,4])."""
+    ymin, xmin, ymax, xmax, inside = anchors.anchors
+    loc, cls, mgt = [], [], []
+    for b in gt_boxes_list:
+        t, l, _, m = anchors.enc.encode_anchors(b.to(ymin.device), ymin, xmin, ymax, xmax, inside, match_mining=False)
+        loc.append(t); cls.append(l); mgt.append(m)
+    return torch.stack(loc), torch.stack(cls), torch.stack(mgt)

@@ -33,3 +33,51 @@ class PBModel(object):
         loc, cls = self.forward(images_u8)["face"]
         boxes = anchors.enc.batch_decode_anchors(loc, *anchors.anchors[:4])
         return boxes, torch.softmax(cls, dim=-1)[..., 1]
+
+
+class PBAnchorTargets(object):
+    """Anchor targets of the PyramidBox input pipeline (train_pb.py:173-247): face anchors on all 6 levels (small-mining
+    match 0.4/0.4), head anchors on levels 1.. matched against the face boxes with anchors shrunk by 2 (dual-max 0.35),
+    body anchors on levels 2.. shrunk by 4."""
+
+    def __init__(self, height, width, device):
+        self.face = AnchorConfig(height, width, device)
+        self.device = device
+        n = self.face.num_anchors_per_layer
+        self.head_off, self.body_off = n[0], n[0] + n[1]
+
+    def _sub(self, off):
+        return tuple(t[off:].contiguous() for t in self.face.anchors)
+
+    def encode_batch(self, gt_boxes_list):
+        enc = self.face.enc
+        out = {k: ([], [], []) for k in ("face", "head", "body")}
+        fa, ha, ba = self.face.anchors, self._sub(self.head_off), self._sub(self.body_off)
+        for b in gt_boxes_list:
+            b = b.to(self.device)
+            t, l, s, _ = enc.encode_anchors(b, *fa, match_mining=True)
+            out["face"][0].append(t); out["face"][1].append(l); out["face"][2].append(s)
+            t, l, s, _ = enc.encode_pa_anchors(b, *ha, 0.35, 0.35, match_mining=False, scale=2.)       # train_pb.py:218
+            out["head"][0].append(t); out["head"][1].append(l); out["head"][2].append(s)
+            t, l, s, _ = enc.encode_pa_anchors(b, *ba, 0.35, 0.35, match_mining=False, scale=4.)       # train_pb.py:223
+            out["body"][0].append(t); out["body"][1].append(l); out["body"][2].append(s)
+        return {k: tuple(torch.stack(v) for v in out[k]) for k in out}
+
+
+from .train_sfd import DetectorTrainer  # noqa: E402
+
+
+class PBTrainer(DetectorTrainer):
+    """pb_model_fn (train_pb.py:350-520): total = face + 0.66 * head + 0.33 * body (+ L2), each term
+    CE*(ratio+1) over mined rows + smooth-L1 over positives (:440-504)."""
+    WEIGHTS = {"face": 1.0, "head": 0.66, "body": 0.33}
+
+    def loss_terms(self, images_u8, targets):
+        out = self.model.forward(images_u8)
+        terms = []
+        for k in ("face", "head", "body"):
+            loc, cls = out[k]
+            loc_t, cls_t, _ = targets[k]
+            acc = ops.detection_loss(cls, loc, cls_t, loc_t, ratio=self.negative_ratio, at_least_one=False, scale=self.WEIGHTS[k] / self.world)
+            terms.append((k, self.WEIGHTS[k], acc))
+        return terms

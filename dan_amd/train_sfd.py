@@ -70,15 +70,21 @@ class SFDModel(object):
         return boxes, torch.softmax(cls, dim=-1)[..., 1]
 
 
-class SFDTrainer(object):
-    """sfd_model_fn (train_sfd.py:261-467) + Momentum optimizer; `world` ranks each see batch/world images."""
+class DetectorTrainer(object):
+    """Shared body of the reference's *_model_fn training branch (train_sfd.py:261-467, train_pb.py:350-520,
+    train_dan.py:386-532): forward -> loss terms (hard-negative mining + CE*(ratio+1) + smooth-L1, each with its weight)
+    -> backward into the flat gradient buffer (+ bucketed all-reduce) -> fused momentum SGD (L2 term, bias gradient x2).
+    `world` ranks each see batch/world images; every term's gradient carries the 1/world of tf_replicate_model_fn.py:297-302.
+    Subclasses implement loss_terms(images_u8, *targets) -> list of (name, acc4 tensor)."""
 
-    def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64)):
+    def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64),
+                 lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01)):
         self.model = model
         self.world = world
         self.negative_ratio = negative_ratio
         self.momentum = momentum
         self.base_lr = base_lr
+        self.lr_boundaries, self.lr_factors = lr_boundaries, lr_factors
         dev = model.vs.device
         with torch.no_grad():       # create every variable (shapes do not depend on the image size)
             model.forward(torch.zeros((1, init_hw[0], init_hw[1], 3), dtype=torch.uint8, device=dev))
@@ -93,27 +99,50 @@ class SFDTrainer(object):
         if n is not None:
             self.buckets.ready(n)
 
-    def train_step(self, images_u8, loc_targets, cls_targets):
-        """One optimisation step on this rank's shard.  Returns the device 4-vector [ce_sum, n_sel, loc_sum, n_pos]."""
+    def loss_terms(self, images_u8, *targets):
+        raise NotImplementedError
+
+    def train_step(self, images_u8, *targets):
+        """One optimisation step on this rank's shard.  Returns the list of (name, weight, device 4-vector
+        [ce_sum, n_selected, loc_sum, n_pos]) loss terms (no host sync)."""
         self.flat.zero_grad()
         self.buckets.begin_step()
         ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
-        loc, cls = self.model.forward(images_u8)
-        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=1.0 / self.world)
-        acc.backward(torch.ones_like(acc))
+        terms = self.loss_terms(images_u8, *targets)
+        accs = [t[2] for t in terms]
+        torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
         ops.GRAD_READY_HOOK = None
         self.buckets.finish()
-        lr = lr_schedule(self.step_no, self.base_lr)
+        lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
         self.flat.sgd_step(lr, self.momentum, grad_scale=1.0)
         self.step_no += 1
-        self.last = acc
-        return acc
+        self.last = terms
+        return terms
+
+    def loss_values(self):
+        """{name: (cross_entropy, loc_loss)} per term + 'l2' + 'total' as python floats (synchronises)."""
+        out, total = {}, 0.0
+        for name, weight, acc in self.last:
+            ce_sum, n_sel, loc_sum, n_pos = [float(v) for v in acc.tolist()]
+            ce = (self.negative_ratio + 1.0) * ce_sum / max(n_sel, 1.0)
+            loc = loc_sum / max(n_pos, 1.0)
+            out[name] = (ce, loc)
+            total += weight * (ce + loc)
+        out["l2"] = float(self.flat.l2.item())
+        out["total"] = total + out["l2"]
+        return out
+
+
+class SFDTrainer(DetectorTrainer):
+    """sfd_model_fn (train_sfd.py:261-467) + Momentum optimizer."""
+
+    def loss_terms(self, images_u8, loc_targets, cls_targets):
+        loc, cls = self.model.forward(images_u8)
+        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=1.0 / self.world)
+        return [("face", 1.0, acc)]
 
     def losses(self):
         """(cross_entropy, loc_loss, l2_loss, total) as python floats (synchronises)."""
-        ce_sum, n_sel, loc_sum, n_pos = [float(v) for v in self.last.tolist()]
-        ce = (self.negative_ratio + 1.0) * ce_sum / max(n_sel, 1.0)
-        loc = loc_sum / max(n_pos, 1.0)
-        l2 = float(self.flat.l2.item())
-        return ce, loc, l2, ce + loc + l2
+        v = self.loss_values()
+        return v["face"][0], v["face"][1], v["l2"], v["total"]

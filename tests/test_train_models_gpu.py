@@ -1,0 +1,69 @@
+"""Training-step checks of the PyramidBox / DAN / DAN-Deform harnesses (train_pb.py / train_dan.py equivalents): every loss
+term of the HIP step equals the oracle's loss (hard-negative mining + CE*(ratio+1) + smooth-L1) evaluated on the HIP
+path's own head outputs and targets (so the comparison isolates mining / loss / routing-target plumbing), gradients reach
+every variable, and the optimizer moves the weights.  Tolerance: 1e-3 relative (fp32 reductions in a different order)."""
+import pytest
+import torch
+
+from oracle import train as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rel=2e-3):
+    return abs(a - b) <= rel * max(abs(b), 1e-3) + 1e-5
+
+
+def test_pyramidbox_train_step(dev):
+    from dan_amd import synthetic
+    from dan_amd.train_pb import PBAnchorTargets, PBModel, PBTrainer
+    H = W = 64
+    model = PBModel(device=dev, seed=3)
+    tr = PBTrainer(model, world=1)
+    tg = PBAnchorTargets(H, W, dev)
+    imgs = synthetic.make_images(2, H, W, dev, seed=1)
+    targets = tg.encode_batch(synthetic.make_gt_boxes(2, H, W, seed=2, max_faces=3))
+    assert targets["face"][0].shape == (2, 342, 4) and targets["head"][0].shape == (2, 86, 4) and targets["body"][0].shape == (2, 22, 4)
+    with torch.no_grad():
+        out = model.forward(imgs)
+    w0 = tr.flat.w.clone()
+    tr.train_step(imgs, targets)
+    vals = tr.loss_values()
+    for k in ("face", "head", "body"):
+        loc, cls = out[k]
+        ce, ll, _ = OT.detection_loss(cls.cpu(), loc.cpu(), targets[k][1].cpu().long(), targets[k][0].cpu())
+        assert _close(vals[k][0], ce.item()) and _close(vals[k][1], ll.item()), (k, vals[k], ce.item(), ll.item())
+    total = sum(w * (vals[k][0] + vals[k][1]) for k, w in (("face", 1.0), ("head", 0.66), ("body", 0.33))) + vals["l2"]
+    assert _close(vals["total"], total)
+    assert torch.isfinite(tr.flat.g).all() and (tr.flat.g != 0).float().mean().item() > 0.5
+    assert (tr.flat.w != w0).any()
+
+
+@pytest.mark.parametrize("deform", [False, True])
+def test_dan_train_step(deform, dev):
+    from dan_amd import synthetic
+    from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
+    H, W = 64, 96
+    model = DANModel(device=dev, seed=4, deform=deform)
+    anchors = dan_anchor_config(H, W, dev)
+    tr = DANTrainer(model, anchors, world=1)
+    imgs = synthetic.make_images(2, H, W, dev, seed=1)
+    loc_t, cls_t, mgt = encode_batch_dan(anchors, synthetic.make_gt_boxes(2, H, W, seed=5, max_faces=3))
+    with torch.no_grad():
+        (loc1, cls1), (loc2, cls2), _ = model.forward(imgs)
+    tr.train_step(imgs, loc_t, cls_t, mgt)
+    vals = tr.loss_values()
+    ce1, ll1, _ = OT.detection_loss(cls1.cpu(), loc1.cpu(), cls_t.cpu().long(), loc_t.cpu(), at_least_one=True)
+    assert _close(vals["stage1"][0], ce1.item()) and _close(vals["stage1"][1], ll1.item()), (vals["stage1"], ce1.item(), ll1.item())
+    fm, fl = tr.last_routing
+    assert set(fm.unique().tolist()) <= {-1, 0, 1} and (fm == 1).sum().item() > 0
+    ce2, ll2, _ = OT.detection_loss(cls2.cpu(), loc2.cpu(), fm.cpu().long(), fl.cpu(), at_least_one=True)
+    assert _close(vals["stage2"][0], ce2.item()) and _close(vals["stage2"][1], ll2.item()), (vals["stage2"], ce2.item(), ll2.item())
+    assert torch.isfinite(tr.flat.g).all()
+    # stop_gradient(stage-1 features) in get_features_stage2 (danet.py:934): the deform offset conv of stage 2 still trains
+    names = [n for n, _ in model.vs.named()]
+    assert any("prediction_modules_stage2" in n for n in names)
+    if deform:
+        gi = {n: tr.flat.g[s:s + k] for n, s, k in zip(tr.flat.names, tr.flat.starts, tr.flat.sizes)}
+        assert gi["prediction_modules_stage1/predict_stage1_0/deform_conv/kernel"].abs().sum().item() > 0
+        assert gi["prediction_modules_stage1/predict_stage1_0/deform_conv/conv2d/bias"].abs().sum().item() > 0
