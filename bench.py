@@ -123,8 +123,14 @@ def main():
         stats.sort(reverse=True)
         ms, label, n, fl = stats[0]
         achieved = fl / (ms * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_bench.sh), if present
+        tj = os.path.join(ROOT, "profiles", "r1", "pmc_bench_traffic.json")
+        if os.path.exists(tj):
+            t = json.load(open(tj)).get(label)
+            if t:
+                traffic = round(t["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": n // args.steps,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": n // args.steps,
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
                 "share_of_step_time": round(ms / (dt * 1e3), 4)}
         out = {

@@ -30,7 +30,7 @@ struct WgHaloArgs {
   float* db;           // [Cout] or null
   int N, H, W, C, Co8, Cout, cin_real;
   int tiles_x, tiles_y, total_tiles, tiles_per_split;
-  int ci_tiles, co_tiles;
+  int ci_tiles, co_tiles, xcd_grouped;
   FastDiv div_tx, div_txy, div_ci, div_pairs;
 };
 
@@ -75,9 +75,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int wco = COT == 128 ? grp : 0;
 
   // ---- block -> (ci tile, co tile, pixel split)
+  // The (ci, co) tile pairs of one pixel split read the same X / dY tiles: put them on one XCD (blocks b and b+8 share an
+  // XCD under round-robin dispatch; speed only) when the grid divides evenly, so the second..last readers hit that L2.
   const int pairs = a.ci_tiles * a.co_tiles;
-  const int split = (int)fdiv(blockIdx.x, a.div_pairs);
-  const int pair = (int)blockIdx.x - split * pairs;
+  int split, pair;
+  if (a.xcd_grouped) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int sq = (int)fdiv((unsigned)slot, a.div_pairs);
+    pair = slot - sq * pairs;
+    split = sq * 8 + xcd;
+  } else {
+    split = (int)fdiv(blockIdx.x, a.div_pairs);
+    pair = (int)blockIdx.x - split * pairs;
+  }
   const int co_tile = (int)fdiv((unsigned)pair, a.div_ci);
   const int ci_tile = pair - co_tile * a.ci_tiles;
   const int ci0 = ci_tile * 64, co0 = co_tile * COT;
@@ -333,6 +343,7 @@ int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
   splits = (a.total_tiles + a.tiles_per_split - 1) / a.tiles_per_split;
   a.div_ci = make_fastdiv(a.ci_tiles);
   a.div_pairs = make_fastdiv(pairs);
+  a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
   hipLaunchKernelGGL((conv_wgrad_halo_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
