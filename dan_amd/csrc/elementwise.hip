@@ -143,65 +143,118 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* _
 }
 
 // ------------------------------------------------------------------ channel L2 normalisation with learned scale
-// one wave per pixel; lane owns C/64 consecutive channels (C in {64..1024}, multiple of 64; handled as float regs)
-template <int CPL>
+// Every lane owns 8 consecutive channels (one 16-byte vector); a pixel is covered by LPP = C/8 lanes (8..64) of one wave
+// (C = 1024: two 16-byte vectors per lane); per-pixel sums are xor-shuffle reductions over those lanes.
+template <int LPP, int VPL>                        // lanes per pixel (power of two <= 64), vectors per lane
+__device__ __forceinline__ float pixel_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPP; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPP, int VPL>
 __global__ void l2norm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, bf16_t* __restrict__ y, long M, int C) {
+  constexpr int PPW = 64 / LPP;                    // pixels per wave
   const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (pix >= M) return;
-  float f[CPL];
-  const bf16_t* px = x + pix * C + lane * CPL;
+  const int sub = lane / LPP, l = lane % LPP;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  float gm[VPL][8];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) f[i] = bf2f(px[i]);
-  float ss = 0.f;
+  for (int v = 0; v < VPL; ++v)
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) ss += f[i] * f[i];
-  ss = wave_sum(ss);
-  const float inv = rsqrtf(fmaxf(ss, 1e-10f));
-  bf16_t* py = y + pix * C + lane * CPL;
+    for (int i = 0; i < 8; ++i) gm[v][i] = gamma[(v * LPP + l) * 8 + i];
+  for (long p0 = wave * PPW; p0 < M; p0 += nwaves * PPW) {
+    const long pix = p0 + sub;
+    const bool ok = pix < M;
+    float f[VPL][8];
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) py[i] = f2bf(f[i] * inv * gamma[lane * CPL + i]);
+    for (int v = 0; v < VPL; ++v) {
+      if (ok) unpack8(*reinterpret_cast<const uint4*>(x + pix * C + (v * LPP + l) * 8), f[v]);
+      else
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[v][i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += f[v][i] * f[v][i];
+    }
+    ss = pixel_sum<LPP, VPL>(ss);
+    const float inv = rsqrtf(fmaxf(ss, 1e-10f));
+    if (ok) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[v][i] = f[v][i] * inv * gm[v][i];
+        *reinterpret_cast<uint4*>(y + pix * C + (v * LPP + l) * 8) = pack8(f[v]);
+      }
+    }
+  }
 }
 
 // dx = gamma*inv*dy - x*inv^3 * sum_c(dy*gamma*x)   (second term dropped where sum x^2 <= 1e-10: clamp inactive grad)
-// dgamma[c] += sum_pix dy*x*inv.  dx is ACCUMULATED into (the tapped map also feeds the next conv block).
-template <int CPL>
+// dgamma[c] += sum_pix dy*x*inv.  dx is ACCUMULATED into when `accumulate` (the tapped map also feeds the next conv block).
+template <int LPP, int VPL>
 __global__ void l2norm_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const bf16_t* __restrict__ dy,
                                   bf16_t* __restrict__ dx, float* __restrict__ dgamma, long M, int C, int accumulate, int relu_mask) {
-  extern __shared__ float sg[];                           // [waves][C] partial dgamma
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float dg[CPL];
+  constexpr int PPW = 64 / LPP;
+  extern __shared__ float sg[];                    // [C] block-level dgamma accumulator
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sg[c] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPP, l = lane % LPP;
+  const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  float gm[VPL][8], dg[VPL][8];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) dg[i] = 0.f;
-  for (long pix = (long)blockIdx.x * nw + wv; pix < M; pix += (long)gridDim.x * nw) {
-    float f[CPL], g[CPL];
-    const long o = pix * C + lane * CPL;
+  for (int v = 0; v < VPL; ++v)
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { f[i] = bf2f(x[o + i]); g[i] = bf2f(dy[o + i]); }
+    for (int i = 0; i < 8; ++i) { gm[v][i] = gamma[(v * LPP + l) * 8 + i]; dg[v][i] = 0.f; }
+  for (long p0 = wave * PPW; p0 < M; p0 += nwaves * PPW) {
+    const long pix = p0 + sub;
+    const bool ok = pix < M;
+    float f[VPL][8], g[VPL][8];
     float ss = 0.f, dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) { ss += f[i] * f[i]; dot += g[i] * gamma[lane * CPL + i] * f[i]; }
-    ss = wave_sum(ss);
-    dot = wave_sum(dot);
+    for (int v = 0; v < VPL; ++v) {
+      const long o = pix * C + (v * LPP + l) * 8;
+      if (ok) {
+        unpack8(*reinterpret_cast<const uint4*>(x + o), f[v]);
+        unpack8(*reinterpret_cast<const uint4*>(dy + o), g[v]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { f[v][i] = 0.f; g[v][i] = 0.f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { ss += f[v][i] * f[v][i]; dot += g[v][i] * gm[v][i] * f[v][i]; }
+    }
+    ss = pixel_sum<LPP, VPL>(ss);
+    dot = pixel_sum<LPP, VPL>(dot);
     const float inv = rsqrtf(fmaxf(ss, 1e-10f));
     const float k = (ss > 1e-10f) ? dot * inv * inv * inv : 0.f;
+    if (ok) {
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      float v = gamma[lane * CPL + i] * inv * g[i] - f[i] * k;
-      if (relu_mask && !(f[i] > 0.f)) v = 0.f;            // x is a ReLU output: fold the producer's ReLU backward in
-      if (accumulate) v += bf2f(dx[o + i]);
-      dx[o + i] = f2bf(v);
-      dg[i] += g[i] * f[i] * inv;
+      for (int v = 0; v < VPL; ++v) {
+        const long o = pix * C + (v * LPP + l) * 8;
+        float r[8], old[8];
+        if (accumulate) unpack8(*reinterpret_cast<const uint4*>(dx + o), old);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = gm[v][i] * inv * g[v][i] - f[v][i] * k;
+          if (relu_mask && !(f[v][i] > 0.f)) t = 0.f;          // x is a ReLU output: fold the producer's ReLU backward in
+          if (accumulate) t += old[i];
+          r[i] = t;
+          dg[v][i] += g[v][i] * f[v][i] * inv;
+        }
+        *reinterpret_cast<uint4*>(dx + o) = pack8(r);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) sg[wv * C + lane * CPL + i] = dg[i];
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(sg + (v * LPP + l) * 8 + i, dg[v][i]);     // LDS atomics: PPW * waves adders per channel
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float t = 0.f;
-    for (int w = 0; w < nw; ++w) t += sg[w * C + c];
-    atomicAdd(dgamma + c, t);
-  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dgamma + c, sg[c]);
 }
 
 // ------------------------------------------------------------------ input preprocessing
@@ -269,14 +322,17 @@ extern "C" int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint
 extern "C" int danhip_l2norm_fwd(const uint16_t* x, const float* gamma, uint16_t* y, int64_t M, int32_t C, void* stream) {
   DH_REQUIRE(x && gamma && y && M > 0, DANHIP_EINVAL, "l2norm_fwd: bad arguments");
   DH_REQUIRE(C == 256 || C == 512 || C == 1024 || C == 128 || C == 64, DANHIP_EINVAL, "l2norm_fwd: C=%d unsupported", C);
-  const unsigned blocks = (unsigned)((M + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
-  switch (C / 64) {
-    case 1: hipLaunchKernelGGL(l2norm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
-    case 2: hipLaunchKernelGGL(l2norm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
-    case 4: hipLaunchKernelGGL(l2norm_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
-    case 8: hipLaunchKernelGGL(l2norm_fwd_kernel<8>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
-    default: hipLaunchKernelGGL(l2norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, x, gamma, y, (long)M, C); break;
+  const int lpp = C >= 512 ? 64 : C / 8, ppw = 64 / lpp;
+  long blocks = (M + 4 * ppw - 1) / (4 * ppw);
+  if (blocks > 4096) blocks = 4096;
+  const dim3 g((unsigned)blocks), b(256);
+  switch (C) {
+    case 64: hipLaunchKernelGGL((l2norm_fwd_kernel<8, 1>), g, b, 0, s, x, gamma, y, (long)M, C); break;
+    case 128: hipLaunchKernelGGL((l2norm_fwd_kernel<16, 1>), g, b, 0, s, x, gamma, y, (long)M, C); break;
+    case 256: hipLaunchKernelGGL((l2norm_fwd_kernel<32, 1>), g, b, 0, s, x, gamma, y, (long)M, C); break;
+    case 512: hipLaunchKernelGGL((l2norm_fwd_kernel<64, 1>), g, b, 0, s, x, gamma, y, (long)M, C); break;
+    default: hipLaunchKernelGGL((l2norm_fwd_kernel<64, 2>), g, b, 0, s, x, gamma, y, (long)M, C); break;
   }
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
@@ -286,16 +342,18 @@ extern "C" int danhip_l2norm_bwd(const uint16_t* x, const float* gamma, const ui
                                  int32_t C, int accumulate, int relu_mask, void* stream) {
   DH_REQUIRE(x && gamma && dy && dx && dgamma && M > 0, DANHIP_EINVAL, "l2norm_bwd: bad arguments");
   DH_REQUIRE(C == 256 || C == 512 || C == 1024 || C == 128 || C == 64, DANHIP_EINVAL, "l2norm_bwd: C=%d unsupported", C);
-  long blocks = (M + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = 4 * (size_t)C * sizeof(float);
-  switch (C / 64) {
-    case 1: hipLaunchKernelGGL(l2norm_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
-    case 2: hipLaunchKernelGGL(l2norm_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
-    case 4: hipLaunchKernelGGL(l2norm_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
-    case 8: hipLaunchKernelGGL(l2norm_bwd_kernel<8>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
-    default: hipLaunchKernelGGL(l2norm_bwd_kernel<16>, dim3((unsigned)blocks), dim3(256), lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+  const int lpp = C >= 512 ? 64 : C / 8, ppw = 64 / lpp;
+  long blocks = (M + 4 * ppw - 1) / (4 * ppw);
+  if (blocks > 2048) blocks = 2048;
+  const dim3 g((unsigned)blocks), b(256);
+  const size_t lds = (size_t)C * sizeof(float);
+  switch (C) {
+    case 64: hipLaunchKernelGGL((l2norm_bwd_kernel<8, 1>), g, b, lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 128: hipLaunchKernelGGL((l2norm_bwd_kernel<16, 1>), g, b, lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 256: hipLaunchKernelGGL((l2norm_bwd_kernel<32, 1>), g, b, lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    case 512: hipLaunchKernelGGL((l2norm_bwd_kernel<64, 1>), g, b, lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
+    default: hipLaunchKernelGGL((l2norm_bwd_kernel<64, 2>), g, b, lds, s, x, gamma, dy, dx, dgamma, (long)M, C, accumulate, relu_mask); break;
   }
   DH_LAUNCH_CHECK();
   return DANHIP_OK;

@@ -38,6 +38,37 @@ class VGG16Backbone(object):
         assert padding == "same" and dilate_rate == 1
         return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True)
 
+    # ---- batch-norm surface (net/sfd_net.py:91-119): defined on every VGG16Backbone, used by no VGG graph ------------
+    def _bn(self, inputs, scope, training, relu):
+        c = inputs.shape[-1]
+        gamma = self.vs.get(scope + "/bn/gamma", (c,), 1.0)
+        beta = self.vs.get(scope + "/bn/beta", (c,), "zeros")
+        mm = self.vs.buffer(scope + "/bn/moving_mean", (c,), 0.0)
+        mv = self.vs.buffer(scope + "/bn/moving_variance", (c,), 1.0)
+        if training:
+            return ops.batch_norm_train(inputs, gamma, beta, mm, mv, eps=self._bn_epsilon, momentum=self._bn_momentum, relu=relu)
+        return ops.batch_norm_infer(inputs, gamma, beta, mm, mv, eps=self._bn_epsilon, relu=relu)
+
+    def _conv_nobias(self, inputs, filters, kernel_size, strides, scope):
+        kh, kw = kernel_size
+        s = strides[0] if isinstance(strides, (tuple, list)) else strides
+        w = self.vs.get(scope + "/conv2d/kernel", (kh, kw, inputs.shape[-1], filters), "glorot")
+        return ops.conv2d(inputs, w, None, stride=s, relu=False)
+
+    def conv_bn_relu(self, inputs, filters, kernel_size, strides, scope, training, padding="same", dilate_rate=1, reuse=None):
+        """net/sfd_net.py:91-101: conv (no bias) -> batch_normalization(momentum 0.997, eps 1e-5) -> relu."""
+        assert padding == "same" and dilate_rate == 1
+        return self._bn(self._conv_nobias(inputs, filters, kernel_size, strides, scope), scope, training, relu=True)
+
+    def bn_relu(self, inputs, scope, training, reuse=None):
+        """net/sfd_net.py:103-107."""
+        return self._bn(inputs, scope, training, relu=True)
+
+    def conv_bn(self, inputs, filters, kernel_size, strides, scope, training, padding="same", dilate_rate=1, reuse=None):
+        """net/sfd_net.py:109-119."""
+        assert padding == "same" and dilate_rate == 1
+        return self._bn(self._conv_nobias(inputs, filters, kernel_size, strides, scope), scope, training, relu=False)
+
     def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None):
         """net/sfd_net.py:121-125."""
         for ind in range(1, num_blocks + 1):

@@ -41,6 +41,14 @@ class VariableStore(torch.nn.Module):
         assert tuple(p.shape) == tuple(shape), (name, tuple(p.shape), tuple(shape))
         return p
 
+    def buffer(self, name, shape, init):
+        """Non-trainable state (batch-norm moving averages): a plain device tensor kept under its TF name."""
+        if not hasattr(self, "bufs"):
+            self.bufs = {}
+        if name not in self.bufs:
+            self.bufs[name] = torch.full(tuple(int(s) for s in shape), float(init), dtype=torch.float32, device=self.device)
+        return self.bufs[name]
+
     def named(self):
         return [(n, self.vars[self._key(n)]) for n in self.order]
 

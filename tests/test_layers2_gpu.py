@@ -91,3 +91,23 @@ def test_batch_norm(shape, relu, dev):
             assert (got - want).abs().max().item() <= 2.0 ** -6 * want.abs().max().item() + 2e-3, name
     yi = ops.batch_norm_infer(x.to(dev), gamma.to(dev), beta.to(dev), mean_ref.detach().to(dev), var_ref.detach().to(dev), eps=1e-5, relu=relu)
     assert (yi.float().cpu() - y_ref.detach()).abs().max().item() <= 2.0 ** -7 * y_ref.abs().max().item() + 1e-3
+
+
+def test_backbone_bn_surface(dev):
+    """conv_bn_relu / bn_relu / conv_bn of VGG16Backbone (net/sfd_net.py:91-119) against the oracle's conv + batch norm."""
+    from dan_amd.net import sfd_net
+    g = torch.Generator().manual_seed(4)
+    x = _bf(torch.randn((2, 10, 12, 64), generator=g))
+    bb = sfd_net.VGG16Backbone("channels_last", variables=sfd_net.VariableStore(device=dev, seed=1))
+    y = bb.conv_bn_relu(x.to(dev), 32, (3, 3), (1, 1), "blk", training=True)
+    w = bb.vs.get("blk/conv2d/kernel", (3, 3, 64, 32), "glorot").detach().cpu().to(torch.bfloat16).float()
+    c = T.conv2d_same(x.float(), w, None, stride=1).to(torch.bfloat16).float()
+    ref, mean, var = T.batch_norm_train(c, torch.ones(32), torch.zeros(32), 1e-5)
+    ref = torch.relu(ref)
+    assert (y.float().cpu() - ref).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item() + 2e-3
+    assert torch.allclose(bb.vs.buffer("blk/bn/moving_mean", (32,), 0.0).cpu(), mean * (1 - 0.997), atol=1e-4)
+    yi = bb.conv_bn(x.to(dev), 32, (3, 3), (1, 1), "blk", training=False)          # inference path uses the moving averages
+    assert yi.shape == y.shape and torch.isfinite(yi.float()).all()
+    z = bb.bn_relu(x.to(dev), "pre", training=True)
+    zr, _, _ = T.batch_norm_train(x.float(), torch.ones(64), torch.zeros(64), 1e-5)
+    assert (z.float().cpu() - torch.relu(zr)).abs().max().item() <= 2.0 ** -7 * zr.abs().max().item() + 1e-3
