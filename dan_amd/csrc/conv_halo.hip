@@ -88,7 +88,7 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned v
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0>
+template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0, int NCU = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int PW = TW + 2;                       // patch row pitch (pixels); even, so LDS row parity == column parity
   constexpr int PROWS = (TH + 2) * PW;             // patch pixels
@@ -100,7 +100,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int D = NSW - 1;                       // weight prefetch distance (steps)
   constexpr int BM = TH * TW;
   constexpr int TP = BM / WM, TC = BN / WN;        // wave tile: pixels x channels
-  constexpr int NPT = TP / 16, NCT = TC / 16;
+  // NCU > 0: "thin head" mode — only the first NCU channel tiles of the wave are computed (Cout <= 16*NCU; the weight tile
+  // rows beyond Cout are zero-filled by the DMA bounds check), ragged Cout handled by a scalar epilogue.
+  constexpr int NPT = TP / 16, NCT = NCU ? NCU : TC / 16;
   static_assert(WM * WN == 8, "8 waves");
   static_assert(TP % 16 == 0 && TC % 16 == 0 && TW % 16 == 0, "MFMA tile alignment");
   static_assert(BN % 64 == 0 && NSW == 4 && (PW % 2) == 0, "layout assumptions");
@@ -290,6 +292,32 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto epilogue = [&]() __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(c_sp, n, y0, x0);
+    if (NCU) {                                     // thin head: Cout < 64, possibly not a multiple of 4; forward only
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const int t = wm * TP + p * 16 + frow;
+        const int y = y0 + t / TW, x = x0 + t % TW;
+        const bool ok = y < a.H && x < a.W;
+        const size_t m = (size_t)((n * a.H + y) * a.W + x);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = wn * TC + c * 16 + fq * 4 + r;
+            if (ok && co < a.Co) {
+              float v = acc[c][p][r] + (a.bias ? a.bias[co] : 0.f);
+              if (a.relu) v = fmaxf(v, 0.f);
+              if (a.out_f32) reinterpret_cast<float*>(a.y)[m * a.Co + co] = v;
+              else reinterpret_cast<bf16_t*>(a.y)[m * a.Co + co] = f2bf(v);
+            }
+          }
+          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      c_v += G;
+      c_ok = decode(c_v, c_sp, c_nb);
+      return;
+    }
     float4 biasv[NCT];                             // this lane's bias quads (one wait for all of them)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -447,13 +475,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
 struct HaloPlan {
   int th, tw, bn;
+  int head;      // thin head: Cout <= 16, one channel tile
 };
 
 // Picks the tile; returns false when the shape should go to the flat-M kernel.
 bool plan_halo(const ConvArgs& a, HaloPlan* p) {
   if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dstride == 1 && a.pad_t == 1 && a.pad_l == 1)) return false;
   if (a.H != a.Ho || a.W != a.Wo) return false;
-  if (a.C % 64 != 0 || a.Co % 64 != 0 || a.C > 2048) return false;
+  p->head = 0;
+  if (a.C % 64 != 0 || a.C > 2048) return false;
+  if (a.Co % 64 != 0) {
+    if (a.Co > 16 || a.mask || a.resid || a.accumulate) return false;      // thin head (forward only)
+    p->head = 1;
+  }
   if ((int64_t)a.Co * a.Kpad >= (1ll << 31)) return false;
   auto util = [&](int th, int tw) {
     const double ph = (double)((a.H + th - 1) / th * th), pw = (double)((a.W + tw - 1) / tw * tw);
@@ -462,7 +496,7 @@ bool plan_halo(const ConvArgs& a, HaloPlan* p) {
   const double u1 = util(8, 32), u2 = util(16, 16);
   if (u1 >= u2) { p->th = 8; p->tw = 32; } else { p->th = 16; p->tw = 16; }
   if ((u1 > u2 ? u1 : u2) < 0.78) return false;
-  p->bn = (a.Co % 128 == 0) ? 128 : 64;
+  p->bn = p->head ? 64 : ((a.Co % 128 == 0) ? 128 : 64);
   return true;
 }
 
@@ -476,19 +510,19 @@ int cu_count() {
   return n;
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0>
+template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0, int NCU = 0>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
   constexpr int LDS = 2 * PPIECES * 1024 + NSW * BN * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   HaloGeom g{};
   g.tiles_x = (a.W + TW - 1) / TW;
   g.tiles_y = (a.H + TH - 1) / TH;
   g.sp_items = a.N * g.tiles_x * g.tiles_y;
-  g.NB = a.Co / BN;
+  g.NB = NCU ? 1 : a.Co / BN;
   g.cch = a.C / 64;
   g.div_tx = make_fastdiv(g.tiles_x);
   g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
@@ -503,7 +537,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
     static unsigned long long* dbgbuf = nullptr;
     if (!dbgbuf) hipMalloc(&dbgbuf, 256 * 8 * 8 * sizeof(unsigned long long));
     g.dbg = dbgbuf;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>), dim3(G), dim3(512), LDS, s, a, g);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>), dim3(G), dim3(512), LDS, s, a, g);
     hipStreamSynchronize(s);
     static unsigned long long host[256 * 8 * 8];
     hipMemcpy(host, dbgbuf, sizeof(host), hipMemcpyDeviceToHost);
@@ -518,7 +552,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
     return DANHIP_OK;
   }
 #endif
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG>), dim3(G), dim3(512), LDS, s, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -528,6 +562,10 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
 namespace {
 template <bool DGRAD>
 int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
+  if (p.head) {
+    if (DGRAD) return 1;
+    return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 4, false, 0, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 4, false, 0, 1>(a, s);
+  }
   if (p.th == 8) {
 #ifdef DANHIP_HALO_EXPERIMENTS
     if (p.bn == 128 && !DGRAD) {
@@ -557,7 +595,7 @@ int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return 1;
-  const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32;
+  const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32 && !p.head;
   if (!dgrad && a.accumulate) return 1;
   if (!dgrad && a.mask) return 1;
   return dgrad ? launch_halo<true>(a, p, s) : launch_halo<false>(a, p, s);
@@ -566,10 +604,14 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
 const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return nullptr;
-  if (p.th == 8) {
-    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, false, 0>";
-    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0>";
+  if (p.head) {
+    if (dgrad) return nullptr;
+    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0, 1>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0, 1>";
   }
-  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, false, 0>";
-  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0>";
+  if (p.th == 8) {
+    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, true, 0, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, false, 0, 0>";
+    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, true, 0, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0, 0>";
+  }
+  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, true, 0, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, false, 0, 0>";
+  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, true, 0, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0, 0>";
 }

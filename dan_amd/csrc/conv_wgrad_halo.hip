@@ -354,7 +354,7 @@ int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
 static bool wg_halo_eligible(const danhip_conv_desc* d) {
   if (!(d->kh == 3 && d->kw == 3 && d->stride == 1)) return false;
   const int co8 = (d->Cout + 7) / 8 * 8;
-  if (d->Cin % 64 != 0 || co8 % 64 != 0) return false;
+  if (d->Cin % 64 != 0 || (co8 % 64 != 0 && co8 > 64)) return false;      // thin heads (co8 < 64) run as one zero-padded 64-wide tile
   const int th = 4, tw = 32;
   const double util = (double)d->H * d->W / ((double)((d->H + th - 1) / th * th) * (double)((d->W + tw - 1) / tw * tw));
   return util >= 0.78;

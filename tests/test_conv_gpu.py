@@ -20,6 +20,8 @@ SHAPES = [
     # items (> 256) that every persistent workgroup walks more than one (XCD-grouped mapping, NB = 2)
     (1, 16, 32, 64, 128, 3, 3, 1), (2, 30, 62, 128, 64, 3, 3, 1), (1, 32, 48, 256, 256, 3, 3, 1), (8, 64, 128, 64, 256, 3, 3, 1),
     (5, 56, 96, 128, 128, 3, 3, 1),
+    # thin detection heads (Cout 8 / 6) on maps large enough for the halo kernels (loc+cls in one pass)
+    (2, 16, 32, 256, 8, 3, 3, 1), (1, 32, 32, 64, 6, 3, 3, 1), (3, 24, 64, 128, 16, 3, 3, 1),
 ]
 
 
