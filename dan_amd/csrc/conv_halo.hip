@@ -1,21 +1,27 @@
 // Halo-reuse 3x3 / stride-1 convolution on MFMA for gfx950 (bf16 NHWC in, fp32 accumulate) — the kernel that carries the
 // backbone (net/sfd_net.py:127-156 conv1_2 .. conv4_3), LFPN fused convs (net/pb_net.py:185-226, net/danet.py:339-380),
-// shared head convs (net/danet.py:469-532), the PyramidBox CPM (net/pb_net.py:158-183) and, run on dY with tap-flipped
-// weights, their data gradients.
+// shared head convs (net/danet.py:469-532), the PyramidBox CPM (net/pb_net.py:158-183), the thin loc/cls heads
+// (net/sfd_net.py:159-219) and, run on dY with tap-flipped weights, their data gradients.
 //
 // One PERSISTENT 512-thread workgroup per CU walks work items (spatial tile TH x TW of one image) x (BN output channels).
 // For every 64-channel chunk of the input the (TH+2) x (TW+2) halo patch is DMA'd into LDS ONCE ([pixel][64 ch] = 128-byte
-// rows, 16-byte XOR swizzle on the source side) and all nine taps read it at shifted row offsets: the activation is
-// fetched once instead of nine times (the flat-M kernel re-gathers it per tap).  Weight tiles [BN][64] (one per tap and
-// chunk) stream through an NSW-deep LDS ring.  All DMAs are global_load_lds_dwordx4; the loop never drains them:
-// a counted s_waitcnt vmcnt(N) + raw s_barrier per step keeps NSW-1 weight tiles and the next patch in flight.
-// The step sequence is flattened across chunks and items, so the next item's first patch and weights are already
-// landing while the current item's epilogue runs.
+// rows) and all nine taps read it at shifted offsets: the activation is fetched once instead of nine times (the flat-M
+// kernel conv_igemm.hip re-gathers it per tap).  Weight tiles [TPS taps][BN][64] stream through an NSW-deep LDS ring
+// (TPS = taps per step: 1 for the 128-wide tile, 3 = one kernel row for the 64-wide tile so a step still carries 48 MFMAs).
+// All DMAs are buffer_load ... lds (16 bytes per lane); padding pixels are lanes whose offset is out of the descriptor's
+// range (hardware zero fill).  The loop never drains the DMA queue: counted s_waitcnt vmcnt(N) + raw s_barrier.
+// The step sequence is flattened across chunks and items, so the next item's first patch and weights are already landing
+// while the current item's epilogue runs.
+//
+// Two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) alternate phases:
+//     A:  mem(c)   | b1 | MFMA(c) | b2          B:  MFMA(c) | b1 | mem(c+1) | b2
+// The MFMA phase is nothing but the step's MFMAs; the mem phase reads the next fragments from LDS, issues the DMAs of
+// step c+D and runs the item epilogue — DMA issue, LDS latency and barrier skew of one group hide under the other's MFMAs.
 //
 // MFMA: v_mfma_f32_16x16x32_bf16, weight fragment = A operand, pixel fragment = B operand -> a lane owns 4 consecutive
 // output channels of one pixel (8-byte bf16 / 16-byte fp32 stores into NHWC).
-#include <cstdio>
-#include <cstdlib>
+// LDS swizzles (16-byte chunks, applied on the DMA source side and on the read side): weight rows by (row & 7), patch rows
+// by the patch COLUMN (hx & 7) so that a tap's row shift is a pure immediate offset; both conflict-free for ds_read_b128.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -29,7 +35,6 @@ struct HaloGeom {
   int cch;                  // 64-channel chunks of the input (C / 64)
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
   FastDiv div_tx, div_txy, div_nb;
-  unsigned long long* dbg;   // diagnostic builds only (DBG & 4): per-wave cycle sums
 };
 
 template <int N>
@@ -37,11 +42,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-
-// Epilogue of the halo kernel for one lane's 4 consecutive channels (Co % 64 == 0: always a full, aligned quad).
+// Epilogue of one lane's 4 consecutive channels (Co % 64 == 0: always a full, aligned quad).
 //   forward : v = acc + bias; relu?; (+ residual, bf16) -> bf16 or fp32
 //   dgrad   : v = acc; * (mask > 0)?; (+= old)?          -> bf16
-// Every read-modify input of the wave tile is issued before the first store (no load waits between stores).
 template <bool DGRAD>
 __device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc, const float4& b, const uint2& in0, const uint2& in1, size_t o) {
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
@@ -78,39 +81,38 @@ __device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc
   *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.y) + o) = t;
 }
 
-// 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is
-// out of range (>= the descriptor's byte count, e.g. 0xFFFFFFFF) writes ZEROS to its LDS slot — that is how halo pixels
-// outside the image are padded, with no branch and no pointer select.
-typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
-template <int DBG = 0>
+// 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out
+// of range (0xFFFFFFFF) writes ZEROS to its LDS slot.
 __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
-  if (DBG & 32) return;                            // timing experiment: no DMA at all
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0, int NCU = 0>
+// TPS: taps per step (1 or 3); NSW: weight ring depth (prefetch distance D = NSW-1 steps);
+// NCU > 0: "thin head" — only the first NCU channel tiles of a wave are computed (Cout <= 16*NCU, ragged Cout allowed).
+template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int PW = TW + 2;                       // patch row pitch (pixels); even, so LDS row parity == column parity
   constexpr int PROWS = (TH + 2) * PW;             // patch pixels
   constexpr int PPIECES = (PROWS + 7) / 8;         // 1 KiB DMA pieces per patch (8 pixel rows each)
   constexpr int PBYTES = PPIECES * 1024;
   constexpr int PL = (PPIECES + 7) / 8;            // patch pieces per wave
-  constexpr int WBYTES = BN * 128;                 // one weight tile
-  constexpr int WL = BN / 64;                      // weight pieces per wave per step
+  constexpr int SPC = 9 / TPS;                     // steps per 64-channel chunk
+  constexpr int TAPBYTES = BN * 128;               // weight tile of one tap
+  constexpr int WBYTES = TPS * TAPBYTES;           // one ring stage
+  constexpr int WL = TPS * BN / 64;                // weight pieces per wave per step
   constexpr int D = NSW - 1;                       // weight prefetch distance (steps)
   constexpr int BM = TH * TW;
   constexpr int TP = BM / WM, TC = BN / WN;        // wave tile: pixels x channels
-  // NCU > 0: "thin head" mode — only the first NCU channel tiles of the wave are computed (Cout <= 16*NCU; the weight tile
-  // rows beyond Cout are zero-filled by the DMA bounds check), ragged Cout handled by a scalar epilogue.
   constexpr int NPT = TP / 16, NCT = NCU ? NCU : TC / 16;
   static_assert(WM * WN == 8, "8 waves");
   static_assert(TP % 16 == 0 && TC % 16 == 0 && TW % 16 == 0, "MFMA tile alignment");
-  static_assert(BN % 64 == 0 && NSW == 4 && (PW % 2) == 0, "layout assumptions");
+  static_assert(BN % 64 == 0 && (PW % 2) == 0 && (TPS == 1 || TPS == 3) && NSW >= 3, "layout assumptions");
+  static_assert(TPS == 3 ? NSW == 3 : NSW == 4, "stage index arithmetic (SPC = 3 = NSW, or SPC = 9 = 1 mod 4)");
   static_assert(2 * PW * 128 + 64 + PBYTES < 65536, "ds_read immediate offsets");
+  static_assert(2 * PBYTES + NSW * WBYTES <= 160 * 1024, "LDS budget");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS map: [patch 0][patch 1][weight ring: NSW tiles]
-  constexpr int WRING = 2 * PBYTES;
+  constexpr int WRING = 2 * PBYTES;                // LDS map: [patch 0][patch 1][weight ring: NSW stages]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     x0 = (rem - ty * g.tiles_x) * TW;
   };
 
-  // ---- patch DMA: per-lane geometry (tile independent) and per-item source pointers ------------------------------------
+  // ---- patch DMA: per-lane geometry (tile independent) and per-item source offsets ---------------------------------------
   // LDS row R = hy*PW + hx holds pixel (y0-1+hy, x0-1+hx); the 16-byte chunk c of its 64 channels sits at position
-  // c ^ (hx & 7) (swizzle keyed on the patch COLUMN: a tap's row shift then is a pure address offset on the read side).
+  // c ^ (hx & 7).
   int pgeo[PL];                                    // (hy << 8) | hx, or -1 when the slot is beyond the patch
 #pragma unroll
   for (int k = 0; k < PL; ++k) {
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     pgeo[k] = row < PROWS ? ((hy << 8) | hx) : -1;
   }
   const __amdgpu_buffer_rsrc_t rsrc_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (DBG & 16) ? 0 : (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (DBG & 8) ? 0 : (int)((unsigned)a.Co * (unsigned)a.Kpad * 2u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)((unsigned)a.Co * (unsigned)a.Kpad * 2u), 0x00020000);
   int p_v = blockIdx.x, p_cc = 0, p_idx = 0;       // patch cursor: next chunk to load; p_idx selects the buffer
   int p_sp, p_nb;
   bool p_ok = decode(p_v, p_sp, p_nb);
@@ -172,13 +174,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       psrc[k] = ok ? off : 0xFFFFFFFFu;
     }
   };
-  auto issue_patch = [&]() __attribute__((always_inline)) {                       // loads chunk (p_v, p_cc) into buffer p_idx & 1 and advances the cursor
+  auto issue_patch = [&]() __attribute__((always_inline)) {   // loads chunk (p_v, p_cc) into buffer p_idx & 1, advances the cursor
     char* dst = smem + (p_idx & 1) * PBYTES;
 #pragma unroll
     for (int k = 0; k < PL; ++k) {
       int piece = k * 8 + wave;
       if (piece > PPIECES - 1) piece = PPIECES - 1;
-      bufdma16<DBG>(rsrc_x, psrc[k], (unsigned)(p_cc * 128), dst + piece * 1024);
+      bufdma16(rsrc_x, psrc[k], (unsigned)(p_cc * 128), dst + piece * 1024);
     }
     ++p_idx;
     if (++p_cc == g.cch) {
@@ -190,19 +192,25 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   if (p_ok) patch_item_setup();
 
-  // ---- weight DMA cursor: step (w_v, w_cc, w_tap) to be loaded next ------------------------------------------------------
-  int w_v = blockIdx.x, w_cc = 0, w_tap = 0, w_idx = 0;
+  // ---- weight DMA cursor: step (w_v, w_cc, w_step) to be loaded next; a stage holds TPS taps x BN rows x 128 bytes ---------
+  int w_v = blockIdx.x, w_cc = 0, w_step = 0, w_idx = 0;
   int w_sp, w_nb;
   bool w_ok = decode(w_v, w_sp, w_nb);
-  const unsigned wlane = (unsigned)((wave * WL * 8 + srow) * a.Kpad) * 2u + (unsigned)(((lane & 7) ^ srow) << 4);   // + k*8 rows
-  auto issue_w = [&]() __attribute__((always_inline)) {
-    char* dst = smem + WRING + (w_idx & (NSW - 1)) * WBYTES;
-    const unsigned soff = (unsigned)((w_nb * BN) * a.Kpad + w_tap * a.C + w_cc * 64) * 2u;   // uniform
+  unsigned wlane[WL];                              // per piece: ((row in BN) * Kpad + tap_in_step * C) * 2 + swizzled chunk
 #pragma unroll
-    for (int k = 0; k < WL; ++k) bufdma16<DBG>(rsrc_w, wlane + (unsigned)(k * 8 * a.Kpad) * 2u, soff, dst + (wave * WL + k) * 1024);
+  for (int k = 0; k < WL; ++k) {
+    const int pz = wave * WL + k;                  // piece inside the stage
+    const int tin = pz / (BN / 8), rp = pz % (BN / 8);
+    wlane[k] = (unsigned)((rp * 8 + srow) * a.Kpad + tin * a.C) * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
+  }
+  auto issue_w = [&]() __attribute__((always_inline)) {
+    char* dst = smem + WRING + (w_idx % NSW) * WBYTES;
+    const unsigned soff = (unsigned)((w_nb * BN) * a.Kpad + (w_step * TPS) * a.C + w_cc * 64) * 2u;   // uniform
+#pragma unroll
+    for (int k = 0; k < WL; ++k) bufdma16(rsrc_w, wlane[k], soff, dst + (wave * WL + k) * 1024);
     ++w_idx;
-    if (++w_tap == 9) {
-      w_tap = 0;
+    if (++w_step == SPC) {
+      w_step = 0;
       if (++w_cc == g.cch) {
         w_cc = 0;
         w_v += G;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   // ---- compute-side per-lane constants --------------------------------------------------------------------------
   const int frow = lane & 15, fq = lane >> 4;
-  const int offW = WRING + (wn * TC + frow) * 128 + ((fq ^ (frow & 7)) << 4);     // + stage*WBYTES, + c*2048, ^ ks*64
+  const int offW = WRING + (wn * TC + frow) * 128 + ((fq ^ (frow & 7)) << 4);     // + stage*WBYTES + tap*TAPBYTES + c*2048, ^ ks*64
   int pxaddr[3][NPT];                              // patch-buffer-0 byte address of fragment p at tap column j, k-slice 0
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
@@ -229,30 +237,57 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bool skip_reads = false;
-  // Fragment loads of k-slice ks of the step at (weight stage base wbase, patch buffer offset pofs, tap TAP).
-  auto load_frags = [&](bf16x8 (&wf)[NCT], bf16x8 (&xf)[NPT], int wbase, int pofs, auto tapc, int ks) __attribute__((always_inline)) {
-    constexpr int TAP = decltype(tapc)::value;
-    constexpr int TI = TAP / 3, TJ = TAP % 3;
-    if ((DBG & 64) && skip_reads) return;          // timing experiment: no fragment reads in the main loop
-    const int wb = ks ? (wbase ^ 64) : wbase;
+  // Fragments: [slot][k-slice].  TPS == 1: one slot.  TPS == 3: two slots — taps 0 and 1 of the step are read in the mem
+  // phase, tap 2 is read at the start of the MFMA phase into slot 0 once tap 0's MFMAs have been issued (its LDS latency
+  // hides under tap 1's 16 MFMAs); 96 instead of 144 fragment VGPRs.
+  constexpr int NSLOT = TPS == 3 ? 2 : 1;
+  bf16x8 wf[NSLOT][2][NCT], xf[NSLOT][2][NPT];
+  auto load_tap = [&](auto slotc, auto tapc, int wbase, int pofs) __attribute__((always_inline)) {   // tap TAP (0..8) of the chunk
+    constexpr int SLOT = decltype(slotc)::value, TAP = decltype(tapc)::value;
+    constexpr int TI = TAP / 3, TJ = TAP % 3, TS = TAP % TPS;
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(smem + wb + c * 2048);
+    for (int ks = 0; ks < 2; ++ks) {
+      const int wb = (ks ? (wbase ^ 64) : wbase) + TS * TAPBYTES;
 #pragma unroll
-    for (int p = 0; p < NPT; ++p) {
-      const int pa = (ks ? (pxaddr[TJ][p] ^ 64) : pxaddr[TJ][p]) + pofs;
-      xf[p] = *reinterpret_cast<const bf16x8*>(smem + pa + TI * PW * 128);
+      for (int c = 0; c < NCT; ++c) wf[SLOT][ks][c] = *reinterpret_cast<const bf16x8*>(smem + wb + c * 2048);
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const int pa = (ks ? (pxaddr[TJ][p] ^ 64) : pxaddr[TJ][p]) + pofs;
+        xf[SLOT][ks][p] = *reinterpret_cast<const bf16x8*>(smem + pa + TI * PW * 128);
+      }
     }
   };
-  auto mma = [&](const bf16x8 (&wf)[NCT], const bf16x8 (&xf)[NPT], auto c0c, auto c1c) __attribute__((always_inline)) {      // channel tiles [C0, C1)
+  auto mma_slot = [&](auto slotc) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slotc)::value;
 #pragma unroll
-    for (int c = decltype(c0c)::value; c < decltype(c1c)::value; ++c)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int p = 0; p < NPT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[c][p], 0, 0, 0);
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p)
+          acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SLOT][ks][c], xf[SLOT][ks][p], acc[c][p], 0, 0, 0);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  using IN = std::integral_constant<int, NCT>;
+  // mem-phase reads of step STEP
+  auto load_frags = [&](int wbase, int pofs, auto stepc) __attribute__((always_inline)) {
+    constexpr int STEP = decltype(stepc)::value;
+    load_tap(I0{}, std::integral_constant<int, STEP * TPS>{}, wbase, pofs);
+    if constexpr (TPS == 3) load_tap(I1{}, std::integral_constant<int, STEP * TPS + 1>{}, wbase, pofs);
+  };
+  // MFMA phase of step STEP (wbase / pofs: for the late tap-2 reads)
+  auto mma = [&](int wbase, int pofs, auto stepc) __attribute__((always_inline)) {
+    constexpr int STEP = decltype(stepc)::value;
+    mma_slot(I0{});
+    if constexpr (TPS == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_tap(I0{}, std::integral_constant<int, STEP * TPS + 2>{}, wbase, pofs);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slot(I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma_slot(I0{});
+    }
+  };
 
   // ---- prologue -----------------------------------------------------------------------------------------------------
   int c_v = blockIdx.x, c_sp, c_nb;
@@ -265,30 +300,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // ---- main loop: two phase-alternating wave groups -----------------------------------------------------------------
-  // One step (= cycle) = one tap of one 64-channel chunk.  Waves 0-3 (group A) and 4-7 (group B) sit one per SIMD each.
-  // Every cycle has two barriers; between them one group runs its 32 MFMAs with nothing else in its stream while the other
-  // does all its memory work (issues the DMAs of step c+3 / the next patch, reads its next fragments from LDS, runs the
-  // item epilogue), then they swap:
-  //     A:  mem(c)   | b1 | MFMA(c) | b2          B:  MFMA(c) | b1 | mem(c+1) | b2
-  // so the matrix pipe of each SIMD always has exactly one wave feeding it and DMA issue / LDS latency / barrier skew are
-  // covered by the partner's MFMA phase.  Hand-offs (all checked at b1 of cycle c, before B reads tile c+1):
-  //   * every wave has waited for its own pieces of weight tile c+1 (A issued them in cycle c-2, B in cycle c-2 too);
-  //   * stage (c+3)&3 == (c-1)&3 was last read by A in mem(c-1) and by B in mem of cycle c-2  -> free to overwrite in c;
-  //   * the patch of chunk q+1 is issued at tap 0 of chunk q and retired by the counted waits long before tap 8.
-  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;     // DBG & 4 only: in-kernel stamps (diagnostic build)
-  auto stamp = [&](int i) __attribute__((always_inline)) {
-    if (DBG & 4) {
-      unsigned long long t;
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-      tsum[i] += t - tprev;
-      tprev = t;
-    }
-  };
-  stamp(4);
-  tsum[4] = 0;
-
-  bf16x8 wf0[NCT], xf0[NPT], wf1[NCT], xf1[NPT];
   auto epilogue = [&]() __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(c_sp, n, y0, x0);
@@ -314,134 +325,126 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      c_v += G;
-      c_ok = decode(c_v, c_sp, c_nb);
-      return;
-    }
-    float4 biasv[NCT];                             // this lane's bias quads (one wait for all of them)
+    } else {
+      float4 biasv[NCT];                           // this lane's bias quads (one wait for all of them)
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
-      biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + c_nb * BN + wn * TC + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = 0; c < NCT; ++c)
+        biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + c_nb * BN + wn * TC + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int p = 0; p < NPT; ++p) {
-      const int t = wm * TP + p * 16 + frow;
-      const int y = y0 + t / TW, x = x0 + t % TW;
-      const bool ok = y < a.H && x < a.W;
-      const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + (c_nb * BN + wn * TC + fq * 4);
-      uint2 in0[NCT], in1[NCT];
-      if (ok) {
+      for (int p = 0; p < NPT; ++p) {
+        const int t = wm * TP + p * 16 + frow;
+        const int y = y0 + t / TW, x = x0 + t % TW;
+        const bool ok = y < a.H && x < a.W;
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + (c_nb * BN + wn * TC + fq * 4);
+        uint2 in0[NCT], in1[NCT];                  // every read-modify input is issued before the first store
+        if (ok) {
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (!DGRAD) {
-            if (a.resid && !a.out_f32) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
-          } else {
-            if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
-            if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+          for (int c = 0; c < NCT; ++c) {
+            if (!DGRAD) {
+              if (a.resid && !a.out_f32) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
+            } else {
+              if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
+              if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+            }
           }
         }
-      }
 #pragma unroll
-      for (int c = 0; c < NCT; ++c) {
-        if (ok) halo_finish4<DGRAD>(a, acc[c][p], biasv[c], in0[c], in1[c], o0 + c * 16);
-        acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NCT; ++c) {
+          if (ok) halo_finish4<DGRAD>(a, acc[c][p], biasv[c], in0[c], in1[c], o0 + c * 16);
+          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
     c_v += G;
     c_ok = decode(c_v, c_sp, c_nb);
   };
 
-  int chunk = 0, cc = 0;                           // running chunk number (patch buffer = chunk & 1; stage = (chunk + tap) & 3)
-  int patch_age = 4;                               // cycles since this wave last issued a patch (>= 3: outside every wait window)
-  bool w_prev = true;                              // group B: did the previous cycle issue a weight tile
+  // ---- main loop ----------------------------------------------------------------------------------------------------
+  // Cycle c = step c of this block's flattened (item, chunk, step) sequence.  Hand-offs, all checked at b1 of cycle c
+  // (after which B reads the tile of step c+1):
+  //   * every wave has waited for its own pieces of weight tile c+1 (both groups issue tile c+D during cycle c);
+  //   * stage (c+D) % NSW == (c-1) % NSW was last read by A in mem(c-1) and by B in the mem phase of cycle c-2;
+  //   * the patch of chunk q+1 is issued at step 0 of chunk q and retired by the counted waits long before its first use.
+  // DMA queue of a wave, oldest first: A at its wait in cycle c: [W(c+1)] ... [W(c+D)] -> (D-1)*WL may stay in flight, plus
+  // a patch if it was issued within the last D-1 cycles; B (which has issued up to cycle c-1): (D-2)*WL, patch age <= D-2.
+  int chunk = 0, cc = 0;                           // running chunk number: patch buffer = chunk & 1
+  int patch_age = 16;                              // cycles since this wave last issued a patch (large: outside every window)
+  auto stage_of = [&](int step) __attribute__((always_inline)) -> int {
+    return TPS == 3 ? step : (chunk + step) & (NSW - 1);      // TPS == 3: SPC == NSW; TPS == 1: SPC = 9 = 1 (mod 4)
+  };
+  using S0 = std::integral_constant<int, 0>;
 
   if (wave < 4) {
-    skip_reads = true;
     // ================================================= group A =================================================
     bool pending = false;                          // an item finished in the previous cycle: its epilogue runs in this mem phase
     for (;;) {
       const int pofs = (chunk & 1) * PBYTES;
-      auto cycle = [&](auto tapc) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tapc)::value;
-        // ---- mem phase
-        // fragment reads first: their LDS latency runs under the epilogue / DMA issue below
-        const int wbase = offW + ((chunk + TAP) & (NSW - 1)) * WBYTES;
-        load_frags(wf0, xf0, wbase, pofs, tapc, 0);
-        load_frags(wf1, xf1, wbase, pofs, tapc, 1);
+      auto cycle = [&](auto stepc) __attribute__((always_inline)) {
+        constexpr int STEP = decltype(stepc)::value;
+        // ---- mem phase: fragment reads first (their LDS latency runs under the epilogue / DMA issue below)
+        const int wbase = offW + stage_of(STEP) * WBYTES;
+        load_frags(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
         if (pending) { epilogue(); pending = false; }
         const bool more_w = w_ok;
         if (more_w) issue_w();
-        if (TAP == 0 && p_ok) { issue_patch(); patch_age = 0; }
-        stamp(5);
-        // A's queue: [W(c+1)] [patch?] [W(c+2)] [patch?] [W(c+3)] [patch?]; tile c+1 must be done before b1 (B reads it
-        // right after); a patch issued in this or the two previous mem phases (age <= 2) is younger than it.
-        if (!more_w) wait_vmcnt<0>();
-        else if (patch_age <= 2) wait_vmcnt<2 * WL + PL>();
-        else wait_vmcnt<2 * WL>();
+        if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        if (!more_w) wait_vmcnt<0>();              // tail of this block's work
+        else if (patch_age <= D - 1) wait_vmcnt<(D - 1) * WL + PL>();
+        else wait_vmcnt<(D - 1) * WL>();
         ++patch_age;
         __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): fragments are in registers before the MFMA phase starts
-        stamp(0);
-        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b1
-        stamp(1);
+        __builtin_amdgcn_s_barrier();              // b1
         // ---- MFMA phase
         __builtin_amdgcn_sched_barrier(0);
-        mma(wf0, xf0, I0{}, IN{});
-        mma(wf1, xf1, I0{}, IN{});
+        mma(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
-        stamp(2);
-        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b2
-        stamp(3);
+        __builtin_amdgcn_s_barrier();              // b2
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
       cycle(std::integral_constant<int, 2>{});
-      cycle(std::integral_constant<int, 3>{});
-      cycle(std::integral_constant<int, 4>{});
-      cycle(std::integral_constant<int, 5>{});
-      cycle(std::integral_constant<int, 6>{});
-      cycle(std::integral_constant<int, 7>{});
-      cycle(std::integral_constant<int, 8>{});
+      if constexpr (SPC == 9) {
+        cycle(std::integral_constant<int, 3>{});
+        cycle(std::integral_constant<int, 4>{});
+        cycle(std::integral_constant<int, 5>{});
+        cycle(std::integral_constant<int, 6>{});
+        cycle(std::integral_constant<int, 7>{});
+        cycle(std::integral_constant<int, 8>{});
+      }
       ++chunk;
       if (++cc == g.cch) {
         cc = 0;
-        // peek: is this the block's last item?  (the epilogue itself advances the cursor)
         int nsp, nnb;
-        if (!decode(c_v + G, nsp, nnb)) { epilogue(); break; }
+        if (!decode(c_v + G, nsp, nnb)) { epilogue(); break; }     // the block's last item
         pending = true;
       }
     }
   } else {
     // ================================================= group B =================================================
-    load_frags(wf0, xf0, offW, 0, std::integral_constant<int, 0>{}, 0);
-    load_frags(wf1, xf1, offW, 0, std::integral_constant<int, 0>{}, 1);
-    skip_reads = true;
+    bool w_prev = true;                            // did the previous cycle issue a weight tile
+    load_frags(offW, 0, S0{});
     for (;;) {
       const int pofs = (chunk & 1) * PBYTES;
       bool last = false;                           // set when the block's last item has been finished
-      auto cycle = [&](auto tapc) __attribute__((always_inline)) {
-        constexpr int TAP = decltype(tapc)::value;
+      auto cycle = [&](auto stepc) __attribute__((always_inline)) {
+        constexpr int STEP = decltype(stepc)::value;
         // ---- MFMA phase (step c)
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_sched_barrier(0);
-        mma(wf0, xf0, I0{}, IN{});
-        mma(wf1, xf1, I0{}, IN{});
+        mma(offW + stage_of(STEP) * WBYTES, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
-        // B's queue at this point: [W(c+1)] [patch?] [W(c+2)] [patch?]; tile c+1 (issued two mem phases ago) must be
-        // done.  A patch issued in one of the last two mem phases (age 0 or 1) is younger than it and may stay in flight.
         if (!w_prev) wait_vmcnt<0>();
-        else if (patch_age <= 1) wait_vmcnt<WL + PL>();
-        else wait_vmcnt<WL>();
-        stamp(2);
-        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b1
-        stamp(3);
-        // ---- mem phase (for step c+1)
-        constexpr int NTAP = (TAP + 1) % 9;
-        const int nwbase = offW + ((chunk + TAP + 1) & (NSW - 1)) * WBYTES;
-        const int npofs = TAP == 8 ? (PBYTES - pofs) : pofs;
-        load_frags(wf0, xf0, nwbase, npofs, std::integral_constant<int, NTAP>{}, 0);   // reads first (see group A)
-        load_frags(wf1, xf1, nwbase, npofs, std::integral_constant<int, NTAP>{}, 1);
+        else if (patch_age <= D - 2) wait_vmcnt<(D - 2) * WL + PL>();
+        else wait_vmcnt<(D - 2) * WL>();
+        __builtin_amdgcn_s_barrier();              // b1
+        // ---- mem phase (for step c+1): reads first
+        constexpr int NSTEP = (STEP + 1) % SPC;
+        const int nstage = TPS == 3 ? NSTEP : (chunk + STEP + 1) & (NSW - 1);
+        const int npofs = STEP == SPC - 1 ? (PBYTES - pofs) : pofs;
+        load_frags(offW + nstage * WBYTES, npofs, std::integral_constant<int, NSTEP>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (TAP == 8 && cc + 1 == g.cch) {         // the item ended with this step
+        if (STEP == SPC - 1 && cc + 1 == g.cch) {  // the item ended with this step
           epilogue();
           if (!c_ok) last = true;
         }
@@ -449,27 +452,24 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (more_w) issue_w();
         w_prev = more_w;
         ++patch_age;
-        if (TAP == 0 && p_ok) { issue_patch(); patch_age = 0; }
-        stamp(0);
-        if (!(DBG & 2)) __builtin_amdgcn_s_barrier();              // b2
-        stamp(1);
+        if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        __builtin_amdgcn_s_barrier();              // b2
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
       cycle(std::integral_constant<int, 2>{});
-      cycle(std::integral_constant<int, 3>{});
-      cycle(std::integral_constant<int, 4>{});
-      cycle(std::integral_constant<int, 5>{});
-      cycle(std::integral_constant<int, 6>{});
-      cycle(std::integral_constant<int, 7>{});
-      cycle(std::integral_constant<int, 8>{});
+      if constexpr (SPC == 9) {
+        cycle(std::integral_constant<int, 3>{});
+        cycle(std::integral_constant<int, 4>{});
+        cycle(std::integral_constant<int, 5>{});
+        cycle(std::integral_constant<int, 6>{});
+        cycle(std::integral_constant<int, 7>{});
+        cycle(std::integral_constant<int, 8>{});
+      }
       ++chunk;
       if (++cc == g.cch) cc = 0;
       if (last) break;
     }
-  }
-  if ((DBG & 4) && g.dbg && lane == 0) {
-    for (int i = 0; i < 8; ++i) g.dbg[(blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
   }
 }
 
@@ -510,12 +510,12 @@ int cu_count() {
   return n;
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int NSW, bool DGRAD, int DBG = 0, int NCU = 0>
+template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
-  constexpr int LDS = 2 * PPIECES * 1024 + NSW * BN * 128;
+  constexpr int LDS = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   HaloGeom g{};
@@ -532,63 +532,30 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.grouped = 0;
   if (items >= G && (G % 8) == 0 && ((G / 8) % g.NB) == 0 && g.NB > 1) g.grouped = 1;
   if (items < G) G = (int)items;
-#ifdef DANHIP_HALO_EXPERIMENTS
-  if (DBG & 4) {
-    static unsigned long long* dbgbuf = nullptr;
-    if (!dbgbuf) hipMalloc(&dbgbuf, 256 * 8 * 8 * sizeof(unsigned long long));
-    g.dbg = dbgbuf;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>), dim3(G), dim3(512), LDS, s, a, g);
-    hipStreamSynchronize(s);
-    static unsigned long long host[256 * 8 * 8];
-    hipMemcpy(host, dbgbuf, sizeof(host), hipMemcpyDeviceToHost);
-    const double steps = (double)items / G * g.cch * 9;
-    for (int grp = 0; grp < 2; ++grp) {
-      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int b = 0; b < G; ++b) for (int w = grp * 4; w < grp * 4 + 4; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)host[(b * 8 + w) * 8 + i];
-      fprintf(stderr, "[halo stamps grp %c] cycles/step: s0=%.0f s1=%.0f s2=%.0f s3=%.0f s4=%.0f s5=%.0f s6=%.0f s7=%.0f | steps/block=%.0f\n", 'A' + grp,
-              sum[0] / (G * 4) / steps, sum[1] / (G * 4) / steps, sum[2] / (G * 4) / steps, sum[3] / (G * 4) / steps, sum[4] / (G * 4) / steps,
-              sum[5] / (G * 4) / steps, sum[6] / (G * 4) / steps, sum[7] / (G * 4) / steps, steps);
-    }
-    return DANHIP_OK;
-  }
-#endif
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, NSW, DGRAD, DBG, NCU>), dim3(G), dim3(512), LDS, s, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
 
-}  // namespace
-
-namespace {
+// configurations: <TH, TW, BN, WM, WN, TPS, NSW>
+//   128-wide : 4x2 waves (64 px x 64 co each), 1 tap / step, 4-deep ring
+//    64-wide : 8x1 waves (32 px x 64 co each), 1 tap / step, 4-deep ring.  (The 3-taps-per-step form <.., 3, 3> is correct
+//              and kept instantiable, but measured slower on conv1_2 / conv2_1-dgrad: with one or two chunks per item the
+//              per-item epilogue + patch DMA land in one long mem phase.)
 template <bool DGRAD>
 int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
   if (p.head) {
     if (DGRAD) return 1;
-    return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 4, false, 0, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 4, false, 0, 1>(a, s);
+    return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 1, 4, false, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 1, 4, false, 1>(a, s);
   }
   if (p.th == 8) {
-#ifdef DANHIP_HALO_EXPERIMENTS
-    if (p.bn == 128 && !DGRAD) {
-      const char* e = getenv("DANHIP_HALO_DBG");
-      const int dbg = e ? atoi(e) : 0;
-      if (dbg == 4) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 4>(a, s);
-      if (dbg == 8) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 8>(a, s);
-      if (dbg == 16) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 16>(a, s);
-      if (dbg == 24) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 24>(a, s);
-      if (dbg == 28) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 28>(a, s);
-      if (dbg == 36) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 36>(a, s);
-      if (dbg == 32) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 32>(a, s);
-      if (dbg == 64) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 64>(a, s);
-      if (dbg == 96) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 96>(a, s);
-      if (dbg == 98) return launch_halo_cfg<8, 32, 128, 4, 2, 4, false, 98>(a, s);
-    }
-#endif
-    if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 4, DGRAD>(a, s);
-    return launch_halo_cfg<8, 32, 64, 8, 1, 4, DGRAD>(a, s);
+    if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 1, 4, DGRAD>(a, s);
+    return launch_halo_cfg<8, 32, 64, 8, 1, 1, 4, DGRAD>(a, s);
   }
-  if (p.bn == 128) return launch_halo_cfg<16, 16, 128, 4, 2, 4, DGRAD>(a, s);
-  return launch_halo_cfg<16, 16, 64, 8, 1, 4, DGRAD>(a, s);
+  if (p.bn == 128) return launch_halo_cfg<16, 16, 128, 4, 2, 1, 4, DGRAD>(a, s);
+  return launch_halo_cfg<16, 16, 64, 8, 1, 1, 4, DGRAD>(a, s);
 }
+
 }  // namespace
 
 // dgrad mode = no bias / relu / residual / fp32 output requested (the data-gradient call); forward otherwise.
@@ -606,12 +573,12 @@ const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {
   if (!plan_halo(a, &p)) return nullptr;
   if (p.head) {
     if (dgrad) return nullptr;
-    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0, 1>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0, 1>";
+    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 1>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 1>";
   }
   if (p.th == 8) {
-    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, true, 0, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 4, false, 0, 0>";
-    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, true, 0, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 4, false, 0, 0>";
+    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, false, 0>";
+    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 0>";
   }
-  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, true, 0, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 4, false, 0, 0>";
-  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, true, 0, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 4, false, 0, 0>";
+  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, false, 0>";
+  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 0>";
 }

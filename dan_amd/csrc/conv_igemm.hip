@@ -262,7 +262,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     case 128: return launch_cfg<128, 128, 2>(a, fast, s);
     case 64: return launch_cfg<256, 64, 1>(a, fast, s);
     case 32: return launch_cfg<256, 32, 1>(a, fast, s);
-    default: return launch_cfg<256, 16, 1>(a, fast, s);
+    default:
+      // thin heads on small maps: 256-pixel tiles would leave most CUs idle (20x20x16 images = 25 tiles) -> 64-pixel tiles
+      if (a.M <= 256 * 128) return launch_cfg<64, 16, 1>(a, fast, s);
+      return launch_cfg<256, 16, 1>(a, fast, s);
   }
 }
 
@@ -389,7 +392,11 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     case 128: return fast ? "conv_igemm_kernel<128, 128, 2, true>" : "conv_igemm_kernel<128, 128, 2, false>";
     case 64: return fast ? "conv_igemm_kernel<256, 64, 1, true>" : "conv_igemm_kernel<256, 64, 1, false>";
     case 32: return fast ? "conv_igemm_kernel<256, 32, 1, true>" : "conv_igemm_kernel<256, 32, 1, false>";
-    default: return fast ? "conv_igemm_kernel<256, 16, 1, true>" : "conv_igemm_kernel<256, 16, 1, false>";
+    default: {
+      const long M = which == 0 ? (long)d->N * d->Ho * d->Wo : (long)d->N * d->H * d->W;
+      if (M <= 256 * 128) return fast ? "conv_igemm_kernel<64, 16, 1, true>" : "conv_igemm_kernel<64, 16, 1, false>";
+      return fast ? "conv_igemm_kernel<256, 16, 1, true>" : "conv_igemm_kernel<256, 16, 1, false>";
+    }
   }
 }
 

@@ -38,7 +38,7 @@ def test_invalid_arguments_are_reported_not_thrown():
     d.Cin = 64
     assert L.danhip_conv_packed_dims(ctypes.byref(d), 0, ctypes.byref(r), ctypes.byref(c)) == 0
     assert (r.value, c.value) == (16, 576)
-    assert L.danhip_conv_kernel_label(ctypes.byref(d), 0) == b"conv_igemm_kernel<256, 16, 1, true>"
+    assert L.danhip_conv_kernel_label(ctypes.byref(d), 0) == b"conv_igemm_kernel<64, 16, 1, true>"
     # small_mining_match attribute validation mirrors the op constructor (small_mining_match.cc:291-306)
     rc = L.danhip_small_mining_match(None, 1, 1, 0.0, 0.4, 0.4, 6, 0.3, None, None, None, 0, None)
     assert rc == -1
