@@ -22,7 +22,10 @@ struct ConvArgs {
 // Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
 // eligible (caller falls back to the flat-M kernel), negative on a launch error.
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
-const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible
+const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);
+// 64 -> 64 channel special case with register-resident weights (conv_halo_c64.hip); same return convention.
+int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s);
+const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible
 
 // Halo-reuse 3x3/stride-1 weight gradient (conv_wgrad_halo.hip): DANHIP_OK when launched, 1 when not eligible.
 const char* danhip_wgrad_halo_label(const danhip_conv_desc* d);

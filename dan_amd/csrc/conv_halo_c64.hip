@@ -1,0 +1,261 @@
+// 3x3 / stride-1 convolution with 64 input and 64 output channels (conv1_2 of every backbone, net/sfd_net.py:128, and its
+// data gradient; DAN's 64->64 branch conv, net/danet.py:880) — register-resident weights.
+//
+// At C = Co = 64 the whole filter is 9 x 64 x 64 bf16 = 72 KiB: each of the 8 waves keeps the 32 output channels it owns
+// (9 taps x 2 k-slices x 2 channel tiles = 36 MFMA A-fragments = 144 VGPRs) in registers for the lifetime of the persistent
+// workgroup.  No weight DMA, no weight LDS reads, and the only workgroup barrier is one per spatial tile (patch hand-off):
+// per 8 x 32 pixel tile a wave (64 pixels x 32 channels) reads 72 pixel fragments and issues 144 MFMAs; the next tile's halo
+// patch (43 KiB, double buffered) lands meanwhile and the epilogue stores drain under the next tile's MFMAs.
+// The kernel is HBM-lean by construction (input read once + halo, output written once) — at 640 x 640 x batch 16 that is
+// 1.7 GB per call, so it sits near both rooflines (0.3 ms at 5.5 TB/s; 0.3 ms at 1.6 PFLOP/s).
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+struct C64Geom {
+  int tiles_x, tiles_y, sp_items;
+  FastDiv div_tx, div_txy;
+};
+
+template <int N>
+__device__ __forceinline__ void c64_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <bool DGRAD>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(const ConvArgs a, const C64Geom g) {
+  constexpr int TH = 8, TW = 32, PW = TW + 2;
+  constexpr int PROWS = (TH + 2) * PW, PPIECES = (PROWS + 7) / 8, PBYTES = PPIECES * 1024, PL = (PPIECES + 7) / 8;
+  constexpr int NPT = 4, NCT = 2;                  // wave tile: 64 pixels (2 tile rows) x 32 channels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int srow = lane >> 3, frow = lane & 15, fq = lane >> 4;
+  const int G = gridDim.x;
+
+  // ---- this wave's weights -> registers: A fragment (tap, ks, ct): W[co = wn*32 + ct*16 + frow][k = tap*64 + ks*32 + fq*8 ..]
+  bf16x8 wr[9][2][NCT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        wr[t][ks][ct] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(wn * 32 + ct * 16 + frow) * a.Kpad + t * 64 + ks * 32 + fq * 8);
+
+  auto sp_coords = [&](int sp, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+    n = (int)fdiv((unsigned)sp, g.div_txy);
+    const int rem = sp - n * (g.tiles_x * g.tiles_y);
+    const int ty = (int)fdiv((unsigned)rem, g.div_tx);
+    y0 = ty * TH;
+    x0 = (rem - ty * g.tiles_x) * TW;
+  };
+
+  // ---- patch DMA (same layout as conv_halo.hip: row R = hy*PW + hx, chunk c at position c ^ (hx & 7))
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+  auto issue_patch = [&](int sp, int buf) __attribute__((always_inline)) {
+    int n, y0, x0;
+    sp_coords(sp, n, y0, x0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                   // keep the per-piece geometry out of long-lived registers (recomputed per tile)
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+      int piece = k * 8 + wave;
+      if (piece > PPIECES - 1) piece = PPIECES - 1;
+      const int row = piece * 8 + (ln >> 3);
+      const int hy = row / PW, hx = row - hy * PW;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = row < PROWS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)((n * a.H + y) * a.W + x) * 128u + (unsigned)(((ln & 7) ^ (hx & 7)) << 4) : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(smem + buf * PBYTES + piece * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  int pxaddr[3][NPT];                              // fragment p at tap column j, k-slice 0, in the CURRENT buffer (flipped per tile)
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int t = wm * 64 + p * 16 + frow;
+    const int ty = t / TW, tx = t % TW;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pxaddr[j][p] = (ty * PW + tx + j) * 128 + ((fq ^ ((tx + j) & 7)) << 4);
+  }
+
+  f32x4 acc[NCT][NPT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 xa[NPT], xb[NPT], xc[NPT];
+  auto read_px = [&](bf16x8 (&x)[NPT], auto tapc, int ks) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(tapc)::value;
+    constexpr int TI = TAP / 3, TJ = TAP % 3;
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) x[p] = *reinterpret_cast<const bf16x8*>(smem + (ks ? (pxaddr[TJ][p] ^ 64) : pxaddr[TJ][p]) + TI * PW * 128);
+  };
+  auto mma = [&](const bf16x8 (&w)[NCT], const bf16x8 (&x)[NPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], x[p], acc[c][p], 0, 0, 0);
+  };
+
+  int sp = blockIdx.x;
+  if (sp >= g.sp_items) return;
+  issue_patch(sp, 0);
+  c64_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (;;) {
+    const int nsp = sp + G;
+    const bool has_next = nsp < g.sp_items;
+    if (has_next) issue_patch(nsp, buf ^ 1);       // the other buffer was released by the barrier that ended the previous tile
+    // ---- 18 half-taps (tap, k-slice); pixel fragments software-pipelined TWO half-taps ahead through three rotating
+    //      register sets (a ds_read_b128 under load takes longer than the 8 MFMAs of one half-tap)
+    auto rd = [&](bf16x8 (&x)[NPT], auto hc) __attribute__((always_inline)) {
+      constexpr int H = decltype(hc)::value;
+      read_px(x, std::integral_constant<int, H / 2>{}, H & 1);
+    };
+    auto half = [&](auto hc, bf16x8 (&cur)[NPT], bf16x8 (&)[NPT]) __attribute__((always_inline)) {
+      constexpr int H = decltype(hc)::value;
+      mma(wr[H / 2][H & 1], cur);
+      if constexpr (H + 3 < 18) rd(cur, std::integral_constant<int, H + 3>{});       // refill the set just consumed
+    };
+    rd(xa, std::integral_constant<int, 0>{});
+    rd(xb, std::integral_constant<int, 1>{});
+    rd(xc, std::integral_constant<int, 2>{});
+#define C64_H(H, X) half(std::integral_constant<int, H>{}, X, X)
+    C64_H(0, xa); C64_H(1, xb); C64_H(2, xc); C64_H(3, xa); C64_H(4, xb); C64_H(5, xc);
+    C64_H(6, xa); C64_H(7, xb); C64_H(8, xc); C64_H(9, xa); C64_H(10, xb); C64_H(11, xc);
+    C64_H(12, xa); C64_H(13, xb); C64_H(14, xc); C64_H(15, xa); C64_H(16, xb); C64_H(17, xc);
+#undef C64_H
+    // ---- hand-off: the next patch has landed (own pieces) and everybody is done reading this one
+    c64_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // ---- epilogue (its stores drain under the next tile's MFMAs)
+    {
+      int n, y0, x0;
+      sp_coords(sp, n, y0, x0);
+      float4 biasv[NCT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+        biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + wn * 32 + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const int t = wm * 64 + p * 16 + frow;
+        const int y = y0 + t / TW, x = x0 + t % TW;
+        const bool ok = y < a.H && x < a.W;
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * 64 + (wn * 32 + fq * 4);
+        uint2 in0[NCT], in1[NCT];
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) {
+            if (!DGRAD) {
+              if (a.resid) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
+            } else {
+              if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
+              if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          if (ok) {
+            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
+            if (!DGRAD) {
+              v[0] += biasv[c].x; v[1] += biasv[c].y; v[2] += biasv[c].z; v[3] += biasv[c].w;
+              if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if (a.resid) {
+                const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
+              }
+            } else {
+              if (a.mask) {
+                const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in0[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+              }
+              if (a.accumulate) {
+                const bf16_t* op = reinterpret_cast<const bf16_t*>(&in1[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
+              }
+            }
+            uint2 tt;
+            tt.x = pack2bf(v[0], v[1]);
+            tt.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.y) + o0 + c * 16) = tt;
+          }
+          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if (!has_next) break;
+    sp = nsp;
+    buf ^= 1;
+    const int dir = buf ? PBYTES : -PBYTES;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) pxaddr[j][p] += dir;
+  }
+}
+
+int c64_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+bool c64_eligible(const ConvArgs& a) {
+  if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dstride == 1 && a.pad_t == 1 && a.pad_l == 1)) return false;
+  if (a.H != a.Ho || a.W != a.Wo || a.C != 64 || a.Co != 64 || a.out_f32 || a.Kpad != 576) return false;
+  const double util = (double)a.H * a.W / ((double)((a.H + 7) / 8 * 8) * (double)((a.W + 31) / 32 * 32));
+  return util >= 0.78 && (int64_t)a.N * a.H * a.W * 128 < (1ll << 32);
+}
+
+template <bool DGRAD>
+int launch_c64(const ConvArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024;
+  static const bool attr_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)attr_ok;
+  C64Geom g{};
+  g.tiles_x = (a.W + 31) / 32;
+  g.tiles_y = (a.H + 7) / 8;
+  g.sp_items = a.N * g.tiles_x * g.tiles_y;
+  g.div_tx = make_fastdiv(g.tiles_x);
+  g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
+  int G = c64_cu_count();
+  if (g.sp_items < G) G = g.sp_items;
+  hipLaunchKernelGGL((conv3x3_c64_kernel<DGRAD>), dim3(G), dim3(512), LDS, s, a, g);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+}  // namespace
+
+int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s) {
+  if (!c64_eligible(a)) return 1;
+  const bool dgrad = !a.bias && !a.relu && !a.resid;
+  if (!dgrad && (a.accumulate || a.mask)) return 1;
+  return dgrad ? launch_c64<true>(a, s) : launch_c64<false>(a, s);
+}
+
+const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad) {
+  if (!c64_eligible(a)) return nullptr;
+  return dgrad ? "conv3x3_c64_kernel<true>" : "conv3x3_c64_kernel<false>";
+}

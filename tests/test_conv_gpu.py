@@ -22,6 +22,8 @@ SHAPES = [
     (5, 56, 96, 128, 128, 3, 3, 1),
     # thin detection heads (Cout 8 / 6) on maps large enough for the halo kernels (loc+cls in one pass)
     (2, 16, 32, 256, 8, 3, 3, 1), (1, 32, 32, 64, 6, 3, 3, 1), (3, 24, 64, 128, 16, 3, 3, 1),
+    # 64 -> 64 channels: the register-resident-weights kernel (full tiles, ragged edges, > 256 tiles)
+    (2, 16, 64, 64, 64, 3, 3, 1), (1, 30, 62, 64, 64, 3, 3, 1), (9, 64, 128, 64, 64, 3, 3, 1),
 ]
 
 
