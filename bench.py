@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
+                    help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
 
     from dan_amd import ops, synthetic
@@ -83,13 +85,30 @@ def main():
     dev = torch.device("cuda", local)
     B, S = args.batch_per_gpu, args.size
 
-    model = SFDModel(device=dev)
-    trainer = SFDTrainer(model, world=world)
-    anchors = AnchorConfig(S, S, dev)
     # synthetic shard of this rank (contiguous split of the global batch, tf_replicate_model_fn.py:458-498)
     imgs = synthetic.make_images(B, S, S, dev, seed=synthetic.SEED + rank)
     gts = synthetic.make_gt_boxes(B, S, S, seed=synthetic.SEED + 100 * rank)
-    loc_t, cls_t, _ = anchors.encode_batch(gts)     # input pipeline work (anchor encoding) — not part of the step
+    if args.model == "sfd":
+        model = SFDModel(device=dev)
+        trainer = SFDTrainer(model, world=world)
+        anchors = AnchorConfig(S, S, dev)
+        loc_t, cls_t, _ = anchors.encode_batch(gts)     # input pipeline work (anchor encoding) — not part of the step
+        step_args = (imgs, loc_t, cls_t)
+        workload = "S3FD VGG-16 backbone + 6 detection heads"
+    elif args.model == "pb":
+        from dan_amd.train_pb import PBAnchorTargets, PBModel, PBTrainer
+        model = PBModel(device=dev)
+        trainer = PBTrainer(model, world=world)
+        anchors = PBAnchorTargets(S, S, dev).face
+        step_args = (imgs, PBAnchorTargets(S, S, dev).encode_batch(gts))
+        workload = "PyramidBox (LFPN + CPM + face/head/body heads)"
+    else:
+        from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
+        model = DANModel(device=dev, deform=args.model == "dan_deform")
+        anchors = dan_anchor_config(S, S, dev)
+        trainer = DANTrainer(model, anchors, world=world)
+        step_args = (imgs,) + encode_batch_dan(anchors, gts)
+        workload = "DAN-Deform (deformable context module)" if args.model == "dan_deform" else "DAN (two-stage heads, dynamic anchor routing)"
     torch.cuda.synchronize()
 
     def barrier():
@@ -98,12 +117,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.train_step(imgs, loc_t, cls_t)
+        trainer.train_step(*step_args)
     barrier()
     ops.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step(imgs, loc_t, cls_t)
+        trainer.train_step(*step_args)
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
@@ -113,7 +132,9 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        ce, ll, l2, total = trainer.losses()
+        lv = trainer.loss_values()
+        first = [k for k in lv if k not in ("l2", "total")][0]
+        ce, ll, l2 = lv[first][0], lv[first][1], lv["l2"]
         # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
         stats = []
         for label, evs in prof.items():
@@ -137,7 +158,7 @@ def main():
             "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "S3FD VGG-16 backbone + 6 detection heads, %dx%d bf16 training (fwd+bwd+SGD), batch %d per GPU" % (S, S, B),
+            "config": {"workload": "%s, %dx%d bf16 training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,

@@ -49,7 +49,7 @@ SIGNATURES = {
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
     "danhip_deform_sample_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_deform_sample_bwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, P],
-    "danhip_cast_pad_f32_to_bf16": [P, P, I64, I32, I32, P],
+    "danhip_cast_pad_f32_to_bf16": [P, P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_hard_neg_select": [P, P, P, P, P, P, I32, I32, FL, ctypes.c_int, P],

@@ -46,7 +46,7 @@ __device__ __forceinline__ int f256(int px) { return (px & 3) | (((px >> 3) & 1)
 
 // COT: output-channel tile (128: waves = 4 ci-groups x 2 co-halves, every wave sees every K-step;
 //                           64: waves = 4 ci-groups x 2 K-groups, group A takes the even rows, group B the odd ones)
-template <int COT>
+template <int COT, bool FRONT = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
   constexpr int TH = 4, TW = 32, PW = TW + 2;
   constexpr int XPIX = (TH + 2) * PW;                 // 204 patch pixels, 128-byte rows (64 ci)
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int CPT = TH / KPC;                       // cycles per pixel tile
   constexpr int NX = (XPIECES + 7) / 8, NY = YPIECES / 8;
   constexpr int NDMA = NX + NY;                       // DMA instructions per wave per tile
-  constexpr int PER = (NDMA + (CPT - 1) - 1) / (CPT - 1);   // issued per cycle in cycles 0 .. CPT-2
+  constexpr int PER_SPREAD = (NDMA + (CPT - 1) - 1) / (CPT - 1);   // spread over cycles 0 .. CPT-2
+  constexpr int PER = FRONT ? NDMA : PER_SPREAD;                   // FRONT: everything in cycle 0 (measured 1-4 % slower: kept off)
   constexpr int NO = 4;                               // co fragments per wave (64 co)
   static_assert(2 * BUF <= 160 * 1024, "LDS budget");
   static_assert(5 * PW * 128 + BUF < 65536 + BUF, "imm offsets");
@@ -326,11 +327,11 @@ int wg_cu_count() {
   return n;
 }
 
-template <int COT>
+template <int COT, bool FRONT = false>
 int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
   constexpr int XB = ((6 * 34 + 7) / 8) * 1024, YB = 128 * COT * 2;
   constexpr int LDS = 2 * (XB + YB);
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<COT>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<COT, FRONT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   a.ci_tiles = a.C / 64;
@@ -344,7 +345,7 @@ int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
   a.div_ci = make_fastdiv(a.ci_tiles);
   a.div_pairs = make_fastdiv(pairs);
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<COT, FRONT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

@@ -267,12 +267,15 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ img, bf16_t*
   }
 }
 
-__global__ void cast_pad_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, int c_src, int c_dst) {
+__global__ void cast_pad_kernel(const float* __restrict__ src, const bf16_t* __restrict__ relu_y, bf16_t* __restrict__ dst, long rows, int c_src,
+                                int c_dst) {
   const long total = rows * c_dst;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / c_dst;
     const int c = (int)(i % c_dst);
-    dst[i] = f2bf(c < c_src ? src[r * c_src + c] : 0.f);
+    float v = c < c_src ? src[r * c_src + c] : 0.f;
+    if (relu_y && c < c_src && !(bf2f(relu_y[r * c_src + c]) > 0.f)) v = 0.f;       // ReLU backward on the UNPADDED layout of y
+    dst[i] = f2bf(v);
   }
 }
 
@@ -366,9 +369,10 @@ extern "C" int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64
   return DANHIP_OK;
 }
 
-extern "C" int danhip_cast_pad_f32_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst, void* stream) {
+extern "C" int danhip_cast_pad_f32_to_bf16(const float* src, const uint16_t* relu_y, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst,
+                                           void* stream) {
   DH_REQUIRE(src && dst && rows > 0 && c_src > 0 && c_dst >= c_src, DANHIP_EINVAL, "cast_pad: bad arguments");
-  hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * c_dst, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, (long)rows, c_src, c_dst);
+  hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for(rows * c_dst, 256)), dim3(256), 0, (hipStream_t)stream, src, relu_y, dst, (long)rows, c_src, c_dst);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

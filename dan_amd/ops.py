@@ -164,11 +164,14 @@ class _Conv2d(torch.autograd.Function):
                 # fp32 / unpadded upstream gradient (head convs): cast + pad channels to a multiple of 8
                 src = dy.contiguous().to(torch.float32)
                 dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=torch.bfloat16, device=dy.device)
-                call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(dyp), M, d.Cout, co8, stream())
+                # ragged Cout: y has Cout (not co8) channels per row, so its ReLU mask is applied here, on the unpadded layout
+                call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(y) if (ctx.relu and d.Cout != co8) else None, ptr(dyp), M, d.Cout, co8, stream())
                 dy, owned = dyp, True
+                masked = ctx.relu and d.Cout != co8
             else:
                 dy, owned = dy.contiguous(), False
-            if ctx.relu:
+                masked = False
+            if ctx.relu and not masked:
                 if not owned:
                     dy = dy.clone()                      # the incoming gradient tensor may be shared with other consumers
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
@@ -403,7 +406,7 @@ def cast_pad(x_f32, c_dst):
     shp = x_f32.shape
     rows = x_f32.numel() // shp[-1]
     out = torch.empty(shp[:-1] + (c_dst,), dtype=torch.bfloat16, device=x_f32.device)
-    call("danhip_cast_pad_f32_to_bf16", ptr(x_f32.contiguous()), ptr(out), rows, shp[-1], c_dst, stream())
+    call("danhip_cast_pad_f32_to_bf16", ptr(x_f32.contiguous()), None, ptr(out), rows, shp[-1], c_dst, stream())
     return out
 
 

@@ -126,8 +126,11 @@ int danhip_batchnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gam
 /* preprocess_for_eval arithmetic (preprocessing/dan_preprocessing.py:55-57,755-758): uint8 RGB [npix,3] ->
  * bf16 [npix,8] = (B-103.94, G-116.78, R-123.68, 0,0,0,0,0). */
 int danhip_preprocess_u8(const uint8_t* img_rgb, uint16_t* out, int64_t npix, void* stream);
-/* fp32 [rows,c_src] -> bf16 [rows,c_dst] zero padded (gradient of the fp32 head outputs). */
-int danhip_cast_pad_f32_to_bf16(const float* src, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst, void* stream);
+/* fp32 [rows,c_src] -> bf16 [rows,c_dst] zero padded (gradient of the fp32 head outputs / of ragged-Cout convs).
+ * relu_y (optional, bf16 [rows,c_src]): the layer's ReLU output — elements where it is <= 0 are zeroed (ReLU backward applied on
+ * the unpadded layout, before the channel padding). */
+int danhip_cast_pad_f32_to_bf16(const float* src, const uint16_t* relu_y, uint16_t* dst, int64_t rows, int32_t c_src, int32_t c_dst,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Detection heads glue, hard-negative mining, losses, optimizer (fp32 / int32).

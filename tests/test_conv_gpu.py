@@ -103,3 +103,27 @@ def test_relu_mask_and_bias_grad(dev):
         scale = want.abs().max().item() + 1e-6
         err = (got - want).abs().max().item()
         assert err <= 2.0 ** -6 * scale + 2e-3, (name, err, scale)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 48, 256, 85, 1, 1, 1), (1, 33, 20, 64, 171, 1, 1, 1), (1, 12, 12, 64, 30, 3, 3, 1)])
+def test_ragged_cout_relu_backward(shape, dev):
+    """Cout not a multiple of 8 with ReLU (DAN stage-2 1x1 convs, danet.py:944-947): the ReLU mask must be taken on the
+    unpadded [.., Cout] layout of y before the gradient is padded to a multiple of 8 channels."""
+    from dan_amd import ops
+    x, w, b, s = _mk(shape, 11)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride=s, relu=True)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(torch.bfloat16)
+    y.float().backward(dy.to(dev).float())
+    torch.cuda.synchronize()
+    mask = (y.detach().float().cpu() > 0).float()
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    T.conv2d_same(xr, wr, br, stride=s, relu=False).backward(dy.float() * mask)
+    for name, got, want in (("dx", xd.grad.float().cpu(), xr.grad), ("dw", wd.grad.cpu(), wr.grad), ("db", bd.grad.cpu(), br.grad)):
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= 2.0 ** -6 * scale + 2e-3, (shape, name, err, scale)
