@@ -153,6 +153,77 @@ __global__ void deform_sample_bwd_kernel(const bf16_t* __restrict__ x, const bf1
   }
 }
 
+
+// Fast path for C / deformable_group == 64: one WAVE per (output pixel, tap, deformable group), lane = channel.  Every
+// atomic wave-instruction then adds 64 consecutive floats (256 contiguous bytes — the full-rate shape of the memory-side
+// float atomics), and the offset gradient is a plain 64-lane reduction.
+__global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                             float* __restrict__ dx, bf16_t* __restrict__ doffs, DeformGeom g) {
+  const int taps = g.kh * g.kw;
+  const int offc = g.dg * 2 * taps;
+  const int lane = threadIdx.x & 63;
+  const long nwork = (long)g.N * g.Ho * g.Wo * taps * g.dg;              // (m, t, grp) triples, grp fastest
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const float Hf = (float)g.H, Wf = (float)g.W;
+  for (long wk = wave0; wk < nwork; wk += nwaves) {
+    const int grp = (int)(wk % g.dg);
+    long r = wk / g.dg;
+    const int t = (int)(r % taps);
+    const long m = r / taps;
+    const int wo = (int)(m % g.Wo);
+    const int ho = (int)((m / g.Wo) % g.Ho);
+    const int n = (int)(m / ((long)g.Wo * g.Ho));
+    const int i = t / g.kw, j = t % g.kw;
+    const int h_in = ho * g.stride - g.pad_t, w_in = wo * g.stride - g.pad_l;
+    const bf16_t* op = offs + m * offc + (grp * taps + t) * 2;
+    const float inv_h = (float)(h_in + i * g.dil) + bf2f(op[0]);
+    const float inv_w = (float)(w_in + j * g.dil) + bf2f(op[1]);
+    const int c = grp * 64 + lane;
+    const float cg = bf2f(dS[(m * taps + t) * g.C + c]);
+    const bf16_t* base = x + ((long)n * g.H * g.W) * g.C + c;
+    // ---- dOffset (get_coordinate_weight)
+    float s_h = 0.f, s_w = 0.f;
+    if (!(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf)) {
+      float ih = inv_h, iw = inv_w;
+      int h_low = (int)ih, w_low = (int)iw, h_high, w_high;
+      if (h_low >= g.H - 1) { h_high = h_low = g.H - 1; ih = (float)h_low; } else h_high = h_low + 1;
+      if (w_low >= g.W - 1) { w_high = w_low = g.W - 1; iw = (float)w_low; } else w_high = w_low + 1;
+      const float vll = bf2f(base[((long)h_low * g.W + w_low) * g.C]), vlh = bf2f(base[((long)h_low * g.W + w_high) * g.C]);
+      const float vhl = bf2f(base[((long)h_high * g.W + w_low) * g.C]), vhh = bf2f(base[((long)h_high * g.W + w_high) * g.C]);
+      const float a_w = (float)(w_low + 1) - iw, b_w = iw - (float)w_low;
+      const float a_h = (float)(h_low + 1) - ih, b_h = ih - (float)h_low;
+      s_h = (-1.f * a_w * vll + -1.f * b_w * vlh + a_w * vhl + b_w * vhh) * cg;
+      s_w = (-1.f * a_h * vll + a_h * vlh + -1.f * b_h * vhl + b_h * vhh) * cg;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s_h += __shfl_xor(s_h, o, 64); s_w += __shfl_xor(s_w, o, 64); }
+    if (lane == 0) {
+      bf16_t* dp = doffs + m * offc + (grp * taps + t) * 2;
+      dp[0] = f2bf(s_h);
+      dp[1] = f2bf(s_w);
+    }
+    // ---- dX (get_gradient_weight), wave-uniform corner geometry
+    if (!(inv_h < 0 || inv_h > Hf || inv_w < 0 || inv_w > Wf)) {
+      float ah = fmaxf(inv_h, 0.f), aw = fmaxf(inv_w, 0.f);
+      int hl = (int)ah, wl = (int)aw, hh, wh;
+      const bool ch = hl >= g.H - 1, cw = wl >= g.W - 1;
+      if (ch) { hh = hl = g.H - 1; ah = (float)hl; } else hh = hl + 1;
+      if (cw) { wh = wl = g.W - 1; aw = (float)wl; } else wh = wl + 1;
+      const int rh[4] = {hl, hl, hh, hh}, rw[4] = {wl, wh, wl, wh};
+      const float wg[4] = {((float)(hl + 1) - ah) * ((float)(wl + 1) - aw), ((float)(hl + 1) - ah) * (aw + 1.f - (float)wh),
+                           (ah + 1.f - (float)hh) * ((float)(wl + 1) - aw), (ah + 1.f - (float)hh) * (aw + 1.f - (float)wh)};
+      const bool dup[4] = {false, cw, ch, ch || cw};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = !dup[k] && fabsf(inv_h - (float)rh[k]) < 1.f && fabsf(inv_w - (float)rw[k]) < 1.f && rh[k] >= 0 && rh[k] < g.H &&
+                        rw[k] >= 0 && rw[k] < g.W;
+        if (ok) atomicAdd(dx + (((long)n * g.H + rh[k]) * g.W + rw[k]) * g.C + c, wg[k] * cg);
+      }
+    }
+  }
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
@@ -217,8 +288,13 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
   if (hipMemsetAsync(workspace, 0, sizeof(float) * nx, s) != hipSuccess) { danhip_set_error("deform_sample_bwd: memset failed"); return DANHIP_ELAUNCH; }
-  const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
-  hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+  if (C / deformable_group == 64) {
+    const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
+    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+  } else {
+    const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
+    hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+  }
   DH_LAUNCH_CHECK();
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate);
   DH_LAUNCH_CHECK();
