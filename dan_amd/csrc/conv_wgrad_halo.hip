@@ -363,7 +363,7 @@ static bool wg_halo_eligible(const danhip_conv_desc* d) {
 
 const char* danhip_wgrad_halo_label(const danhip_conv_desc* d) {
   if (!wg_halo_eligible(d)) return nullptr;
-  return ((d->Cout + 7) / 8 * 8) % 128 == 0 ? "conv_wgrad_halo_kernel<128>" : "conv_wgrad_halo_kernel<64>";
+  return ((d->Cout + 7) / 8 * 8) % 128 == 0 ? "conv_wgrad_halo_kernel<128, false>" : "conv_wgrad_halo_kernel<64, false>";
 }
 
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
