@@ -1,0 +1,9 @@
+"""eval_sfd.py's test-time pipeline (:60-196, :323-330): the same helpers as eval_dan.py without the pyramid pass."""
+from .eval_dan import (Detector, bbox_vote, bbox_vote_batch, detect_face, flip_test, get_shrink, multi_scale_test,  # noqa: F401
+                       resize_image, write_to_txt)
+from .eval_dan import detect_image as _detect_image
+
+
+def detect_image(net, image):
+    """eval_sfd.py:323-328: origin + flip + multi-scale, merged by box voting."""
+    return _detect_image(net, image, pyramid=False)

@@ -230,6 +230,20 @@ int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_ta
 int danhip_nms(const float* boxes_sorted, int32_t B, int32_t K, int32_t max_out, float iou_threshold, int32_t* keep_idx,
                int32_t* num_keep, void* stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * Test-time pipeline of eval_dan.py / eval_sfd.py
+ *   resize_u8_linear : cv2.resize(image, None, None, fx, fy, INTER_LINEAR) of eval_dan.py:96-97 on an 8-bit HWC image
+ *                      (generic fixed-point path of OpenCV); Ho/Wo = round-half-even(H*fy / W*fx), computed by the caller.
+ *   bbox_vote        : eval_dan.py:201-241.  det float64 [B,Nmax,5] rows (xmin,ymin,xmax,ymax,score) in the order of
+ *                      det[:,4].argsort()[::-1] (:202-203), counts int32 [B]; IoU with +1, merge when >= iou_threshold,
+ *                      clusters of one dropped, float64 sums, float32 results.  out fp32 [B,max_out,5], num_out int32 [B].
+ * ------------------------------------------------------------------------------------------------ */
+int danhip_resize_u8_linear(const uint8_t* src, int32_t H, int32_t W, uint8_t* dst, int32_t Ho, int32_t Wo, int32_t C, double fx,
+                            double fy, void* stream);
+size_t danhip_bbox_vote_workspace_bytes(int32_t B, int32_t Nmax);
+int danhip_bbox_vote(const double* det, const int32_t* counts, int32_t B, int32_t Nmax, double iou_threshold, int32_t max_out,
+                     float* out, int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,26 @@ def test_dan_eval_output_assembly(dev):
         # the easy-mask threshold (score > 0.03) and the routing arg-max are discrete: compare where the two score vectors agree
         assert np.allclose(got_s, ref_s, atol=2e-6)
         assert np.allclose(got_b, ref_b, rtol=1e-4, atol=1e-3), np.abs(got_b - ref_b).max()
+
+
+@pytest.mark.parametrize("h,w", [(75, 133), (203, 331)])
+def test_dan_forward_parity_ragged_sizes(h, w, dev):
+    """eval-time image sizes are arbitrary (eval_dan.py:303 placeholder (None, None, 3)): SAME pools / stride-2 convs round
+    up, the LFPN resize targets the lateral's size, and every conv tile is ragged at the right / bottom edge."""
+    from dan_amd import synthetic
+    from dan_amd.train_dan import DANModel
+    from dan_amd.train_sfd import layer_shapes
+    imgs = synthetic.make_images(1, h, w, "cpu", seed=h)
+    x = ON.preprocess_synthetic(imgs)
+    fwd = lambda P, xx: ON.dan_forward(P, xx, deform=False)
+    P = _weights(fwd, x, 33)
+    with torch.no_grad():
+        (l1r, c1r), (l2r, c2r) = fwd(ON.Params(P.t, emulate_bf16=True), x.to(torch.bfloat16).float())
+    model = DANModel(device=dev)
+    model.vs.load_tf_named(P.t)
+    with torch.no_grad():
+        (l1, c1), (l2, c2), sizes = model.forward(imgs.to(dev))
+    assert sizes == layer_shapes(h, w)
+    for got, want, name in ((l1, l1r, "stage1/loc"), (c1, c1r, "stage1/cls"), (l2, l2r, "stage2/loc"), (c2, c2r, "stage2/cls")):
+        assert got.shape == want.shape
+        _check(got, want, name, 0.04)

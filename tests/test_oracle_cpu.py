@@ -177,3 +177,47 @@ def test_nms_and_parse_by_class():
     logits = np.log(np.stack([1 - s, s], -1))
     ob, os_ = OA.parse_by_class(logits, b, (100, 100), 0.03, 4, 4, 3, 0.5)
     assert ob.shape == (3, 4) and os_[0] > os_[1] >= os_[2]
+
+
+# ------------------------------------------------------------------------------------------------ test-time pipeline
+def test_evalpipe_resize_kats():
+    """Hand-computed KATs of OpenCV's fixed-point INTER_LINEAR (11-bit coefficients, >>4 / >>16 / +2 >>2 vertical pass)."""
+    from oracle import evalpipe as E
+    img = np.array([[[0] * 3, [100] * 3]], dtype=np.uint8)
+    # 2x enlargement of the row [0, 100]: source positions -0.25, 0.25, 0.75, 1.25 -> 0, 25, 75, 100 (both output rows)
+    assert E.cv2_resize_linear_u8(img, 2, 2)[:, :, 0].tolist() == [[0, 25, 75, 100]] * 2
+    rng = np.random.RandomState(0)
+    im = rng.randint(0, 256, (6, 8, 3)).astype(np.uint8)
+    quad = (im[0::2, 0::2].astype(int) + im[0::2, 1::2] + im[1::2, 0::2] + im[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(E.cv2_resize_linear_u8(im, 0.5, 0.5), quad)           # OpenCV: linear at exactly 1/2 == 2x2 area mean
+    assert E.cv2_resize_linear_u8(im, 0.75, 0.75).shape == (4, 6, 3)            # cvRound(4.5) = 4 (half to even), cvRound(6.0) = 6
+
+
+def test_evalpipe_vote_and_shrink_kats():
+    from oracle import evalpipe as E
+    det = np.array([[0, 0, 9, 9, 0.9], [1, 1, 10, 10, 0.6], [100, 100, 109, 109, 0.8]])
+    # IoU(+1) of the first two = 81 / 119 >= 0.3 -> merged with score weights; the lone third box is dropped (eval_dan.py:223-229)
+    out = E.bbox_vote(det)
+    assert out.dtype == np.float32 and out.shape == (1, 5)
+    assert np.allclose(out[0], [0.4, 0.4, 9.4, 9.4, 0.9], rtol=1e-6)
+    assert E.bbox_vote(det[2:]).shape == (0, 5)
+    assert E.get_shrink(1024, 1024) == (1, 1.62 - 0.3)                          # min(1.88.., 1.627..) -> "1.62" -> -0.3
+    assert E.get_shrink(480, 640) == (1, 3.0 - 0.3 - 0.2)                       # 3.006.. -> 3.0 -> 2.7 -> band [2,3): -0.2
+    s, m = E.get_shrink(1400, 2000)
+    assert s == m == 0.99 - 0.3                                                 # 0.996.. -> 0.99 -> 0.69 (< 1: the image is shrunk)
+    assert E.format_detections(out, "ev/im.jpg") == ["ev/im.jpg", "1", "0.0 0.0 10.0 10.0 0.900"]
+
+
+def test_eval_host_logic_matches_oracle():
+    """get_shrink / write_to_txt of the product module are host code: identical to the restatement on a sweep of sizes."""
+    import io
+    from dan_amd import eval_dan as P
+    from oracle import evalpipe as E
+    for h, w in [(96, 128), (480, 640), (683, 1024), (1024, 1024), (1400, 2000), (3000, 4000), (51, 77)]:
+        assert P.get_shrink(h, w) == E.get_shrink(h, w)
+    rng = np.random.RandomState(3)
+    det = np.concatenate([rng.rand(40, 2) * 50, 50 + rng.rand(40, 2) * 60, rng.rand(40, 1) * 0.05], axis=1).astype(np.float32)
+    det[:5, 3] = det[:5, 1] + 3                                                  # too flat: filtered (ceil(h) < 10)
+    f = io.StringIO()
+    P.write_to_txt(f, det, "ev", "im")
+    assert f.getvalue().splitlines() == E.format_detections(det, "ev/im.jpg")
