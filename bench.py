@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the inference-FPS leg (the 'eval FPS' half of BASELINE.json's metric)")
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
@@ -131,6 +132,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- inference leg ("eval FPS"): eval_sfd.py / eval_dan.py single-scale graph (forward + softmax + decode [+ routing]) on the same
+    # resident images, outside the timed training region; every rank runs it, the slowest rank's time counts
+    eval_out = None
+    if not args.no_eval:
+        for _ in range(2):
+            model.predict(imgs, anchors)
+        barrier()
+        e0 = time.perf_counter()
+        n_eval = max(3, args.steps)
+        for _ in range(n_eval):
+            model.predict(imgs, anchors)
+        barrier()
+        et = time.perf_counter() - e0
+        if world > 1:
+            t = torch.tensor([et], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            et = float(t.item())
+        eval_out = {"value": round(world * B * n_eval / et, 2), "unit": "images/sec", "batch_per_gpu": B, "ms_per_batch": round(et / n_eval * 1e3, 3),
+                    "what": "single-scale inference graph (forward + softmax + box decode%s), %dx%d" % (", anchor routing" if args.model.startswith("dan") else "", S, S)}
+
     if rank == 0:
         lv = trainer.loss_values()
         first = [k for k in lv if k not in ("l2", "total")][0]
@@ -164,6 +185,8 @@ def main():
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / args.steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],
         }
+        if eval_out:
+            out["eval"] = eval_out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

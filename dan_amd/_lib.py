@@ -51,6 +51,8 @@ SIGNATURES = {
     "danhip_bbox_vote": [P, P, I32, I32, ctypes.c_double, I32, P, P, P, ctypes.c_size_t, P],
     "danhip_deform_sample_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_deform_sample_bwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, P],
+    "danhip_deform_conv_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
+    "danhip_deform_conv_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_cast_pad_f32_to_bf16": [P, P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
@@ -92,6 +94,8 @@ def lib():
         L.danhip_routing_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_routing_workspace_bytes.argtypes = [I64, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.argtypes = [I32, I32]
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is missing

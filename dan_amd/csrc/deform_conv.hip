@@ -300,3 +300,62 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// DeformConvOp / DeformConvBackpropOp as single entry points (cpp/Deform/deform_conv.cc:392-535, :635-771): the same
+// orchestration as the reference's Compute() — im2col, GEMM; and for the backward GEMM^T, col2im_coord, col2im,
+// re-im2col, filter GEMM — with the im2col buffer living in the caller's workspace only for the duration of the call
+// (the reference allocates it with allocate_temp per call, :497-503) and all samples processed in one batch.
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t danhip_deform_conv_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride,
+                                                     int backward) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
+  const size_t Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const size_t col = align256((size_t)N * Ho * Wo * kh * kw * C * sizeof(uint16_t));
+  return backward ? 2 * col + align256((size_t)N * H * W * C * sizeof(float)) : col;
+}
+
+static int deform_gemm_desc(danhip_conv_desc* d, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride) {
+  d->N = N; d->Ho = (H + stride - 1) / stride; d->Wo = (W + stride - 1) / stride;
+  d->H = d->Ho; d->W = d->Wo; d->Cin = kh * kw * C; d->Cout = Cout; d->kh = 1; d->kw = 1; d->stride = 1;
+  return 0;
+}
+
+extern "C" int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_packed, const float* bias, const uint16_t* offsets, uint16_t* y,
+                                      int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                      int32_t dilation, int32_t deformable_group, int relu, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  DH_REQUIRE(x && wf_packed && offsets && y && workspace, DANHIP_EINVAL, "deform_conv_fwd: null pointer");
+  DH_REQUIRE(workspace_bytes >= danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0) && workspace_bytes > 0, DANHIP_EWORKSPACE,
+             "deform_conv_fwd: workspace too small");
+  uint16_t* col = (uint16_t*)workspace;
+  int rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);
+  if (rc) return rc;
+  danhip_conv_desc d;
+  deform_gemm_desc(&d, N, H, W, C, Cout, kh, kw, stride);
+  return danhip_conv2d_fwd(&d, col, wf_packed, bias, y, DANHIP_BF16, relu, nullptr, stream);
+}
+
+extern "C" int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy, uint16_t* dx,
+                                      uint16_t* d_offsets, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+                                      int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, int accumulate_dx,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  DH_REQUIRE(x && wb_packed && offsets && dy && dx && d_offsets && dw && workspace, DANHIP_EINVAL, "deform_conv_bwd: null pointer");
+  const size_t need = danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1);
+  DH_REQUIRE(workspace_bytes >= need && need > 0, DANHIP_EWORKSPACE, "deform_conv_bwd: workspace too small");
+  const size_t colb = danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0);
+  uint16_t* col = (uint16_t*)workspace;
+  uint16_t* dcol = (uint16_t*)((char*)workspace + colb);
+  float* scatter = (float*)((char*)workspace + 2 * colb);
+  danhip_conv_desc d;
+  deform_gemm_desc(&d, N, H, W, C, Cout, kh, kw, stride);
+  int rc = danhip_conv2d_bwd_data(&d, dy, wb_packed, nullptr, dcol, 0, stream);                       // col gradient = W^T dOut (:700-712)
+  if (rc) return rc;
+  rc = danhip_deform_sample_bwd(x, offsets, dcol, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate_dx, scatter,
+                                stream);                                                              // col2im_coord + col2im (:716-741)
+  if (rc) return rc;
+  rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);   // re-im2col (:744-748)
+  if (rc) return rc;
+  return danhip_conv2d_bwd_weight(&d, col, dy, dw, db, kh * kw * C, stream);                          // dW += dOut col^T (:750-768)
+}

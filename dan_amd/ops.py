@@ -538,5 +538,77 @@ class _DeformSample(torch.autograd.Function):
         return dx, doff, None, None, None, None, None
 
 
+class _DeformConv(torch.autograd.Function):
+    """DeformConvOp / DeformConvBackpropOp (cpp/Deform/deform_conv.cc:392-535, :635-771) through the single-call entry
+    points: the im2col buffer exists only inside each call (the backward re-samples it, as the reference does), so nothing
+    of size 9x the activation is kept between forward and backward.
+    x bf16 [N,H,W,C]; w fp32 [1,1,kh*kw*C,Cout] (the OIHW variable viewed as the GEMM operand); offsets bf16."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot):
+        N, H, W, C = x.shape
+        cout = w.shape[-1]
+        assert x.dtype == torch.bfloat16 and offsets.dtype == torch.bfloat16 and x.is_contiguous() and offsets.is_contiguous()
+        assert w.shape == (1, 1, kh * kw * C, cout) and cout % 8 == 0
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        assert offsets.shape == (N, Ho, Wo, dg * 2 * kh * kw), (offsets.shape, (N, Ho, Wo, dg * 2 * kh * kw))
+        d = _desc(N, Ho, Wo, kh * kw * C, cout, 1, 1, 1)
+        need_bwd = w.requires_grad or x.requires_grad or offsets.requires_grad
+        wf, wb = pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
+        y = torch.empty((N, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+        nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0)
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        call("danhip_deform_conv_fwd", ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(offsets), ptr(y), N, H, W, C, cout, kh, kw,
+             stride, dilation, dg, int(relu), ptr(ws), nws, stream())
+        ctx.cfg = (kh, kw, stride, dilation, dg, cout, relu)
+        ctx.b_param, ctx.yslot, ctx.has_bias = b_param, yslot, b is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, offsets, wb, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, offsets, wb, y = ctx.saved_tensors
+        kh, kw, stride, dilation, dg, cout, relu = ctx.cfg
+        N, H, W, C = x.shape
+        g = ctx.yslot.take() if ctx.yslot is not None else None          # slot deliveries arrive ReLU-masked
+        if dy is not None:
+            assert dy.dtype == torch.bfloat16 and dy.shape[-1] == cout
+            dy = dy.contiguous()
+            if relu:
+                dy = dy.clone()
+                call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, dy.numel() // cout, cout, stream())
+            g = dy if g is None else g.add_(dy)
+        if g is None:
+            return (None,) * 12
+        bp = ctx.b_param
+        db_sink = _grad_sink(bp) if bp is not None else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = db_sink if db_sink is not None else torch.zeros(cout, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        doff = torch.empty_like(offsets)
+        dw = torch.zeros((1, 1, kh * kw * C, cout), dtype=torch.float32, device=x.device)
+        nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1)
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        call("danhip_deform_conv_bwd", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout, kh, kw, stride,
+             dilation, dg, 0, ptr(ws), nws, stream())
+        if GRAD_READY_HOOK is not None and bp is not None:
+            GRAD_READY_HOOK(bp)
+        return dx, dw, (None if db_sink is not None else db), doff, None, None, None, None, None, None, None, None
+
+
+def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_group=1, relu=False):
+    """y = act(DeformConvOp(x, filter, offsets) + b); w1x1 = the filter viewed [1,1,kh*kw*C,Cout]."""
+    bp = b if isinstance(b, torch.nn.Parameter) else None
+    track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad)
+    yslot = GradSlot.__new__(GradSlot) if track else None
+    y = _DeformConv.apply(x, w1x1, b, offsets, kh, kw, stride, dilation, deformable_group, relu, bp, yslot)
+    if yslot is not None:
+        yslot.__init__(y, relu)
+        y._dh_slot = yslot
+    return y
+
+
 def deform_sample(x, offsets, kh, kw, stride=1, dilation=1, deformable_group=1):
     return _DeformSample.apply(x, offsets, kh, kw, stride, dilation, deformable_group)

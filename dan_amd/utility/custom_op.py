@@ -44,8 +44,8 @@ def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, defor
     """custom_op.deform_conv_op (utility/custom_op.py:62; DeformConvOp cpp/Deform/deform_conv.cc:51-167) on NHWC tensors:
     x bf16 [N,H,W,C], filter fp32 OIHW [Cout,C,kh,kw] (the reference's variable layout, custom_op.py:134), offset bf16
     [N,Ho,Wo,dg*2*kh*kw].  rates / strides are the reference's 4-vectors [1,1,r,r] / [1,1,s,s].
-    = deformable im2col (HIP gather kernel) followed by the MFMA convolution kernel run as a 1x1 GEMM over the samples;
-    autograd composes DeformConvBackpropOp from the two backward kernels.  `bias` / `relu` fuse the Python-side bias add of
+    = deformable im2col (HIP gather kernel) followed by the MFMA convolution kernel run as a 1x1 GEMM over the samples,
+    both inside danhip_deform_conv_fwd; the backward is danhip_deform_conv_bwd (DeformConvBackpropOp, :170-189).  `bias` / `relu` fuse the Python-side bias add of
     deform_conv_2d (custom_op.py:145) and the activation that follows it into the GEMM epilogue."""
     from .. import ops
     if padding != "SAME":
@@ -60,8 +60,13 @@ def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, defor
     if offset.shape[-1] != 2 * kh * kw * deformable_group:
         raise ValueError("offset must have 2*kh*kw*deformable_group = %d channels (deform_conv.cc:116), got %d"
                          % (2 * kh * kw * deformable_group, offset.shape[-1]))
-    S = ops.deform_sample(x, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group)
     w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
+    if cout % 8 == 0:
+        # DeformConvOp / DeformConvBackpropOp as single library calls (danhip_deform_conv_{fwd,bwd})
+        return ops.deform_conv(x, w1x1, bias, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group,
+                               relu=relu)
+    # ragged Cout: the two halves as separate ops (same kernels; the conv wrapper pads the output-gradient channels)
+    S = ops.deform_sample(x, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group)
     return ops.conv2d(S, w1x1, bias, stride=1, relu=relu)
 
 

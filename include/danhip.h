@@ -205,6 +205,24 @@ int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const u
                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
                              int32_t deformable_group, int accumulate, float* workspace, void* stream);
 
+/* DeformConvOp / DeformConvBackpropOp as single calls (the bindings custom_op.py:62-63 would make): same tensors and attrs as
+ * the TF ops (strides / rates collapsed to one int each, num_groups = 1 as every call site uses), NHWC bf16, all samples in
+ * one batch.  The im2col buffer lives in the workspace for the duration of the call only (deform_conv.cc:497-503
+ * allocate_temp); the backward re-runs im2col as the reference does (:744-748) instead of keeping it from the forward.
+ *   filter : the OIHW variable [Cout,C,kh,kw] viewed as HWIO [1,1,kh*kw*C,Cout] (k = tap*C + c) and packed with
+ *            danhip_pack_conv_weight for the 1x1 descriptor {N,Ho,Wo,kh*kw*C -> Cout}: wf_packed (forward), wb_packed (backward).
+ *   dw     : fp32 [kh*kw*C, Cout] in that same view, ACCUMULATED (zero it first); db fp32 [Cout] accumulated, or NULL.
+ *   dy     : bf16 [N,Ho,Wo,Cout] gradient w.r.t. the op's output (after the caller's ReLU backward if relu was fused), Cout % 8 == 0.
+ *   dx = | += (accumulate_dx) bf16 [N,H,W,C]; d_offsets bf16 like offsets (overwritten). */
+size_t danhip_deform_conv_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int backward);
+int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_packed, const float* bias, const uint16_t* offsets, uint16_t* y,
+                           int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                           int32_t dilation, int32_t deformable_group, int relu, void* workspace, size_t workspace_bytes, void* stream);
+int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy, uint16_t* dx,
+                           uint16_t* d_offsets, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+                           int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, int accumulate_dx,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DynamicAnchorRouting custom op (cpp/ExtraLib/dynamic_anchor_routing.cc:32-65 op def, :188-518 kernel; Python name
  * utility/custom_op.py:52) — same tensors / scalars / attrs as the TF op, plus a leading batch B (the reference maps the op

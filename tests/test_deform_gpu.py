@@ -53,3 +53,36 @@ def test_deform_conv_rejects_bad_arguments(dev):
         custom_op.deform_conv_op(x.to(dev), w.to(dev), off.to(dev)[..., :70].contiguous(), [1, 1, 1, 1], "SAME", [1, 1, 1, 1], 1, 4)
     with pytest.raises(ValueError):
         custom_op.deform_conv_op(x.to(dev), w.to(dev), off.to(dev), [1, 1, 1, 1], "VALID", [1, 1, 1, 1], 1, 4)
+
+
+def test_single_call_entry_points_equal_the_two_halves(dev):
+    """danhip_deform_conv_{fwd,bwd} (DeformConvOp / DeformConvBackpropOp as one call each, workspace-resident im2col) against
+    the separately exposed halves (deform_sample + 1x1 conv ops): bit-identical outputs and gradients, bias + fused ReLU on."""
+    from dan_amd import ops
+    from dan_amd._lib import DanhipError, call, lib, ptr, stream
+    x, w, off = _case(7, 2, 11, 13, 128, 64, 2, 2.0)
+    g = torch.Generator().manual_seed(8)
+    b = torch.randn(64, generator=g)
+    dy = torch.randn((2, 11, 13, 64), generator=g).to(torch.bfloat16).to(dev)
+    res = []
+    for single in (True, False):
+        xd, od = x.to(dev).requires_grad_(True), off.to(dev).requires_grad_(True)
+        w1 = w.permute(2, 3, 1, 0).reshape(1, 1, 9 * 128, 64).contiguous().to(dev).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True)
+        if single:
+            y = ops.deform_conv(xd, w1, bd, od, 3, 3, deformable_group=2, relu=True)
+        else:
+            y = ops.conv2d(ops.deform_sample(xd, od, 3, 3, deformable_group=2), w1, bd, relu=True)
+        y.backward(dy)
+        res.append((y, xd.grad, od.grad, w1.grad, bd.grad))
+    for a, c, name in zip(res[0], res[1], ("y", "dx", "doffset", "dw", "db")):
+        if name in ("dw", "db", "dx"):        # fp32 atomics: order-dependent in the last bits
+            assert torch.allclose(a.float(), c.float(), rtol=1e-2, atol=1e-3 * c.float().abs().max().item()), name
+        else:
+            assert torch.equal(a, c), name
+    need = lib().danhip_deform_conv_workspace_bytes(2, 11, 13, 128, 3, 3, 1, 0)
+    assert need >= 2 * 11 * 13 * 9 * 128 * 2
+    ws = torch.empty(16, dtype=torch.uint8, device=dev)
+    with pytest.raises(DanhipError):
+        call("danhip_deform_conv_fwd", ptr(x.to(dev)), ptr(x.to(dev)), None, ptr(off.to(dev)), ptr(dy), 2, 11, 13, 128, 64, 3, 3, 1, 1, 2, 0, ptr(ws), 16,
+             stream())
