@@ -127,3 +127,39 @@ def test_ragged_cout_relu_backward(shape, dev):
         scale = want.abs().max().item() + 1e-6
         err = (got - want).abs().max().item()
         assert err <= 2.0 ** -6 * scale + 2e-3, (shape, name, err, scale)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(16, 1024, 1024, 64, 64), (8, 1024, 1024, 128, 128)])
+def test_two_gib_activations_batch_equals_its_halves(N, H, W, Cin, Cout, dev):
+    """BASELINE.json configs[3..4] run at 1024x1024: conv1_2 / conv2_2 activations reach 2 GiB (byte offsets beyond 2^31).
+    Size-independent property: a batch-N launch equals its two batch-N/2 launches image for image (fwd, dgrad bit-exact;
+    the weight gradient is their sum up to fp32 atomics order)."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import BF16, call, ptr, stream
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((N, H, W, Cin), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    dy = torch.randn((N, H, W, Cout), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    w = torch.randn((3, 3, Cin, Cout), generator=g, device=dev) / (9 * Cin) ** 0.5
+    b = torch.randn((Cout,), generator=g, device=dev)
+    assert x.numel() * 2 >= 2 ** 31
+
+    def all3(xx, dd):
+        n = xx.shape[0]
+        d = ops._desc(n, H, W, Cin, Cout, 3, 3, 1)
+        wf, wb = ops.pack_conv_weight(d, w, need_bwd=True)
+        y = torch.empty((n, H, W, Cout), dtype=torch.bfloat16, device=dev)
+        dx = torch.empty_like(xx)
+        dw = torch.zeros((3, 3, Cin, Cout), dtype=torch.float32, device=dev)
+        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(xx), ptr(wf), ptr(b), ptr(y), BF16, 1, None, stream())
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dd), ptr(wb), ptr(xx), ptr(dx), 0, stream())
+        call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(xx), ptr(dd), ptr(dw), None, Cin, stream())
+        return y, dx, dw
+
+    y, dx, dw = all3(x, dy)
+    h = N // 2
+    ya, dxa, dwa = all3(x[:h].contiguous(), dy[:h].contiguous())
+    yb, dxb, dwb = all3(x[h:].contiguous(), dy[h:].contiguous())
+    assert torch.equal(y[:h], ya) and torch.equal(y[h:], yb)
+    assert torch.equal(dx[:h], dxa) and torch.equal(dx[h:], dxb)
+    assert ((dw - dwa - dwb).abs().max() / dw.abs().max()).item() < 1e-5

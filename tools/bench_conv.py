@@ -30,6 +30,12 @@ PB = [
     ("cpm160_a", 4, 160, 160, 256, 1024, 3, 1), ("cpm160_b", 4, 160, 160, 1024, 256, 3, 1), ("cpm80_a", 4, 80, 80, 512, 1024, 3, 1),
     ("lat160", 16, 160, 160, 256, 256, 1, 1),
 ]
+# 1024x1024 inputs (BASELINE.json configs[3..4]) and sizes that are multiples of nothing.  NB: --check uses torch's fp32 NCHW conv as the
+# yardstick, which itself breaks down on b1_2 (4.3 GB operand); tests/test_conv_gpu.py covers >= 2 GiB activations by self-consistency
+BIG = [("b1_2", 16, 1024, 1024, 64, 64, 3, 1), ("b2_2", 8, 512, 512, 128, 128, 3, 1), ("b3_2", 8, 256, 256, 256, 256, 3, 1),
+       ("b4_2", 8, 128, 128, 512, 512, 3, 1), ("b5_1", 8, 64, 64, 512, 512, 3, 1), ("bfc6", 8, 32, 32, 512, 1024, 3, 1),
+       ("odd1", 3, 203, 331, 64, 64, 3, 1), ("odd2", 3, 102, 166, 128, 128, 3, 1), ("odd3", 2, 51, 83, 256, 256, 3, 1),
+       ("odd4", 2, 26, 42, 512, 512, 3, 1), ("oddh", 2, 102, 166, 256, 8, 3, 1)]
 SMALL = [("s64", 2, 32, 64, 64, 64, 3, 1), ("s128", 2, 24, 40, 128, 128, 3, 1), ("s256", 1, 48, 48, 256, 256, 3, 1)]
 
 
@@ -107,7 +113,7 @@ def main():
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL}[args.set]
+    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG}[args.set]
     if args.only:
         shapes = [s for s in shapes if s[0] in args.only.split(",")]
     which = args.which.split(",")
