@@ -39,7 +39,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // plain cast: hipcc emits v_
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (two scalar casts cost cvt+cvt+shift+or)
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 // ---------------------------------------------------------------- fast division by a runtime constant
 struct FastDiv {

@@ -27,6 +27,10 @@ const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);
 int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s);
 const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible
 
+// 8 (= 3 padded) -> 64 channel first layer, store-bound (conv_c8.hip); same return convention, forward only.
+int danhip_launch_conv_c8(const ConvArgs& a, hipStream_t s);
+const char* danhip_conv_c8_label(const ConvArgs& a);
+
 // Halo-reuse 3x3/stride-1 weight gradient (conv_wgrad_halo.hip): DANHIP_OK when launched, 1 when not eligible.
 const char* danhip_wgrad_halo_label(const danhip_conv_desc* d);
 int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);

@@ -255,6 +255,8 @@ int launch_cfg(const ConvArgs& a, bool fast, hipStream_t s) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
+  const int c8 = danhip_launch_conv_c8(a, s);          // conv1_1: 3 (padded to 8) -> 64 channels, bound by its output write
+  if (c8 <= 0) return c8;
   const int cr = danhip_launch_conv_c64(a, s);         // 3x3 / stride-1, 64 -> 64 channels: register-resident weights
   if (cr <= 0) return cr;
   const int hr = danhip_launch_conv_halo(a, s);        // 3x3 / stride-1 on large maps: halo-reuse kernel
@@ -386,6 +388,7 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
   if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
   {
     const ConvArgs a = which == 0 ? fwd_args(d) : bwd_args(d);
+    if (which == 0 && danhip_conv_c8_label(a)) return danhip_conv_c8_label(a);
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;
     const char* hl = danhip_conv_halo_label(a, which == 1);

@@ -24,6 +24,8 @@ SHAPES = [
     (2, 16, 32, 256, 8, 3, 3, 1), (1, 32, 32, 64, 6, 3, 3, 1), (3, 24, 64, 128, 16, 3, 3, 1),
     # 64 -> 64 channels: the register-resident-weights kernel (full tiles, ragged edges, > 256 tiles)
     (2, 16, 64, 64, 64, 3, 3, 1), (1, 30, 62, 64, 64, 3, 3, 1), (9, 64, 128, 64, 64, 3, 3, 1),
+    # first layer (3 channels padded to 8 -> 64): the store-bound direct kernel; ragged width, one-pixel-wide, many units
+    (2, 17, 45, 8, 64, 3, 3, 1), (1, 5, 1, 8, 64, 3, 3, 1), (3, 64, 100, 8, 64, 3, 3, 1),
 ]
 
 

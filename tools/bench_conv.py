@@ -21,7 +21,7 @@ from dan_amd._lib import BF16, call, lib, ptr, stream
 
 # (name, N, H, W, Cin, Cout, k, stride)
 S3FD = [
-    ("conv1_2", 16, 640, 640, 64, 64, 3, 1), ("conv2_1", 16, 320, 320, 64, 128, 3, 1), ("conv2_2", 16, 320, 320, 128, 128, 3, 1),
+    ("conv1_1", 16, 640, 640, 8, 64, 3, 1), ("conv1_2", 16, 640, 640, 64, 64, 3, 1), ("conv2_1", 16, 320, 320, 64, 128, 3, 1), ("conv2_2", 16, 320, 320, 128, 128, 3, 1),
     ("conv3_1", 16, 160, 160, 128, 256, 3, 1), ("conv3_2", 16, 160, 160, 256, 256, 3, 1), ("conv4_1", 16, 80, 80, 256, 512, 3, 1),
     ("conv4_2", 16, 80, 80, 512, 512, 3, 1), ("conv5_1", 16, 40, 40, 512, 512, 3, 1), ("fc6", 16, 20, 20, 512, 1024, 3, 1),
     ("fc7", 16, 20, 20, 1024, 1024, 1, 1),
