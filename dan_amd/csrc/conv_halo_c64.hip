@@ -37,7 +37,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int srow = lane >> 3, frow = lane & 15, fq = lane >> 4;
   const int G = gridDim.x;
 
-  // ---- this wave's weights -> registers: A fragment (tap, ks, ct): W[co = wn*32 + ct*16 + frow][k = tap*64 + ks*32 + fq*8 ..]
+  // ---- this wave's weights -> registers: A fragment (tap, ks, ct): W[co][k = tap*64 + ks*32 + fq*8 ..] with the rows of the two
+  //      channel tiles interleaved, co = wn*32 + (frow>>2)*8 + ct*4 + (frow&3): accumulator rows fq*4..+3 of tiles ct = 0, 1 are then
+  //      the 8 CONSECUTIVE channels wn*32 + fq*8 .. +7 of one pixel -> one 16-byte store per lane and pixel
   bf16x8 wr[9][2][NCT];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
-        wr[t][ks][ct] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(wn * 32 + ct * 16 + frow) * a.Kpad + t * 64 + ks * 32 + fq * 8);
+        wr[t][ks][ct] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(wn * 32 + (frow >> 2) * 8 + ct * 4 + (frow & 3)) * a.Kpad + t * 64 + ks * 32 + fq * 8);
 
   auto sp_coords = [&](int sp, int& n, int& y0, int& x0) __attribute__((always_inline)) {
     n = (int)fdiv((unsigned)sp, g.div_txy);
@@ -141,62 +143,52 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     {
       int n, y0, x0;
       sp_coords(sp, n, y0, x0);
-      float4 biasv[NCT];
+      static_assert(NCT == 2, "epilogue packs the two channel tiles of a lane into one 16-byte vector");
+      const int cbase = wn * 32 + fq * 8;                     // this lane's 8 consecutive output channels
+      float bv[8];
 #pragma unroll
-      for (int c = 0; c < NCT; ++c)
-        biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + wn * 32 + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = 0; r < 8; ++r) bv[r] = (!DGRAD && a.bias) ? a.bias[cbase + r] : 0.f;
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * 64 + p * 16 + frow;
         const int y = y0 + t / TW, x = x0 + t % TW;
         const bool ok = y < a.H && x < a.W;
-        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * 64 + (wn * 32 + fq * 4);
-        uint2 in0[NCT], in1[NCT];
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * 64 + cbase;
         if (ok) {
+          float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3], acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
+          if (!DGRAD) {
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) {
-            if (!DGRAD) {
-              if (a.resid) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
-            } else {
-              if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
-              if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+            for (int r = 0; r < 8; ++r) v[r] += bv[r];
+            if (a.relu) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.resid) {
+              const uint4 in = *reinterpret_cast<const uint4*>(a.resid + o0);
+              const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bf2f(rp[r]);
+            }
+          } else {
+            if (a.mask) {
+              const uint4 in = *reinterpret_cast<const uint4*>(a.mask + o0);
+              const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+            }
+            if (a.accumulate) {
+              const uint4 in = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.y) + o0);
+              const bf16_t* op = reinterpret_cast<const bf16_t*>(&in);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bf2f(op[r]);
             }
           }
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          const u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
         }
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (ok) {
-            float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
-            if (!DGRAD) {
-              v[0] += biasv[c].x; v[1] += biasv[c].y; v[2] += biasv[c].z; v[3] += biasv[c].w;
-              if (a.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-              }
-              if (a.resid) {
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0[c]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
-              }
-            } else {
-              if (a.mask) {
-                const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in0[c]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
-              }
-              if (a.accumulate) {
-                const bf16_t* op = reinterpret_cast<const bf16_t*>(&in1[c]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bf2f(op[r]);
-              }
-            }
-            uint2 tt;
-            tt.x = pack2bf(v[0], v[1]);
-            tt.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.y) + o0 + c * 16) = tt;
-          }
-          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int c = 0; c < NCT; ++c) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     if (!has_next) break;
