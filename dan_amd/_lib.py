@@ -17,6 +17,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride")]
 
 
+class PackEntry(ctypes.Structure):
+    _fields_ = [("w_hwio", ctypes.c_void_p), ("wf_packed", ctypes.c_void_p), ("wb_packed", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("kh", "kw", "cin", "cin_real", "cout", "rows_f", "cols_f", "rows_b", "cols_b", "co8", "first_block", "pad_")]
+
+
 P = ctypes.c_void_p
 I32 = ctypes.c_int32
 I64 = ctypes.c_int64
@@ -27,6 +32,8 @@ DESC = ctypes.POINTER(ConvDesc)
 SIGNATURES = {
     "danhip_conv_packed_dims": [DESC, ctypes.c_int, ctypes.POINTER(I64), ctypes.POINTER(I64)],
     "danhip_pack_conv_weight": [DESC, P, I32, P, P, P],
+    "danhip_pack_entry_init": [ctypes.POINTER(PackEntry), DESC, P, I32, P, P, I32, ctypes.POINTER(ctypes.c_int32)],
+    "danhip_pack_conv_weights_batched": [P, I32, I32, P],
     "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],

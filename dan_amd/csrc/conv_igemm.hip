@@ -425,6 +425,71 @@ extern "C" int danhip_pack_conv_weight(const danhip_conv_desc* d, const float* w
   return DANHIP_OK;
 }
 
+namespace {
+// All conv weights of a model in ONE launch (the per-layer launches cost more than the packing itself: 28 per S3FD step,
+// 230 per DAN step).  Block b works on entry e = the last one with first_block[e] <= b (binary search over <= a few hundred).
+__global__ void pack_weights_batched_kernel(const danhip_pack_entry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const danhip_pack_entry e = tab[lo];
+  const int nb = (lo + 1 < n ? tab[lo + 1].first_block : (int)gridDim.x) - e.first_block;
+  const float* __restrict__ w = e.w_hwio;
+  bf16_t* __restrict__ wf = e.wf_packed;
+  bf16_t* __restrict__ wb = e.wb_packed;
+  const long total_f = (long)e.rows_f * e.cols_f, total_b = wb ? (long)e.rows_b * e.cols_b : 0;
+  for (long idx = (long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)nb * blockDim.x) {
+    if (idx < total_f) {
+      const int co = (int)(idx / e.cols_f), k = (int)(idx % e.cols_f);
+      const int tap = k / e.cin, c = k % e.cin;
+      float v = 0.f;
+      if (co < e.cout && tap < e.kh * e.kw && c < e.cin_real) v = w[((long)tap * e.cin_real + c) * e.cout + co];
+      wf[idx] = f2bf(v);
+    } else {
+      const long j = idx - total_f;
+      const int ci = (int)(j / e.cols_b), k = (int)(j % e.cols_b);
+      const int tapf = k / e.co8, co = k % e.co8;
+      float v = 0.f;
+      if (ci < e.cin_real && tapf < e.kh * e.kw && co < e.cout) {
+        const int fi = tapf / e.kw, fj = tapf % e.kw;
+        const int tap = (e.kh - 1 - fi) * e.kw + (e.kw - 1 - fj);
+        v = w[((long)tap * e.cin_real + ci) * e.cout + co];
+      }
+      wb[j] = f2bf(v);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real,
+                                      uint16_t* wf_packed, uint16_t* wb_packed, int32_t first_block, int32_t* blocks) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(e && w_hwio && wf_packed && blocks, DANHIP_EINVAL, "pack_entry_init: null pointer");
+  DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "pack_entry_init: cin_real=%d out of range", cin_real);
+  int64_t rf, cf, rb, cb;
+  danhip_conv_packed_dims(d, 0, &rf, &cf);
+  danhip_conv_packed_dims(d, 1, &rb, &cb);
+  e->w_hwio = w_hwio; e->wf_packed = wf_packed; e->wb_packed = wb_packed;
+  e->kh = d->kh; e->kw = d->kw; e->cin = d->Cin; e->cin_real = cin_real; e->cout = d->Cout;
+  e->rows_f = (int)rf; e->cols_f = (int)cf; e->rows_b = (int)rb; e->cols_b = (int)cb; e->co8 = round_up(d->Cout, 8);
+  e->first_block = first_block;
+  const long total = rf * cf + (wb_packed ? rb * cb : 0);
+  long nb = (total + 2047) / 2048;                      // 8 elements per thread
+  if (nb > 64) nb = 64;
+  *blocks = (int)nb;
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_dev, int32_t n, int32_t total_blocks, void* stream) {
+  DH_REQUIRE(table_dev && n > 0 && total_blocks > 0, DANHIP_EINVAL, "pack_conv_weights_batched: bad arguments");
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
 extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, void* y,
                                  int out_dtype, int relu, const uint16_t* residual, void* stream) {
   int rc = check_desc(d);

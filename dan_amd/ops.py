@@ -39,6 +39,87 @@ def pack_conv_weight(d, w_hwio, need_bwd=True):
     return wf, wb
 
 
+# ---- packed-weight cache.  A conv weight that is an nn.Parameter keeps its two bf16 packings in persistent buffers; they are
+# reused while the parameter is unchanged (inference: no packing at all) and refreshed for ALL parameters by one launch
+# after an optimizer update (repack_all).  "Unchanged" = same WEIGHT_EPOCH (bumped by the fused optimizer, which writes
+# through raw pointers), same tensor version (in-place torch ops) and same storage.
+WEIGHT_EPOCH = 0
+_PACKED = {}
+_PACK_TABLE = None
+
+
+class _Packed(object):
+    __slots__ = ("ref", "key", "d", "wf", "wb", "stamp")
+
+
+def _stamp(p):
+    return (WEIGHT_EPOCH, p._version, p.data_ptr())
+
+
+def _drop_packed(pid):
+    global _PACK_TABLE
+    _PACKED.pop(pid, None)
+    _PACK_TABLE = None
+
+
+def packed_weights(d, w, w_param, need_bwd):
+    """-> (wf, wb) for conv descriptor d; cached per Parameter, packed on the spot for plain tensors."""
+    global _PACK_TABLE
+    if w_param is None:
+        return pack_conv_weight(d, w.detach(), need_bwd=need_bwd)
+    import weakref
+    key = (d.kh, d.kw, d.Cin, d.Cout, w.shape[2])
+    pid = id(w_param)
+    e = _PACKED.get(pid)
+    if e is None or e.key != key or e.ref() is not w_param:
+        e = _Packed()
+        e.ref = weakref.ref(w_param, lambda _r, pid=pid: _drop_packed(pid))
+        e.key, e.stamp, e.wb = key, None, None
+        e.d = _desc(1, 8, 8, d.Cin, d.Cout, d.kh, d.kw, 1)           # packing depends on the kernel / channel dims only
+        rf, cf = packed_dims(e.d, 0)
+        e.wf = torch.empty((rf, cf), dtype=torch.bfloat16, device=w.device)
+        _PACKED[pid] = e
+        _PACK_TABLE = None
+    if need_bwd and e.wb is None:
+        rb, cb = packed_dims(e.d, 1)
+        e.wb = torch.empty((rb, cb), dtype=torch.bfloat16, device=w.device)
+        e.stamp = None
+        _PACK_TABLE = None
+    st = _stamp(w_param)
+    if e.stamp != st:
+        wd = w_param.detach()
+        assert wd.dtype == torch.float32 and wd.is_contiguous()
+        call("danhip_pack_conv_weight", ctypes.byref(e.d), ptr(wd), wd.shape[2], ptr(e.wf), ptr(e.wb), stream())
+        e.stamp = st
+    return e.wf, (e.wb if need_bwd else None)
+
+
+def repack_all():
+    """One launch refreshing every cached packing (call after the optimizer changed the parameters)."""
+    global _PACK_TABLE
+    entries = [(e, e.ref()) for e in _PACKED.values()]
+    entries = [(e, p) for e, p in entries if p is not None]
+    if not entries:
+        return
+    if _PACK_TABLE is None or _PACK_TABLE[0] != len(entries):
+        arr = (_lib.PackEntry * len(entries))()
+        first = 0
+        nb = ctypes.c_int32()
+        for i, (e, p) in enumerate(entries):
+            call("danhip_pack_entry_init", ctypes.byref(arr[i]), ctypes.byref(e.d), ptr(p.detach()), p.shape[2], ptr(e.wf), ptr(e.wb), first,
+                 ctypes.byref(nb))
+            first += nb.value
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        _PACK_TABLE = (len(entries), host.to(entries[0][1].device), first, [id(p) for _, p in entries], [p.data_ptr() for _, p in entries])
+    n, tab, blocks, ids, ptrs = _PACK_TABLE
+    if ids != [id(p) for _, p in entries] or ptrs != [p.data_ptr() for _, p in entries]:
+        _PACK_TABLE = None
+        return repack_all()
+    call("danhip_pack_conv_weights_batched", ptr(tab), n, blocks, stream())
+    for e, p in entries:
+        e.stamp = _stamp(p)
+
+
 def _grad_sink(p):
     return getattr(p, "_danhip_grad", None)
 
@@ -127,7 +208,7 @@ class _Conv2d(torch.autograd.Function):
         assert C % 8 == 0 and cin_real <= C
         d = _desc(N, H, W, C, cout, kh, kw, stride)
         need_bwd = w.requires_grad or x.requires_grad
-        wf, wb = pack_conv_weight(d, w.detach(), need_bwd=need_bwd)
+        wf, wb = packed_weights(d, w, w_param, need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
         e0 = _prof_begin()
         call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),

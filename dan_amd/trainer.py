@@ -70,6 +70,9 @@ class FlatParams(object):
         self.l2.zero_()
         call("danhip_sgd_momentum_flat", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc), len(self.names),
              self.total, float(lr), float(momentum), float(grad_scale), ptr(self.l2), stream())
+        from . import ops
+        ops.WEIGHT_EPOCH += 1          # the kernel wrote the parameters through raw pointers: cached bf16 packings are stale
+        ops.repack_all()               # ... and are refreshed by one launch for all conv weights
 
 
 class GradBuckets(object):

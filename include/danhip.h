@@ -59,6 +59,19 @@ int danhip_conv_packed_dims(const danhip_conv_desc* d, int which, int64_t* rows,
 int danhip_pack_conv_weight(const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real,
                             uint16_t* wf_packed, uint16_t* wb_packed, void* stream);
 
+/* All conv weights of a model packed by ONE launch (after each optimizer update).  The caller fills a host array of
+ * entries with danhip_pack_entry_init (which also returns how many workgroups the entry gets; first_block is the running
+ * sum), copies it to the device and passes it here with the total.  Same packing as danhip_pack_conv_weight. */
+typedef struct {
+  const float* w_hwio;
+  uint16_t* wf_packed;
+  uint16_t* wb_packed;       /* NULL: forward packing only */
+  int32_t kh, kw, cin, cin_real, cout, rows_f, cols_f, rows_b, cols_b, co8, first_block, pad_;
+} danhip_pack_entry;
+int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real,
+                           uint16_t* wf_packed, uint16_t* wb_packed, int32_t first_block, int32_t* blocks);
+int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_dev, int32_t n, int32_t total_blocks, void* stream);
+
 /* y = act(conv(x, w) + bias).  x bf16; y bf16 (out_dtype=DANHIP_BF16) or fp32; bias fp32[Cout] or NULL.
  * relu: 0/1.  residual: optional bf16 tensor of y's shape added AFTER the activation (DAN context modules,
  * net/danet.py:912-918) or NULL. */
