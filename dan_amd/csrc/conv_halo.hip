@@ -81,6 +81,47 @@ __device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc
   *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.y) + o) = t;
 }
 
+// 8 consecutive channels of one pixel (two interleaved channel tiles): 16-byte mask / residual / old-value reads, one
+// 16-byte store (fp32 output: two float4 stores).
+template <bool DGRAD>
+__device__ __forceinline__ void halo_finish8(const ConvArgs& a, const f32x4& lo, const f32x4& hi, const float (&b)[8], const uint4& in0,
+                                             const uint4& in1, size_t o) {
+  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  if (!DGRAD) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += b[r];
+    if (a.relu) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (a.out_f32) {
+      float* y = reinterpret_cast<float*>(a.y) + o;
+      *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(y + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      return;
+    }
+    if (a.resid) {
+      const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bf2f(rp[r]);
+    }
+  } else {
+    if (a.mask) {
+      const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in0);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
+    }
+    if (a.accumulate) {
+      const bf16_t* op = reinterpret_cast<const bf16_t*>(&in1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bf2f(op[r]);
+    }
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o) = t;      // (non-temporal stores measured neutral here)
+}
+
 // 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out
 // of range (0xFFFFFFFF) writes ZEROS to its LDS slot.
 __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
@@ -196,12 +237,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int w_v = blockIdx.x, w_cc = 0, w_step = 0, w_idx = 0;
   int w_sp, w_nb;
   bool w_ok = decode(w_v, w_sp, w_nb);
+  // Weight-tile swizzle key of row r (chunk c of row r sits at position c ^ key): the 8 rows one ds_read_b128 group touches
+  // must have distinct keys.  Plain kernels interleave pairs of channel tiles (IL: lane row frow of tile c is output channel
+  // (c>>1)*32 + (frow>>2)*8 + (c&1)*4 + (frow&3), so a lane owns 8 consecutive channels -> 16-byte epilogue accesses) and
+  // read rows {0-3, 8-11 | 16-19, 24-27} (+4 for odd tiles): key = (r & 3) | ((r >> 3) & 1) << 2.  Thin heads read rows 0..15.
+  constexpr bool IL = (NCU == 0);
+  auto wkey = [](int r) __attribute__((always_inline)) -> int { return IL ? ((r & 3) | (((r >> 3) & 1) << 2)) : (r & 7); };
   unsigned wlane[WL];                              // per piece: ((row in BN) * Kpad + tap_in_step * C) * 2 + swizzled chunk
 #pragma unroll
   for (int k = 0; k < WL; ++k) {
     const int pz = wave * WL + k;                  // piece inside the stage
     const int tin = pz / (BN / 8), rp = pz % (BN / 8);
-    wlane[k] = (unsigned)((rp * 8 + srow) * a.Kpad + tin * a.C) * 2u + (unsigned)(((lane & 7) ^ srow) << 4);
+    wlane[k] = (unsigned)((rp * 8 + srow) * a.Kpad + tin * a.C) * 2u + (unsigned)(((lane & 7) ^ wkey(rp * 8 + srow)) << 4);
   }
   auto issue_w = [&]() __attribute__((always_inline)) {
     char* dst = smem + WRING + (w_idx % NSW) * WBYTES;
@@ -221,7 +268,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   // ---- compute-side per-lane constants --------------------------------------------------------------------------
   const int frow = lane & 15, fq = lane >> 4;
-  const int offW = WRING + (wn * TC + frow) * 128 + ((fq ^ (frow & 7)) << 4);     // + stage*WBYTES + tap*TAPBYTES + c*2048, ^ ks*64
+  const int wrow0 = IL ? ((frow >> 2) * 8 + (frow & 3)) : frow;                   // lane's row inside the first tile (pair)
+  const int offW = WRING + (wn * TC + wrow0) * 128 + ((fq ^ wkey(wrow0)) << 4);   // + stage*WBYTES + tap*TAPBYTES + tile offset, ^ ks*64
   int pxaddr[3][NPT];                              // patch-buffer-0 byte address of fragment p at tap column j, k-slice 0
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
@@ -249,7 +297,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int ks = 0; ks < 2; ++ks) {
       const int wb = (ks ? (wbase ^ 64) : wbase) + TS * TAPBYTES;
 #pragma unroll
-      for (int c = 0; c < NCT; ++c) wf[SLOT][ks][c] = *reinterpret_cast<const bf16x8*>(smem + wb + c * 2048);
+      for (int c = 0; c < NCT; ++c) wf[SLOT][ks][c] = *reinterpret_cast<const bf16x8*>(smem + wb + (IL ? (c >> 1) * 4096 + (c & 1) * 512 : c * 2048));
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int pa = (ks ? (pxaddr[TJ][p] ^ 64) : pxaddr[TJ][p]) + pofs;
@@ -303,7 +351,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto epilogue = [&]() __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(c_sp, n, y0, x0);
-    if (NCU) {                                     // thin head: Cout < 64, possibly not a multiple of 4; forward only
+    if constexpr (NCU != 0) {                      // thin head: Cout < 64, possibly not a multiple of 4; forward only
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * TP + p * 16 + frow;
@@ -326,32 +374,37 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
       }
     } else {
-      float4 biasv[NCT];                           // this lane's bias quads (one wait for all of them)
+      static_assert(NCU != 0 || NCT % 2 == 0, "channel tiles are stored in interleaved pairs");
+      constexpr int NPAIR = NCT / 2 > 0 ? NCT / 2 : 1;
+      const int cb = c_nb * BN + wn * TC + fq * 8;    // this lane's 8 consecutive channels of pair 0 (+32 per pair)
+      float bv[NPAIR][8];
 #pragma unroll
-      for (int c = 0; c < NCT; ++c)
-        biasv[c] = (!DGRAD && a.bias) ? *reinterpret_cast<const float4*>(a.bias + c_nb * BN + wn * TC + c * 16 + fq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && a.bias) ? a.bias[cb + q * 32 + r] : 0.f;
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * TP + p * 16 + frow;
         const int y = y0 + t / TW, x = x0 + t % TW;
         const bool ok = y < a.H && x < a.W;
-        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + (c_nb * BN + wn * TC + fq * 4);
-        uint2 in0[NCT], in1[NCT];                  // every read-modify input is issued before the first store
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + cb;
+        uint4 in0[NPAIR], in1[NPAIR];              // every read-modify input is issued before the first store
         if (ok) {
 #pragma unroll
-          for (int c = 0; c < NCT; ++c) {
+          for (int q = 0; q < NPAIR; ++q) {
             if (!DGRAD) {
-              if (a.resid && !a.out_f32) in0[c] = *reinterpret_cast<const uint2*>(a.resid + o0 + c * 16);
+              if (a.resid && !a.out_f32) in0[q] = *reinterpret_cast<const uint4*>(a.resid + o0 + q * 32);
             } else {
-              if (a.mask) in0[c] = *reinterpret_cast<const uint2*>(a.mask + o0 + c * 16);
-              if (a.accumulate) in1[c] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + c * 16);
+              if (a.mask) in0[q] = *reinterpret_cast<const uint4*>(a.mask + o0 + q * 32);
+              if (a.accumulate) in1[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + q * 32);
             }
           }
         }
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (ok) halo_finish4<DGRAD>(a, acc[c][p], biasv[c], in0[c], in1[c], o0 + c * 16);
-          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NPAIR; ++q) {
+          if (ok) halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
+          acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
