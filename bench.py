@@ -4,6 +4,7 @@
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (DANHIP_DTYPE=fp16 python bench.py ... runs the fp16 build of the library; the default and the headline are bf16)
 
 One "step" = one optimisation step on a synthetic batch of 16 images per GPU (BASELINE.json configs[1]); inputs
 (uint8 images, encoded anchor targets) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
@@ -77,7 +78,7 @@ def main():
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
 
-    from dan_amd import ops, synthetic
+    from dan_amd import _lib, ops, synthetic
     from dan_amd.trainer import init_distributed
     from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
 
@@ -178,8 +179,8 @@ def main():
         out = {
             "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s, %dx%d bf16 training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, B),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _lib.ACT_NAME, "data": "synthetic",
+            "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,

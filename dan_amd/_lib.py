@@ -8,9 +8,14 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdanhip.so")
+# 16-bit activation type of this process: DANHIP_DTYPE=bf16 (default) | fp16 selects the library build (include/danhip.h)
+ACT_NAME = os.environ.get("DANHIP_DTYPE", "bf16").lower()
+if ACT_NAME not in ("bf16", "fp16"):
+    raise ValueError("DANHIP_DTYPE must be bf16 or fp16, got %r" % ACT_NAME)
+ACT_DTYPE = torch.float16 if ACT_NAME == "fp16" else torch.bfloat16
+SO_PATH = os.path.join(_HERE, "libdanhip_f16.so" if ACT_NAME == "fp16" else "libdanhip.so")
 
-F32, BF16 = 0, 1
+F32, BF16 = 0, 1      # BF16 = "the build's 16-bit activation type" in out_dtype arguments
 
 
 class ConvDesc(ctypes.Structure):
@@ -92,6 +97,9 @@ def lib():
         L.danhip_last_error.restype = ctypes.c_char_p
         L.danhip_last_error.argtypes = []
         L.danhip_version.restype = ctypes.c_int
+        L.danhip_act_dtype.restype = ctypes.c_int
+        if L.danhip_act_dtype() != (2 if ACT_NAME == "fp16" else 1):
+            raise DanhipError("%s was built for another activation dtype than DANHIP_DTYPE=%s" % (SO_PATH, ACT_NAME))
         L.danhip_match_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_conv_kernel_label.restype = ctypes.c_char_p
         L.danhip_conv_kernel_label.argtypes = [DESC, ctypes.c_int]

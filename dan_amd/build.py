@@ -1,4 +1,5 @@
-"""Builds libdanhip.so (all HIP kernels + the C ABI) in-tree for gfx950 with hipcc.
+"""Builds libdanhip.so (bf16 activations) and libdanhip_f16.so (fp16 activations, -DDANHIP_FP16) — all HIP kernels + the
+C ABI — in-tree for gfx950 with hipcc.
 
     python -m dan_amd.build [--force]
 
@@ -13,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdanhip.so")
+OUT_F16 = os.path.join(HERE, "libdanhip_f16.so")
 OBJ = os.path.join(CSRC, "_obj")
 FLAGS = (["-DDANHIP_HALO_EXPERIMENTS"] if os.environ.get("DANHIP_HALO_EXPERIMENTS") else []) + ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
@@ -21,20 +23,20 @@ def _newer(a, deps):
     return not os.path.exists(a) or any(os.path.getmtime(d) > os.path.getmtime(a) for d in deps)
 
 
-def build(force=False, verbose=False):
+def _build_variant(out, objdir, defines, force, verbose):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "danhip.h")]
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s) + ".o")
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
         if force or _newer(o, [s] + hdrs):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
         extra = ["-ffp-contract=off"] if s.endswith("_exact.hip") else []   # bit-exact index/box kernels: no FMA contraction
-        cmd = ["hipcc"] + FLAGS + extra + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        cmd = ["hipcc"] + FLAGS + defines + extra + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr))
@@ -44,12 +46,18 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, os.path.basename(s) + ".o") for s in srcs]
-    if force or jobs or _newer(OUT, objs):
-        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs, capture_output=True, text=True)
+    objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in srcs]
+    if force or jobs or _newer(out, objs):
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
-    return OUT
+    return out
+
+
+def build(force=False, verbose=False):
+    out = _build_variant(OUT, OBJ, [], force, verbose)
+    _build_variant(OUT_F16, OBJ + "_f16", ["-DDANHIP_FP16"], force, verbose)
+    return out
 
 
 if __name__ == "__main__":

@@ -15,3 +15,10 @@ void danhip_set_error(const char* fmt, ...) {
 
 extern "C" const char* danhip_last_error(void) { return g_err; }
 extern "C" int danhip_version(void) { return 1; }
+extern "C" int danhip_act_dtype(void) {
+#ifdef DANHIP_FP16
+  return DANHIP_F16;
+#else
+  return DANHIP_BF16;
+#endif
+}

@@ -5,8 +5,17 @@
 
 #include "../../include/danhip.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// 16-bit activation storage type of this build: bf16 (libdanhip.so, default) or fp16 (libdanhip_f16.so, -DDANHIP_FP16;
+// BASELINE.json configs[4]).  The historical names bf16_t / bf2f / f2bf / pack2bf / bf16x8 mean "the build's 16-bit type".
+#ifdef DANHIP_FP16
+typedef _Float16 act16_t;
+#define DH_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
+typedef __bf16 act16_t;
+#define DH_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) act16_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) act16_t bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -33,15 +42,27 @@ void danhip_set_error(const char* fmt, ...);
     }                                                                            \
   } while (0)
 
-// ---------------------------------------------------------------- bf16 <-> f32
+// ---------------------------------------------------------------- 16-bit activation <-> f32
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) act16_t bf16x2;
+#ifdef DANHIP_FP16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// (w & 0xffff) and (w >> 16) halves of a packed pair
+__device__ __forceinline__ void unpack2bf(unsigned w, float& lo, float& hi) {
+  const bf16x2 h = __builtin_bit_cast(bf16x2, w);
+  lo = (float)h[0]; hi = (float)h[1];
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-safe)
-  __bf16 b = (__bf16)f;
+__device__ __forceinline__ void unpack2bf(unsigned w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
+}
+#endif
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even (bf16: v_cvt_pk_bf16_f32, NaN-safe; fp16: v_cvt_f16_f32)
+  const act16_t b = (act16_t)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (two scalar casts cost cvt+cvt+shift+or)
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {  // one packed convert (two scalar casts cost cvt+cvt+shift+or)
   const f32x2 v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }

@@ -84,11 +84,11 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16x8 f0 = __builtin_bit_cast(bf16x8, b0), f1 = __builtin_bit_cast(bf16x8, b1), f2 = __builtin_bit_cast(bf16x8, b2);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[m][0], f0, acc[m], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][0], f0, acc[m]);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[m][1], f1, acc[m], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][1], f1, acc[m]);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[m][2], f2, acc[m], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][2], f2, acc[m]);
     if (t.x0 + px < a.W) {
       bf16_t* yo = reinterpret_cast<bf16_t*>(a.y) + ((size_t)(unsigned)(t.base + px)) * 64 + q * 8;
 #pragma unroll

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int p = 0; p < NPT; ++p)
-          acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SLOT][ks][c], xf[SLOT][ks][p], acc[c][p], 0, 0, 0);
+          acc[c][p] = DH_MFMA_16x16x32(wf[SLOT][ks][c], xf[SLOT][ks][p], acc[c][p]);
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;

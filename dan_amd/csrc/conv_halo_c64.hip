@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int p = 0; p < NPT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c], x[p], acc[c][p], 0, 0, 0);
+      for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(w[c], x[p], acc[c][p]);
   };
 
   int sp = blockIdx.x;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int p = 0; p < NPT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[p], acc[c][p], 0, 0, 0);
+        for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(wf[c], xf[p], acc[c][p]);
     }
   }
 
@@ -495,6 +495,7 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   int rc = check_desc(d);
   if (rc) return rc;
   DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd: null pointer");
+  if (out_dtype == DANHIP_F16 && danhip_act_dtype() == DANHIP_F16) out_dtype = DANHIP_BF16;      // alias for "the build's 16-bit type"
   DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
   DH_REQUIRE(!(residual && out_dtype == DANHIP_F32), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
   ConvArgs a = fwd_args(d);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   for (int o = 0; o < NO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = (act16_t)1.0f;
 
   stage(kt_begin, 0);
   for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) acc[i][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf[o], acc[i][o], 0, 0, 0);
+        for (int o = 0; o < NO; ++o) acc[i][o] = DH_MFMA_16x16x32(xf[i], yf[o], acc[i][o]);
       if (do_bias) {
 #pragma unroll
-        for (int o = 0; o < NO; ++o) accb[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[o], accb[o], 0, 0, 0);
+        for (int o = 0; o < NO; ++o) accb[o] = DH_MFMA_16x16x32(ones, yf[o], accb[o]);
       }
     }
   }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto mma_tap = [&](int t, const bf16x8& x) __attribute__((always_inline)) {
 #pragma unroll
-    for (int o = 0; o < NO; ++o) acc[t][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, yf[o], acc[t][o], 0, 0, 0);
+    for (int o = 0; o < NO; ++o) acc[t][o] = DH_MFMA_16x16x32(x, yf[o], acc[t][o]);
   };
   auto mma = [&](auto rc) __attribute__((always_inline)) {              // MFMA phase of K-step R
     constexpr int R = decltype(rc)::value;

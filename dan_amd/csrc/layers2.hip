@@ -9,7 +9,7 @@ namespace {
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
   const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  for (int i = 0; i < 4; ++i) unpack2bf(w[i], f[2 * i], f[2 * i + 1]);
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 u;

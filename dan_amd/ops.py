@@ -1,5 +1,5 @@
 """torch.autograd.Function wrappers over the libdanhip C ABI (device memory / streams / autograd are PyTorch
-plumbing; all arithmetic happens in the HIP kernels).  Activations are NHWC torch.bfloat16 tensors.
+plumbing; all arithmetic happens in the HIP kernels).  Activations are NHWC 16-bit tensors (bf16, or fp16 with DANHIP_DTYPE=fp16: _lib.ACT_DTYPE).
 
 Gradient sinks: when a parameter carries a `_danhip_grad` tensor (a view into the trainer's flat fp32 gradient
 buffer) the backward kernels accumulate straight into it and return None to autograd; otherwise a fresh
@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, ConvDesc, call, ptr, stream
+from ._lib import ACT_DTYPE as ACT, BF16, F32, ConvDesc, call, ptr, stream
 
 
 def _desc(N, H, W, Cin, Cout, kh, kw, stride):
@@ -30,11 +30,11 @@ def pack_conv_weight(d, w_hwio, need_bwd=True):
     """fp32 HWIO [kh,kw,cin_real,Cout] -> (wf bf16 [Cout_pad,Kpad], wb bf16 [Cin_pad,Kpad_b] or None)."""
     assert w_hwio.dtype == torch.float32 and w_hwio.is_contiguous()
     rf, cf = packed_dims(d, 0)
-    wf = torch.empty((rf, cf), dtype=torch.bfloat16, device=w_hwio.device)
+    wf = torch.empty((rf, cf), dtype=ACT, device=w_hwio.device)
     wb = None
     if need_bwd:
         rb, cb = packed_dims(d, 1)
-        wb = torch.empty((rb, cb), dtype=torch.bfloat16, device=w_hwio.device)
+        wb = torch.empty((rb, cb), dtype=ACT, device=w_hwio.device)
     call("danhip_pack_conv_weight", ctypes.byref(d), ptr(w_hwio), w_hwio.shape[2], ptr(wf), ptr(wb), stream())
     return wf, wb
 
@@ -77,12 +77,12 @@ def packed_weights(d, w, w_param, need_bwd):
         e.key, e.stamp, e.wb = key, None, None
         e.d = _desc(1, 8, 8, d.Cin, d.Cout, d.kh, d.kw, 1)           # packing depends on the kernel / channel dims only
         rf, cf = packed_dims(e.d, 0)
-        e.wf = torch.empty((rf, cf), dtype=torch.bfloat16, device=w.device)
+        e.wf = torch.empty((rf, cf), dtype=ACT, device=w.device)
         _PACKED[pid] = e
         _PACK_TABLE = None
     if need_bwd and e.wb is None:
         rb, cb = packed_dims(e.d, 1)
-        e.wb = torch.empty((rb, cb), dtype=torch.bfloat16, device=w.device)
+        e.wb = torch.empty((rb, cb), dtype=ACT, device=w.device)
         e.stamp = None
         _PACK_TABLE = None
     st = _stamp(w_param)
@@ -204,12 +204,12 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
-        assert x.dtype == torch.bfloat16 and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
+        assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
         assert C % 8 == 0 and cin_real <= C
         d = _desc(N, H, W, C, cout, kh, kw, stride)
         need_bwd = w.requires_grad or x.requires_grad
         wf, wb = packed_weights(d, w, w_param, need_bwd)
-        y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+        y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
         e0 = _prof_begin()
         call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
              F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
@@ -241,10 +241,10 @@ class _Conv2d(torch.autograd.Function):
         if dy is not None:
             if ctx.has_res:
                 dres = dy                                # residual is added after the activation
-            if dy.dtype != torch.bfloat16 or dy.shape[-1] != co8:
+            if dy.dtype != ACT or dy.shape[-1] != co8:
                 # fp32 / unpadded upstream gradient (head convs): cast + pad channels to a multiple of 8
                 src = dy.contiguous().to(torch.float32)
-                dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=torch.bfloat16, device=dy.device)
+                dyp = torch.empty((d.N, d.Ho, d.Wo, co8), dtype=ACT, device=dy.device)
                 # ragged Cout: y has Cout (not co8) channels per row, so its ReLU mask is applied here, on the unpadded layout
                 call("danhip_cast_pad_f32_to_bf16", ptr(src), ptr(y) if (ctx.relu and d.Cout != co8) else None, ptr(dyp), M, d.Cout, co8, stream())
                 dy, owned = dyp, True
@@ -477,7 +477,7 @@ def preprocess_u8(img_rgb_u8):
     """uint8 RGB [N,H,W,3] -> bf16 [N,H,W,8] (BGR - mean, zero padded): dan_preprocessing.py:55-57,755-758."""
     assert img_rgb_u8.dtype == torch.uint8 and img_rgb_u8.shape[-1] == 3
     N, H, W, _ = img_rgb_u8.shape
-    out = torch.empty((N, H, W, 8), dtype=torch.bfloat16, device=img_rgb_u8.device)
+    out = torch.empty((N, H, W, 8), dtype=ACT, device=img_rgb_u8.device)
     call("danhip_preprocess_u8", ptr(img_rgb_u8.contiguous()), ptr(out), N * H * W, stream())
     return out
 
@@ -486,7 +486,7 @@ def cast_pad(x_f32, c_dst):
     """fp32 [..., C] -> bf16 [..., c_dst] zero padded."""
     shp = x_f32.shape
     rows = x_f32.numel() // shp[-1]
-    out = torch.empty(shp[:-1] + (c_dst,), dtype=torch.bfloat16, device=x_f32.device)
+    out = torch.empty(shp[:-1] + (c_dst,), dtype=ACT, device=x_f32.device)
     call("danhip_cast_pad_f32_to_bf16", ptr(x_f32.contiguous()), None, ptr(out), rows, shp[-1], c_dst, stream())
     return out
 
@@ -499,8 +499,8 @@ class _ResizeAdd(torch.autograd.Function):
     def forward(ctx, up, lateral, size):
         N, Hi, Wi, C = up.shape
         Ho, Wo = (lateral.shape[1], lateral.shape[2]) if lateral is not None else size
-        assert up.dtype == torch.bfloat16 and up.is_contiguous() and C % 8 == 0
-        out = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=up.device)
+        assert up.dtype == ACT and up.is_contiguous() and C % 8 == 0
+        out = torch.empty((N, Ho, Wo, C), dtype=ACT, device=up.device)
         call("danhip_resize_bilinear_add_fwd", ptr(up), ptr(lateral.contiguous()) if lateral is not None else None, ptr(out), N, Hi, Wi, Ho, Wo, C, stream())
         ctx.dims = (N, Hi, Wi, Ho, Wo, C)
         ctx.has_lat = lateral is not None
@@ -512,7 +512,7 @@ class _ResizeAdd(torch.autograd.Function):
         dout = dout.contiguous()
         dup = None
         if ctx.needs_input_grad[0]:
-            dup = torch.empty((N, Hi, Wi, C), dtype=torch.bfloat16, device=dout.device)
+            dup = torch.empty((N, Hi, Wi, C), dtype=ACT, device=dout.device)
             call("danhip_resize_bilinear_add_bwd", ptr(dout), ptr(dup), N, Hi, Wi, Ho, Wo, C, 0, stream())
         return dup, (dout if ctx.has_lat else None), None
 
@@ -535,13 +535,13 @@ class _AvgPool2x2S1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C = ctx.dims
-        dx = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+        dx = torch.empty((N, H, W, C), dtype=ACT, device=dy.device)
         call("danhip_avgpool2x2s1_same_bwd", ptr(dy.contiguous()), ptr(dx), N, H, W, C, 0, stream())
         return dx
 
 
 def avg_pool_2x2_s1(x):
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 8 == 0
+    assert x.dtype == ACT and x.is_contiguous() and x.shape[-1] % 8 == 0
     return _AvgPool2x2S1.apply(x)
 
 
@@ -598,9 +598,9 @@ class _DeformSample(torch.autograd.Function):
     def forward(ctx, x, offsets, kh, kw, stride, dilation, dg):
         N, H, W, C = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
-        assert x.dtype == torch.bfloat16 and offsets.dtype == torch.bfloat16 and x.is_contiguous() and offsets.is_contiguous()
+        assert x.dtype == ACT and offsets.dtype == ACT and x.is_contiguous() and offsets.is_contiguous()
         assert offsets.shape == (N, Ho, Wo, dg * 2 * kh * kw), (offsets.shape, (N, Ho, Wo, dg * 2 * kh * kw))
-        S = torch.empty((N, Ho, Wo, kh * kw * C), dtype=torch.bfloat16, device=x.device)
+        S = torch.empty((N, Ho, Wo, kh * kw * C), dtype=ACT, device=x.device)
         call("danhip_deform_sample_fwd", ptr(x), ptr(offsets), ptr(S), N, H, W, C, kh, kw, stride, dilation, dg, stream())
         ctx.save_for_backward(x, offsets)
         ctx.cfg = (kh, kw, stride, dilation, dg)
@@ -629,14 +629,14 @@ class _DeformConv(torch.autograd.Function):
     def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot):
         N, H, W, C = x.shape
         cout = w.shape[-1]
-        assert x.dtype == torch.bfloat16 and offsets.dtype == torch.bfloat16 and x.is_contiguous() and offsets.is_contiguous()
+        assert x.dtype == ACT and offsets.dtype == ACT and x.is_contiguous() and offsets.is_contiguous()
         assert w.shape == (1, 1, kh * kw * C, cout) and cout % 8 == 0
         Ho, Wo = -(-H // stride), -(-W // stride)
         assert offsets.shape == (N, Ho, Wo, dg * 2 * kh * kw), (offsets.shape, (N, Ho, Wo, dg * 2 * kh * kw))
         d = _desc(N, Ho, Wo, kh * kw * C, cout, 1, 1, 1)
         need_bwd = w.requires_grad or x.requires_grad or offsets.requires_grad
         wf, wb = pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
-        y = torch.empty((N, Ho, Wo, cout), dtype=torch.bfloat16, device=x.device)
+        y = torch.empty((N, Ho, Wo, cout), dtype=ACT, device=x.device)
         nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         call("danhip_deform_conv_fwd", ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(offsets), ptr(y), N, H, W, C, cout, kh, kw,
@@ -654,7 +654,7 @@ class _DeformConv(torch.autograd.Function):
         N, H, W, C = x.shape
         g = ctx.yslot.take() if ctx.yslot is not None else None          # slot deliveries arrive ReLU-masked
         if dy is not None:
-            assert dy.dtype == torch.bfloat16 and dy.shape[-1] == cout
+            assert dy.dtype == ACT and dy.shape[-1] == cout
             dy = dy.contiguous()
             if relu:
                 dy = dy.clone()

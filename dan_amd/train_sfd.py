@@ -78,8 +78,12 @@ class DetectorTrainer(object):
     Subclasses implement loss_terms(images_u8, *targets) -> list of (name, acc4 tensor)."""
 
     def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64),
-                 lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01)):
+                 lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01), loss_scale=None):
         self.model = model
+        # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale and the
+        # fused optimizer divides the (fp32) weight gradients again; bf16 has fp32's exponent range and needs none
+        from ._lib import ACT_NAME
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if ACT_NAME == "fp16" else 1.0)
         self.world = world
         self.negative_ratio = negative_ratio
         self.momentum = momentum
@@ -110,12 +114,12 @@ class DetectorTrainer(object):
         ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
         terms = self.loss_terms(images_u8, *targets)
         accs = [t[2] for t in terms]
-        torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
+        torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
         ops.GRAD_READY_HOOK = None
         self.buckets.finish()
         lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
-        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0)
+        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0 / self.loss_scale)
         self.step_no += 1
         self.last = terms
         return terms

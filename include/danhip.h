@@ -16,7 +16,11 @@
  *     inside; scratch comes from a caller-supplied workspace where a *_workspace_bytes() query exists.
  *   - every call takes a hipStream_t (passed as void*) and is asynchronous on it; no host sync.
  *   - re-entrant and thread-safe: no mutable globals.
- *   - activations are NHWC; bf16 storage is raw uint16 (upper half of the fp32 pattern).
+ *   - activations are NHWC, 16-bit, passed as raw uint16.  The 16-bit type is a property of the library build:
+ *     libdanhip.so = bf16 (default; every "bf16" below), libdanhip_f16.so = IEEE fp16 (same entry points, same layouts,
+ *     v_mfma_f32_16x16x32_f16; BASELINE.json configs[4] "fp16 + MFMA").  danhip_act_dtype() tells which one is loaded;
+ *     wherever an out_dtype argument says DANHIP_BF16 it means "the build's 16-bit type" (DANHIP_F16 is accepted as an
+ *     alias in the fp16 build).  Accumulation, master weights, gradients of weights and all box / loss arithmetic are fp32.
  */
 #ifndef DANHIP_H_
 #define DANHIP_H_
@@ -34,9 +38,11 @@ extern "C" {
 
 #define DANHIP_F32 0
 #define DANHIP_BF16 1
+#define DANHIP_F16 2
 
 const char* danhip_last_error(void);
 int danhip_version(void);
+int danhip_act_dtype(void);   /* DANHIP_BF16 or DANHIP_F16 */
 
 /* ------------------------------------------------------------------------------------------------
  * Dense convolution (tf.layers.conv2d, padding='same'; net/sfd_net.py:81-89 conv_relu and every

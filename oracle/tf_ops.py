@@ -143,17 +143,21 @@ def batch_norm_infer(x, gamma, beta, mean, var, eps):
 # ---------------------------------------------------------------------------------------------------------------
 # bf16 storage emulation (what the MI355X build stores between kernels): used by the parity tests so that the only
 # remaining differences to the HIP path are accumulation order and ties at the ReLU boundary.
+# storage type emulated by round_bf16: bf16 (default build) or torch.float16 (the fp16 build, tests set it explicitly)
+EMULATE_DTYPE = torch.bfloat16
+
+
 class _RoundBF16(torch.autograd.Function):
     """forward: round to bf16 (kept in fp32 container) if fwd; backward: round the incoming gradient if bwd."""
 
     @staticmethod
     def forward(ctx, x, fwd, bwd):
         ctx.bwd = bwd
-        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.clone()
+        return x.to(EMULATE_DTYPE).to(x.dtype) if fwd else x.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
+        return (g.to(EMULATE_DTYPE).to(g.dtype) if ctx.bwd else g), None, None
 
 
 def round_bf16(x, fwd=True, bwd=True):

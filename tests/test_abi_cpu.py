@@ -25,6 +25,13 @@ def test_library_exports_every_declared_symbol():
     for n in _lib.SIGNATURES:
         assert n in names, "ctypes table binds %s which the header does not declare" % n
     assert L.danhip_version() >= 1
+    assert L.danhip_act_dtype() == 1
+    # the fp16 build of the same sources exports the same ABI
+    L16 = ctypes.CDLL(build.OUT_F16)
+    for n in names:
+        assert hasattr(L16, n), "fp16 build misses export " + n
+    L16.danhip_act_dtype.restype = ctypes.c_int
+    assert L16.danhip_act_dtype() == 2
 
 
 def test_invalid_arguments_are_reported_not_thrown():
