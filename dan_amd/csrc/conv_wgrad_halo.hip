@@ -9,7 +9,7 @@
 //
 // A persistent 512-thread workgroup owns a (64 ci) x (COT co) x (9 taps) gradient tile IN REGISTERS (wave tile 16 ci x
 // 64 co x 9 taps = 144 accumulator VGPRs) and sweeps its share of 4 x 32 pixel tiles.  Per pixel tile the X halo patch
-// (6 x 34 pixels x 64 ci) and the dY tile (128 pixels x COT co) are DMA'd once; every K-step (one 32-pixel row) reads the dY
+// (6 x 34 pixels x 64 ci, LDS row pitch 40) and the dY tile (128 pixels x COT co) are DMA'd once; every K-step (one 32-pixel row) reads the dY
 // fragments once and reuses them for all nine taps, whose X fragments are the same patch at shifted row/column offsets
 // (the LDS swizzle is keyed on the patch COLUMN so a tap's row shift is a pure immediate offset).  Compared with the
 // per-tap split-K kernel (conv_wgrad.hip) this moves ~5.6x fewer bytes L2->LDS per MAC and reads 0.7 fragments per MFMA.
@@ -49,8 +49,12 @@ __device__ __forceinline__ int f256(int px) { return (px & 3) | (((px >> 3) & 1)
 template <int COT, bool FRONT = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
   constexpr int TH = 4, TW = 32, PW = TW + 2;
-  constexpr int XPIX = (TH + 2) * PW;                 // 204 patch pixels, 128-byte rows (64 ci)
-  constexpr int XPIECES = (XPIX + 7) / 8;             // 26
+  // The X halo patch ((TH+2) x PW pixels, 128-byte rows = 64 ci) lives in LDS with a row pitch of PITCH = 40 pixels = 5 DMA
+  // pieces: a piece (8 pixels) never straddles two patch rows, so its row / validity / base address are wave-uniform
+  // (scalar ALU) and a lane adds only its pixel-in-piece and chunk — ~7 VALU per DMA instead of ~27 (divisions by 34 and
+  // three quarter-rate 32-bit multiplies per lane), which was 14 % of the kernel's time.  Pieces 4 of each row carry 2 pixels.
+  constexpr int PITCH = 40, PPR = PITCH / 8;          // pieces per patch row
+  constexpr int XPIECES = (TH + 2) * PPR;             // 30
   constexpr int XBYTES = XPIECES * 1024;
   constexpr int RBY = COT * 2;                        // dY row bytes
   constexpr int YBYTES = TH * TW * RBY;
@@ -61,11 +65,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   constexpr int CPT = TH / KPC;                       // cycles per pixel tile
   constexpr int NX = (XPIECES + 7) / 8, NY = YPIECES / 8;
   constexpr int NDMA = NX + NY;                       // DMA instructions per wave per tile
-  constexpr int PER_SPREAD = (NDMA + (CPT - 1) - 1) / (CPT - 1);   // spread over cycles 0 .. CPT-2
+  constexpr int PER_EVEN = (NDMA + (CPT - 1) - 1) / (CPT - 1);     // spread over cycles 0 .. CPT-2 ...
+  constexpr int PER_SPREAD = (NX == NY && 2 <= CPT - 1) ? NX : PER_EVEN;   // ... as one X-only and one dY-only call when that fits
   constexpr int PER = FRONT ? NDMA : PER_SPREAD;                   // FRONT: everything in cycle 0 (measured 1-4 % slower: kept off)
   constexpr int NO = 4;                               // co fragments per wave (64 co)
   static_assert(2 * BUF <= 160 * 1024, "LDS budget");
-  static_assert(5 * PW * 128 + BUF < 65536 + BUF, "imm offsets");
+  static_assert(5 * PITCH * 128 + BUF < 65536 + BUF, "imm offsets");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -110,32 +115,58 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     x0 = (rem - ty * a.tiles_x) * TW;
   };
   int dn = 0, dy0 = 0, dx0 = 0;                        // coordinates of the tile whose pieces are being issued (uniform)
-  auto dma_setup = [&](int t) __attribute__((always_inline)) { tile_coords(t, dn, dy0, dx0); };
+  auto dma_setup = [&](int t) __attribute__((always_inline)) {
+    tile_coords(t, dn, dy0, dx0);
+    dn = __builtin_amdgcn_readfirstlane(dn); dy0 = __builtin_amdgcn_readfirstlane(dy0); dx0 = __builtin_amdgcn_readfirstlane(dx0);
+  };
   auto dma_issue = [&](int bufoff, auto s0c, auto s1c) __attribute__((always_inline)) {      // slots [S0, S1)
-    int lane = lane_;                                 // opaque copy: keeps the per-slot geometry from being hoisted out of the
-    asm volatile("" : "+v"(lane));                    // tile loop into ~24 long-lived VGPRs (it is ~15 VALU per DMA to recompute)
+    int lane = lane_;                                 // opaque copy: the lane-only terms below are recomputed per call (~8 VALU)
+    asm volatile("" : "+v"(lane));                    // instead of being hoisted out of the tile loop into long-lived VGPRs
+    int wv = wave;                                    // same for the wave-uniform per-slot geometry (would pin ~40 SGPRs and
+    asm volatile("" : "+s"(wv));                      // spill them into VGPR lanes)
+    constexpr bool HAS_X = decltype(s0c)::value < NX, HAS_Y = decltype(s1c)::value > NX;
+    constexpr int CPP = RBY / 16;                                        // dY: 16-byte chunks per pixel (16 / 8)
+    int l8 = 0, xA = 0, lp = 0, yB = 0;
+    if constexpr (HAS_X) {
+      l8 = lane >> 3;                                                    // X: pixel inside the piece
+      xA = (lane & 7) ^ (((l8 >> 1) & 1) << 1);                          // X: chunk position, lane part of the swizzle key
+    }
+    if constexpr (HAS_Y) {
+      lp = lane / CPP;                                                   // dY: pixel inside the piece
+      const int cpos = lane % CPP;                                       // dY: chunk position
+      yB = COT == 128 ? (cpos ^ (lp << 1)) : (cpos ^ (((lp >> 1) & 1) << 1));
+    }
+    const bool need_cc = co0 + COT > a.Co8;                              // thin heads: channel chunks beyond Co8 are zero-filled
 #pragma unroll
     for (int s = decltype(s0c)::value; s < decltype(s1c)::value && s < NDMA; ++s) {
       if (s < NX) {
-        int piece = s * 8 + wave;
+        int piece = s * 8 + wv;                      // wave-uniform from here to sbase
         if (piece > XPIECES - 1) piece = XPIECES - 1;
-        const int px = piece * 8 + (lane >> 3);        // patch pixel
-        const int prow = px / PW, pcol = px - prow * PW;
-        const int y = dy0 - 1 + prow, x = dx0 - 1 + pcol;
-        const bool ok = px < XPIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        const int chunk = (lane & 7) ^ (f128(pcol) << 1);
-        const unsigned voff = ok ? (unsigned)(((dn * a.H + y) * a.W + x) * a.C + ci0 + chunk * 8) * 2u : 0xFFFFFFFFu;
+        const int prow = piece / PPR, pc5 = piece - prow * PPR;
+        const int y = dy0 - 1 + prow, xs = dx0 - 1 + pc5 * 8;
+        const unsigned bady = (unsigned)y < (unsigned)a.H ? 0u : 0xFFFFFFFFu;                  // scalar select, no branch
+        const int lim = pc5 == PPR - 1 ? PW - (PPR - 1) * 8 : 8;
+        const unsigned sbase = (unsigned)(((dn * a.H + y) * a.W + xs) * a.C + ci0) * 2u;      // may wrap; exact for valid lanes
+        const int x = xs + l8;
+        const unsigned badx = (l8 < lim && (unsigned)x < (unsigned)a.W) ? 0u : 0xFFFFFFFFu;
+        const int chunk = xA ^ ((pc5 & 1) << 2);       // = (lane & 7) ^ (f128(pcol) << 1), pcol = pc5*8 + l8
+        const unsigned voff = (__umul24((unsigned)l8, (unsigned)(a.C * 2)) + sbase + (unsigned)(chunk << 4)) | bady | badx;   // invalid -> ~0
         wg_dma16(rsrc_x, voff, smem + bufoff + piece * 1024);
+        __builtin_amdgcn_sched_barrier(0);             // one slot's temporaries at a time (register budget)
       } else {
-        const int piece = (s - NX) * 8 + wave;
-        const int px = piece * YROWS_PER_PIECE + lane / (RBY / 16);   // tile pixel r*32 + c
-        const int y = dy0 + (px >> 5), x = dx0 + (px & 31);
-        const int cpos = lane % (RBY / 16);
-        const int chunk = cpos ^ ((COT == 128 ? f256(px) : f128(px)) << 1);
-        const int cc = co0 + chunk * 8;
-        const bool ok = y < a.H && x < a.W && cc < a.Co8;
-        const unsigned voff = ok ? (unsigned)(((dn * a.H + y) * a.W + x) * a.Co8 + cc) * 2u : 0xFFFFFFFFu;
+        const int piece = (s - NX) * 8 + wv;         // wave-uniform
+        const int pxb = piece * YROWS_PER_PIECE;       // tile pixel r*32 + c of the piece's first pixel
+        const int y = dy0 + (pxb >> 5), xs = dx0 + (pxb & 31);
+        const unsigned bady = y < a.H ? 0u : 0xFFFFFFFFu;
+        const unsigned sbase = (unsigned)(((dn * a.H + y) * a.W + xs) * a.Co8 + co0) * 2u;
+        const int x = xs + lp;
+        const int sb = (pxb >> 3) & 1;
+        const int chunk = yB ^ (COT == 128 ? (sb << 3) : (sb << 2));     // = cpos ^ (f256 / f128 (pxb + lp) << 1)
+        const int cclim = need_cc ? a.Co8 : 0x7FFFFFFF;                  // thin heads: chunks beyond Co8 are zero-filled
+        const unsigned badx = (x < a.W && co0 + chunk * 8 < cclim) ? 0u : 0xFFFFFFFFu;
+        const unsigned voff = (__umul24((unsigned)lp, (unsigned)(a.Co8 * 2)) + sbase + (unsigned)(chunk << 4)) | bady | badx;
         wg_dma16(rsrc_y, voff, smem + bufoff + XBYTES + piece * 1024);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -151,15 +182,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int ch = (wci * 2 + (p >> 1)) ^ (f128(pcol) << 1);
       xaddr[j][h] = pcol * 128 + (ch << 4) + (p & 1) * 8;
     }
-  int yaddr[NO][2];                                   // [co fragment][half]: dY fragment base of row 0
-#pragma unroll
-  for (int o = 0; o < NO; ++o)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int px = 8 * g + 4 * h + q;                // + r*32 (does not change the swizzle bits 0,1,3)
-      const int ch = ((wco * 4 + o) * 2 + (p >> 1)) ^ ((COT == 128 ? f256(px) : f128(px)) << 1);
-      yaddr[o][h] = XBYTES + px * RBY + (ch << 4) + (p & 1) * 8;
-    }
+  int yaddr[NO];                                      // [co fragment]: dY fragment base of row 0, half 0; half 1 (pixel + 4) is
+#pragma unroll                                         // + 4*RBY: the swizzle bits (px & 3, px >> 3) do not see bit 2 of the pixel
+  for (int o = 0; o < NO; ++o) {
+    const int px = 8 * g + q;                          // + r*32 (does not change the swizzle bits 0,1,3)
+    const int ch = ((wco * 4 + o) * 2 + (p >> 1)) ^ ((COT == 128 ? f256(px) : f128(px)) << 1);
+    yaddr[o] = XBYTES + px * RBY + (ch << 4) + (p & 1) * 8;
+  }
 
   f32x4 acc[9][NO];
 #pragma unroll
@@ -174,16 +203,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   bf16x8 xf[6], yf[NO];
   auto read_x = [&](bf16x8& dst, int tap, int R) __attribute__((always_inline)) {
     const int i = tap / 3, j = tap % 3;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][0] + (R + i) * PW * 128));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][1] + (R + i) * PW * 128));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][0] + (R + i) * PITCH * 128));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][1] + (R + i) * PITCH * 128));
     dst = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
   auto read_frags = [&](auto rc) __attribute__((always_inline)) {        // K-step R of the current tile (addresses hold the buffer)
     constexpr int R = decltype(rc)::value;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o][0] + R * 32 * RBY));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o][1] + R * 32 * RBY));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o] + R * 32 * RBY));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + yaddr[o] + 4 * RBY + R * 32 * RBY));
       yf[o] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 #pragma unroll
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int j = 0; j < 3; ++j) { xaddr[j][0] += dir; xaddr[j][1] += dir; }
 #pragma unroll
-    for (int o = 0; o < NO; ++o) { yaddr[o][0] += dir; yaddr[o][1] += dir; }
+    for (int o = 0; o < NO; ++o) yaddr[o] += dir;
   };
 
   // ---- prologue: tile t_begin into buffer 0
@@ -329,7 +358,7 @@ int wg_cu_count() {
 
 template <int COT, bool FRONT = false>
 int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
-  constexpr int XB = ((6 * 34 + 7) / 8) * 1024, YB = 128 * COT * 2;
+  constexpr int XB = 6 * 5 * 1024, YB = 128 * COT * 2;
   constexpr int LDS = 2 * (XB + YB);
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<COT, FRONT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
