@@ -46,6 +46,9 @@ __device__ __forceinline__ int f256(int px) { return (px & 3) | (((px >> 3) & 1)
 
 // COT: output-channel tile (128: waves = 4 ci-groups x 2 co-halves, every wave sees every K-step;
 //                           64: waves = 4 ci-groups x 2 K-groups, group A takes the even rows, group B the odd ones)
+#ifndef WG_ALL9
+#define WG_ALL9 1
+#endif
 template <int COT, bool FRONT = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_halo_kernel(const WgHaloArgs a) {
   constexpr int TH = 4, TW = 32, PW = TW + 2;
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   // Register budget: the X fragments of taps 0..5 are read in the mem phase; taps 6..8 are read at the start of the MFMA
   // phase into the registers of taps 0..2 once their MFMAs have been issued (their LDS latency hides under taps 3..5).
-  bf16x8 xf[6], yf[NO];
+  constexpr int NXF = WG_ALL9 ? 9 : 6;
+  bf16x8 xf[NXF], yf[NO];
   auto read_x = [&](bf16x8& dst, int tap, int R) __attribute__((always_inline)) {
     const int i = tap / 3, j = tap % 3;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + xaddr[j][0] + (R + i) * PITCH * 128));
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       yf[o] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 #pragma unroll
-    for (int t = 0; t < 6; ++t) read_x(xf[t], t, R);
+    for (int t = 0; t < NXF; ++t) read_x(xf[t], t, R);
   };
   auto mma_tap = [&](int t, const bf16x8& x) __attribute__((always_inline)) {
 #pragma unroll
@@ -224,13 +228,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto mma = [&](auto rc) __attribute__((always_inline)) {              // MFMA phase of K-step R
     constexpr int R = decltype(rc)::value;
-    mma_tap(0, xf[0]); mma_tap(1, xf[1]); mma_tap(2, xf[2]);
-    __builtin_amdgcn_sched_barrier(0);
-    read_x(xf[0], 6, R); read_x(xf[1], 7, R); read_x(xf[2], 8, R);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_tap(3, xf[3]); mma_tap(4, xf[4]); mma_tap(5, xf[5]);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_tap(6, xf[0]); mma_tap(7, xf[1]); mma_tap(8, xf[2]);
+    if constexpr (WG_ALL9) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) mma_tap(t, xf[t]);
+    } else {
+      mma_tap(0, xf[0]); mma_tap(1, xf[1]); mma_tap(2, xf[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_x(xf[0], 6, R); read_x(xf[1], 7, R); read_x(xf[2], 8, R);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(3, xf[3]); mma_tap(4, xf[4]); mma_tap(5, xf[5]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_tap(6, xf[0]); mma_tap(7, xf[1]); mma_tap(8, xf[2]);
+    }
     if (do_bias) {                                    // db += column sums of this K-step's dY fragments (VALU, beside the MFMAs)
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
