@@ -477,8 +477,8 @@ extern "C" int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_de
   e->rows_f = (int)rf; e->cols_f = (int)cf; e->rows_b = (int)rb; e->cols_b = (int)cb; e->co8 = round_up(d->Cout, 8);
   e->first_block = first_block;
   const long total = rf * cf + (wb_packed ? rb * cb : 0);
-  long nb = (total + 2047) / 2048;                      // 8 elements per thread
-  if (nb > 64) nb = 64;
+  long nb = (total + 1023) / 1024;                      // 4 elements per thread (fc6: 9.4 M elements -> 9 k workgroups)
+  if (nb > 16384) nb = 16384;
   *blocks = (int)nb;
   return DANHIP_OK;
 }
