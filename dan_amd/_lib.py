@@ -56,7 +56,7 @@ SIGNATURES = {
     "danhip_batchnorm_fwd_infer": [P, P, P, P, P, P, I64, I32, ctypes.c_int, P],
     "danhip_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I32, P],
     "danhip_dynamic_anchor_routing_eval": [P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, ctypes.c_size_t, P],
-    "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P,
+    "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P, P,
                                             ctypes.c_size_t, P],
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
     "danhip_resize_u8_linear": [P, I32, I32, P, I32, I32, I32, ctypes.c_double, ctypes.c_double, P],

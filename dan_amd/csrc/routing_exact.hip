@@ -174,8 +174,9 @@ __global__ void route_scatter_kernel(const int* __restrict__ cand_cell, const in
 __global__ void route_train_cell_kernel(const float* __restrict__ anchors, const float* __restrict__ gt, const int* __restrict__ matched,
                                         const int* __restrict__ ignore_flag, const int* __restrict__ count, const int* __restrict__ offset,
                                         int* __restrict__ bucket, int* __restrict__ mask_out, float* __restrict__ decode_out, long N,
-                                        unsigned long long seed, unsigned long long counter0) {
+                                        unsigned long long seed, unsigned long long counter0, const unsigned long long* __restrict__ counter_dev) {
   const long b = blockIdx.y;
+  if (counter_dev) counter0 += *counter_dev;                            // device-resident part of the counter (replayable launches)
   anchors += b * N * 4; gt += b * N * 4; matched += b * N; ignore_flag += b * N; count += b * N; offset += b * N; bucket += b * N;
   mask_out += b * N; decode_out += b * N * 4;
   for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
@@ -296,8 +297,9 @@ extern "C" int danhip_dynamic_anchor_routing_eval(const float* anchors, const fl
 /* u(i) of image b, source i = splitmix64(seed, counter0 + b*N + i) — the stream oracle_uniform() replays on the CPU. */
 extern "C" int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_targets, const float* labels, const int32_t* mask_in,
                                                    int64_t N, int32_t feat_height, int32_t feat_width, int32_t anchor_depth, int32_t feat_strides,
-                                                   int32_t B, float thres, float ignore_thres, uint64_t seed, uint64_t counter0, int32_t* mask_out,
-                                                   float* decode_out, void* workspace, size_t workspace_bytes, void* stream) {
+                                                   int32_t B, float thres, float ignore_thres, uint64_t seed, uint64_t counter0,
+                                                   const uint64_t* counter_dev, int32_t* mask_out, float* decode_out, void* workspace,
+                                                   size_t workspace_bytes, void* stream) {
   int rc = check_route(anchors, gt_targets, labels, mask_in, mask_out, decode_out, N, feat_height, feat_width, anchor_depth, feat_strides, B,
                        "dynamic_anchor_routing_train");
   if (rc) return rc;
@@ -318,7 +320,7 @@ extern "C" int danhip_dynamic_anchor_routing_train(const float* anchors, const f
   hipLaunchKernelGGL(route_scatter_kernel, grid, dim3(256), 0, s, cand, offset, cursor, bucket, (long)N);
   DH_LAUNCH_CHECK();
   hipLaunchKernelGGL(route_train_cell_kernel, grid, dim3(256), 0, s, anchors, gt_targets, matched, ignore_flag, count, offset, bucket, mask_out,
-                     decode_out, (long)N, (unsigned long long)seed, (unsigned long long)counter0);
+                     decode_out, (long)N, (unsigned long long)seed, (unsigned long long)counter0, (const unsigned long long*)counter_dev);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

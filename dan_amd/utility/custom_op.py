@@ -11,11 +11,12 @@ from .anchor_manipulator import small_mining_match  # noqa: F401  (re-exported u
 
 
 def dynamic_anchor_routing(anchors, gt_targets, labels, mask_in, feat_height, feat_width, anchor_depth, feat_strides, img_height, img_width,
-                           trainging, thres, ignore_thres, seed=0, counter0=0):
+                           trainging, thres, ignore_thres, seed=0, counter0=0, counter_dev=None):
     """custom_op.dynamic_anchor_routing (utility/custom_op.py:52).  Tensors may carry a leading batch dimension
     ([B,N,4] / [B,N]); img_height / img_width are accepted and ignored exactly as the reference kernel does.
     Training mode draws u(b,i) from the counter-based stream keyed by (seed, counter0) (the reference's
-    std::random_device stream is not reproducible).  Returns (mask_out int32, decode_out fp32) of the input's shape."""
+    std::random_device stream is not reproducible); counter_dev (int64 device tensor, optional) is added to counter0 on the device.
+    Returns (mask_out int32, decode_out fp32) of the input's shape."""
     if not (0.0 <= thres < 1.0) or not (0.0 <= ignore_thres < 1.0):
         raise ValueError("thres / ignore_thres must be in [0, 1) (dynamic_anchor_routing.cc:526-530)")
     batched = labels.dim() == 2
@@ -33,7 +34,8 @@ def dynamic_anchor_routing(anchors, gt_targets, labels, mask_in, feat_height, fe
     ws = torch.empty((nws + 7) // 8, dtype=torch.int64, device=l.device)
     if trainging:
         call("danhip_dynamic_anchor_routing_train", ptr(a), ptr(g), ptr(l), ptr(m), N, int(feat_height), int(feat_width), int(anchor_depth),
-             int(feat_strides), B, float(thres), float(ignore_thres), int(seed), int(counter0), ptr(mo), ptr(do), ptr(ws), nws, stream())
+             int(feat_strides), B, float(thres), float(ignore_thres), int(seed), int(counter0), ptr(counter_dev), ptr(mo), ptr(do), ptr(ws), nws,
+             stream())
     else:
         call("danhip_dynamic_anchor_routing_eval", ptr(a), ptr(g), ptr(l), ptr(m), N, int(feat_height), int(feat_width), int(anchor_depth),
              int(feat_strides), B, ptr(mo), ptr(do), ptr(ws), nws, stream())

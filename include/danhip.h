@@ -250,6 +250,8 @@ int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const u
  *   eval  (trainging=false, :328-408): mask_out in {0,1}, decode_out = stage-2 boxes decoded against the routed stage-1 box.
  *   train (trainging=true,  :203-327): mask_out in {1,0,-1}, decode_out = stage-2 regression targets.  The reference draws
  *          from std::mt19937(std::random_device) (not reproducible); here u(b,i) = splitmix64(seed, counter0 + b*N + i).
+ *          counter_dev (nullable): device uint64 added to counter0 at run time, so a launch recorded in a hipGraph draws a
+ *          fresh stream on every replay (the caller advances it with a device-side add).
  * ------------------------------------------------------------------------------------------------ */
 size_t danhip_routing_workspace_bytes(int64_t N, int32_t B, int training);
 int danhip_dynamic_anchor_routing_eval(const float* anchors, const float* gt_targets, const float* labels, const int32_t* mask_in,
@@ -258,8 +260,9 @@ int danhip_dynamic_anchor_routing_eval(const float* anchors, const float* gt_tar
                                        void* stream);
 int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_targets, const float* labels, const int32_t* mask_in,
                                         int64_t N, int32_t feat_height, int32_t feat_width, int32_t anchor_depth, int32_t feat_strides,
-                                        int32_t B, float thres, float ignore_thres, uint64_t seed, uint64_t counter0, int32_t* mask_out,
-                                        float* decode_out, void* workspace, size_t workspace_bytes, void* stream);
+                                        int32_t B, float thres, float ignore_thres, uint64_t seed, uint64_t counter0,
+                                        const uint64_t* counter_dev, int32_t* mask_out, float* decode_out, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 
 /* tf.image.non_max_suppression as used by utility/bbox_util.py:75-91: greedy over candidates already ordered by descending
  * score (stable), suppress when IoU > iou_threshold (raw areas, no +1, corners normalised by min/max).
