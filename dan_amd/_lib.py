@@ -37,6 +37,7 @@ DESC = ctypes.POINTER(ConvDesc)
 SIGNATURES = {
     "danhip_conv_packed_dims": [DESC, ctypes.c_int, ctypes.POINTER(I64), ctypes.POINTER(I64)],
     "danhip_pack_conv_weight": [DESC, P, I32, P, P, P],
+    "danhip_conv2d_fwd_pool": [DESC, P, P, P, P, P, P],
     "danhip_pack_entry_init": [ctypes.POINTER(PackEntry), DESC, P, I32, P, P, I32, ctypes.POINTER(ctypes.c_int32)],
     "danhip_pack_conv_weights_batched": [P, I32, I32, P],
     "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],

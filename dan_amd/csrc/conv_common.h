@@ -9,6 +9,7 @@ struct ConvArgs {
   const bf16_t* mask;
   const bf16_t* resid;
   void* y;
+  bf16_t* pool_y;   // optional: 2x2/stride-2 SAME max-pool of y (ReLU outputs), written by the kernels that can fuse it
   int N, H, W, C;
   int Ho, Wo, Co;
   int kh, kw, stride, pad_t, pad_l;
@@ -18,6 +19,18 @@ struct ConvArgs {
   int dshift;    // log2(dstride)
   int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
 };
+
+// true when launch_conv's kernel for these args writes a.pool_y itself (conv_halo_c64.hip / conv_halo.hip forward tiles)
+bool danhip_conv_pool_fusable(const ConvArgs& a);
+bool danhip_conv_halo_pool_fusable(const ConvArgs& a);
+bool danhip_conv_c64_eligible(const ConvArgs& a);
+
+// packed max of two pairs of NON-NEGATIVE 16-bit floats (ReLU outputs): they order like signed 16-bit integers, and a
+// stray -0.0 (0x8000) is the smallest value.  One v_pk_max_i16.
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned pkmax_relu(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
 
 // Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
 // eligible (caller falls back to the flat-M kernel), negative on a launch error.

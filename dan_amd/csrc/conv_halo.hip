@@ -83,9 +83,10 @@ __device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc
 
 // 8 consecutive channels of one pixel (two interleaved channel tiles): 16-byte mask / residual / old-value reads, one
 // 16-byte store (fp32 output: two float4 stores).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <bool DGRAD>
-__device__ __forceinline__ void halo_finish8(const ConvArgs& a, const f32x4& lo, const f32x4& hi, const float (&b)[8], const uint4& in0,
-                                             const uint4& in1, size_t o) {
+__device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo, const f32x4& hi, const float (&b)[8], const uint4& in0,
+                                              const uint4& in1, size_t o) {
   float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   if (!DGRAD) {
 #pragma unroll
@@ -98,7 +99,7 @@ __device__ __forceinline__ void halo_finish8(const ConvArgs& a, const f32x4& lo,
       float* y = reinterpret_cast<float*>(a.y) + o;
       *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(y + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      return;
+      return u32x4{0u, 0u, 0u, 0u};
     }
     if (a.resid) {
       const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0);
@@ -117,9 +118,9 @@ __device__ __forceinline__ void halo_finish8(const ConvArgs& a, const f32x4& lo,
       for (int r = 0; r < 8; ++r) v[r] += bf2f(op[r]);
     }
   }
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
   *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o) = t;      // (non-temporal stores measured neutral here)
+  return t;
 }
 
 // 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out
@@ -130,7 +131,7 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 
 // TPS: taps per step (1 or 3); NSW: weight ring depth (prefetch distance D = NSW-1 steps);
 // NCU > 0: "thin head" — only the first NCU channel tiles of a wave are computed (Cout <= 16*NCU, ragged Cout allowed).
-template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0>
+template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0, bool POOL = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvArgs a, const HaloGeom g) {
   constexpr int PW = TW + 2;                       // patch row pitch (pixels); even, so LDS row parity == column parity
   constexpr int PROWS = (TH + 2) * PW;             // patch pixels
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int q = 0; q < NPAIR; ++q)
 #pragma unroll
         for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && a.bias) ? a.bias[cb + q * 32 + r] : 0.f;
+      [[maybe_unused]] u32x4 pk[POOL ? NPAIR : 1][POOL ? NPT : 1];      // POOL: packed outputs (zero where the pixel is outside)
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * TP + p * 16 + frow;
@@ -402,9 +404,38 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
-          if (ok) halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
+          u32x4 r = {0u, 0u, 0u, 0u};
+          if (ok) r = halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
+          if constexpr (POOL) pk[q][p] = r;
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      if constexpr (POOL) {
+        // 2x2 / stride-2 SAME max-pool of this wave's rows (tf.layers.max_pooling2d after the block, net/sfd_net.py:132-143) from
+        // the packed ReLU outputs still in registers: the vertical neighbour is fragment p + PV of the same lane, the horizontal
+        // one sits in lane ^ 1; even lanes store the pooled pixel (16 bytes per channel pair).
+        static_assert((TP / TW) % 2 == 0 && TP / TW >= 2 && TH % 2 == 0 && TW % 2 == 0, "a wave must own whole row pairs");
+        constexpr int FPR = TW / 16;                 // fragments per tile row
+        constexpr int PV = FPR;                      // fragment index distance of the row below
+        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          if (((p / FPR) & 1) != 0) continue;        // top rows of the pairs only
+          const int t = wm * TP + p * 16 + frow;
+          const int y = y0 + t / TW, x = x0 + t % TW;
+          const bool okp = y < a.H && x < a.W && (frow & 1) == 0;
+          const size_t op = ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * a.Co + cb;
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q) {
+            u32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned v = pkmax_relu(pk[q][p][e], pk[q][p + PV][e]);
+              m[e] = pkmax_relu(v, (unsigned)__shfl_xor((int)v, 1));
+            }
+            if (okp) *reinterpret_cast<u32x4*>(a.pool_y + op + q * 32) = m;
+          }
         }
       }
     }
@@ -563,12 +594,12 @@ int cu_count() {
   return n;
 }
 
-template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0>
+template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0, bool POOL = false>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
   constexpr int LDS = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU, POOL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   HaloGeom g{};
@@ -585,7 +616,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.grouped = 0;
   if (items >= G && (G % 8) == 0 && ((G / 8) % g.NB) == 0 && g.NB > 1) g.grouped = 1;
   if (items < G) G = (int)items;
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU>), dim3(G), dim3(512), LDS, s, a, g);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU, POOL>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -600,6 +631,10 @@ int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
   if (p.head) {
     if (DGRAD) return 1;
     return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 1, 4, false, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 1, 4, false, 1>(a, s);
+  }
+  if constexpr (!DGRAD) {
+    if (a.pool_y && p.bn == 128)                   // fused 2x2 max-pool epilogue (the 128-wide tiles own whole row pairs per wave)
+      return p.th == 8 ? launch_halo_cfg<8, 32, 128, 4, 2, 1, 4, false, 0, true>(a, s) : launch_halo_cfg<16, 16, 128, 4, 2, 1, 4, false, 0, true>(a, s);
   }
   if (p.th == 8) {
     if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 1, 4, DGRAD>(a, s);
@@ -619,6 +654,12 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
   if (!dgrad && a.accumulate) return 1;
   if (!dgrad && a.mask) return 1;
   return dgrad ? launch_halo<true>(a, p, s) : launch_halo<false>(a, p, s);
+}
+
+bool danhip_conv_halo_pool_fusable(const ConvArgs& a) {
+  HaloPlan p;
+  if (!plan_halo(a, &p) || p.head || p.bn != 128) return false;
+  return a.bias && a.relu && !a.resid && !a.out_f32 && !a.mask && !a.accumulate;      // forward conv_relu only
 }
 
 const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {

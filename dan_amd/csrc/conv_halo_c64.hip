@@ -148,6 +148,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       float bv[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) bv[r] = (!DGRAD && a.bias) ? a.bias[cbase + r] : 0.f;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      u32x4 pk[NPT];                                         // packed outputs of this lane (zero outside the image), for the fused pool
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) pk[p] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * 64 + p * 16 + frow;
@@ -183,12 +187,30 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               for (int r = 0; r < 8; ++r) v[r] += bf2f(op[r]);
             }
           }
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
           const u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
           __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
+          pk[p] = tt;
         }
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!DGRAD && a.pool_y) {
+        // fused 2x2 / stride-2 SAME max-pool (pool1, net/sfd_net.py:132): wave rows (2*wm, 2*wm+1); fragments p = 0,1 are the top
+        // row (x 0-15, 16-31), p + 2 the row below; the horizontal neighbour is lane ^ 1; even lanes store.  ReLU outputs only.
+        const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int t = wm * 64 + p * 16 + frow;
+          const int y = y0 + t / TW, x = x0 + t % TW;
+          u32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned v = pkmax_relu(pk[p][e], pk[p + 2][e]);
+            m[e] = pkmax_relu(v, (unsigned)__shfl_xor((int)v, 1));
+          }
+          if (y < a.H && x < a.W && (frow & 1) == 0)
+            *reinterpret_cast<u32x4*>(a.pool_y + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * 64 + cbase) = m;
+        }
       }
     }
     if (!has_next) break;
@@ -246,6 +268,8 @@ int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s) {
   if (!dgrad && (a.accumulate || a.mask)) return 1;
   return dgrad ? launch_c64<true>(a, s) : launch_c64<false>(a, s);
 }
+
+bool danhip_conv_c64_eligible(const ConvArgs& a) { return c64_eligible(a); }
 
 const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad) {
   if (!c64_eligible(a)) return nullptr;

@@ -504,6 +504,30 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   return launch_conv(a, (hipStream_t)stream);
 }
 
+// conv_relu followed by tf.layers.max_pooling2d([2,2],[2,2],'same') (net/sfd_net.py:128-143: every VGG block): y as
+// danhip_conv2d_fwd(relu = 1) and pool_y = maxpool2x2(y) [N,ceil(Ho/2),ceil(Wo/2),Cout].  The 3x3 kernels that own whole row
+// pairs per wave pool their packed outputs in the epilogue (no second pass over y); other shapes run the pool kernel after.
+bool danhip_conv_pool_fusable(const ConvArgs& a) {
+  if (!(a.bias && a.relu && !a.resid && !a.out_f32 && !a.mask && !a.accumulate)) return false;
+  return danhip_conv_c64_eligible(a) || danhip_conv_halo_pool_fusable(a);
+}
+
+extern "C" int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                      uint16_t* pool_y, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(x && wf_packed && bias && y && pool_y, DANHIP_EINVAL, "conv2d_fwd_pool: null pointer");
+  DH_REQUIRE(d->Cout % 8 == 0, DANHIP_EINVAL, "conv2d_fwd_pool: Cout must be a multiple of 8");
+  ConvArgs a = fwd_args(d);
+  a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = nullptr; a.y = y;
+  a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
+  const bool fused = danhip_conv_pool_fusable(a);
+  a.pool_y = fused ? pool_y : nullptr;
+  rc = launch_conv(a, (hipStream_t)stream);
+  if (rc || fused) return rc;
+  return danhip_maxpool2x2_fwd(y, pool_y, d->N, d->Ho, d->Wo, d->Cout, stream);
+}
+
 namespace {
 // Direct (gather-form) data gradient for strided convolutions (only conv6_2 / conv7_2, 3x3 stride 2, tiny maps).
 // One thread per (input pixel, 8 input channels).

@@ -25,18 +25,19 @@ class VGG16Backbone(object):
         w = self.vs.get((name or "l2_normalize") + "/weight", (inputs.shape[-1],), init_value)
         return ops.l2_normalize(inputs, w)
 
-    def conv2d(self, inputs, filters, kernel_size, strides, scope, relu, out_f32=False, residual=None, init="glorot"):
+    def conv2d(self, inputs, filters, kernel_size, strides, scope, relu, out_f32=False, residual=None, init="glorot", pool=False):
         kh, kw = kernel_size
         s = strides[0] if isinstance(strides, (tuple, list)) else strides
         cin = inputs.shape[-1]
         w = self.vs.get(scope + "/kernel", (kh, kw, getattr(inputs, "_real_channels", cin), filters), init)
         b = self.vs.get(scope + "/bias", (filters,), "zeros")
-        return ops.conv2d(inputs, w, b, stride=s, relu=relu, out_f32=out_f32, residual=residual)
+        return ops.conv2d(inputs, w, b, stride=s, relu=relu, out_f32=out_f32, residual=residual, pool=pool)
 
-    def conv_relu(self, inputs, filters, kernel_size, strides, scope, padding="same", dilate_rate=1, reuse=None):
-        """net/sfd_net.py:81-89."""
+    def conv_relu(self, inputs, filters, kernel_size, strides, scope, padding="same", dilate_rate=1, reuse=None, pool=False):
+        """net/sfd_net.py:81-89.  pool=True (not in the reference signature): the caller max-pools the result next, so the conv
+        kernel produces the pooled map in its epilogue (ops.max_pool_2x2 then just hands it over)."""
         assert padding == "same" and dilate_rate == 1
-        return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True)
+        return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True, pool=pool)
 
     # ---- batch-norm surface (net/sfd_net.py:91-119): defined on every VGG16Backbone, used by no VGG graph ------------
     def _bn(self, inputs, scope, training, relu):
@@ -69,27 +70,27 @@ class VGG16Backbone(object):
         assert padding == "same" and dilate_rate == 1
         return self._bn(self._conv_nobias(inputs, filters, kernel_size, strides, scope), scope, training, relu=False)
 
-    def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None):
-        """net/sfd_net.py:121-125."""
+    def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None, pool_after=False):
+        """net/sfd_net.py:121-125.  pool_after: the block is followed by max_pooling2d (get_featmaps): fuse it into the last conv."""
         for ind in range(1, num_blocks + 1):
-            inputs = self.conv_relu(inputs, filters, kernel_size, strides, "{0}/{0}_{1}".format(name, ind))
+            inputs = self.conv_relu(inputs, filters, kernel_size, strides, "{0}/{0}_{1}".format(name, ind), pool=pool_after and ind == num_blocks)
         return inputs
 
     def get_featmaps(self, inputs, training=False):
         """net/sfd_net.py:127-156.  inputs: bf16 NHWC BGR mean-subtracted, channels zero-padded to 8
         (ops.preprocess_u8 makes it; `_real_channels` = 3 keeps the TF kernel shape [3,3,3,64])."""
         feature_layers = []
-        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1")
+        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1", pool_after=True)
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2")
+        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2", pool_after=True)
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 3, 256, (3, 3), (1, 1), "conv3")
+        inputs = self.conv_block(inputs, 3, 256, (3, 3), (1, 1), "conv3", pool_after=True)
         feature_layers.append(self.l2_normalize(inputs, 10, training, "l2_norm_layer_3"))
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv4")
+        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv4", pool_after=True)
         feature_layers.append(self.l2_normalize(inputs, 8, training, "l2_norm_layer_4"))
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv5")
+        inputs = self.conv_block(inputs, 3, 512, (3, 3), (1, 1), "conv5", pool_after=True)
         feature_layers.append(self.l2_normalize(inputs, 5, training, "l2_norm_layer_5"))
         inputs = ops.max_pool_2x2(inputs)
         inputs = self.conv_relu(inputs, 1024, (3, 3), (1, 1), "fc6")

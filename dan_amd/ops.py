@@ -201,7 +201,7 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
@@ -211,8 +211,14 @@ class _Conv2d(torch.autograd.Function):
         wf, wb = packed_weights(d, w, w_param, need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
         e0 = _prof_begin()
-        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
-             F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
+        if pool_out is not None:                         # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
+            assert relu and not out_f32 and residual is None and b is not None and cout % 8 == 0
+            pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
+            call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
+            pool_out.append(pooled)
+        else:
+            call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
+                 F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
         _prof_end(e0, d, 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
         ctx.xslot, ctx.yslot = xslot, yslot
@@ -258,7 +264,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 11
+            return (None,) * 12
         db_in_wgrad = need_db and ctx.needs_input_grad[1]       # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -291,20 +297,24 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None):
+def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False):
+    """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up."""
     wp = w if isinstance(w, torch.nn.Parameter) else None
     bp = b if isinstance(b, torch.nn.Parameter) else None
     track = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
     if track and relu and residual is not None:
         raise NotImplementedError("relu + fused residual needs a separate ReLU mask in backward (y > 0 is not the mask)")
     yslot = GradSlot.__new__(GradSlot) if (track and not out_f32) else None
-    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot)
+    pool_out = [] if (pool and relu and not out_f32 and residual is None and b is not None and w.shape[-1] % 8 == 0) else None
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out)
     if yslot is not None:
         yslot.__init__(y, relu)
         y._dh_slot = yslot
+    if pool_out:
+        y._dh_pooled = pool_out[0]
     return y
 
 
@@ -312,10 +322,13 @@ class _MaxPool(torch.autograd.Function):
     """tf.layers.max_pooling2d([2,2],[2,2],'same') — net/sfd_net.py:132."""
 
     @staticmethod
-    def forward(ctx, x, xslot, yslot):
+    def forward(ctx, x, xslot, yslot, pre=None):
         N, H, W, C = x.shape
-        y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
-        call("danhip_maxpool2x2_fwd", ptr(x), ptr(y), N, H, W, C, stream())
+        if pre is not None:                              # already computed by the producing conv's epilogue
+            y = pre
+        else:
+            y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
+            call("danhip_maxpool2x2_fwd", ptr(x), ptr(y), N, H, W, C, stream())
         ctx.save_for_backward(x)
         ctx.xslot, ctx.yslot = xslot, yslot
         ctx.set_materialize_grads(False)
@@ -329,17 +342,17 @@ class _MaxPool(torch.autograd.Function):
         if dy is not None:
             g = dy.contiguous() if g is None else g.add_(dy)
         if g is None:
-            return None, None, None
+            return None, None, None, None
         if ctx.xslot is not None:
             # the pooled maximum is > 0 exactly where its source is, so a gradient masked at the pooled level scatters to
             # an already ReLU-masked gradient; an unmasked one (autograd path) is masked by the producer's own backward
             buf, acc = ctx.xslot.target() if _pool_deliver_ok(ctx, dy) else (None, 0)
             if buf is not None:
                 call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(buf), N, H, W, C, acc, stream())
-                return None, None, None
+                return None, None, None, None, None
         dx = torch.empty_like(x)
         call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(dx), N, H, W, C, 0, stream())
-        return dx, None, None
+        return dx, None, None, None
 
 
 def _pool_deliver_ok(ctx, dy):
@@ -351,7 +364,7 @@ def max_pool_2x2(x):
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
     yslot = GradSlot.__new__(GradSlot) if track else None
-    y = _MaxPool.apply(x, xs, yslot)
+    y = _MaxPool.apply(x, xs, yslot, getattr(x, "_dh_pooled", None))
     if yslot is not None:
         # consumers may mask by (pooled > 0) when the source is a ReLU output
         yslot.__init__(y, xs.is_relu if xs is not None else False)

@@ -84,6 +84,12 @@ int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_dev, int32_t
 int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias,
                       void* y, int out_dtype, int relu, const uint16_t* residual, void* stream);
 
+/* conv_relu + the 2x2 / stride-2 'same' max-pool that follows every VGG block (net/sfd_net.py:128-143) in one call:
+ * y = relu(conv(x, w) + bias) [N,Ho,Wo,Cout] and pool_y = maxpool2x2(y) [N,ceil(Ho/2),ceil(Wo/2),Cout], both in the build's
+ * 16-bit type.  3x3 kernels that own whole row pairs per wave pool in their epilogue; other shapes run the pool kernel. */
+int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                           uint16_t* pool_y, void* stream);
+
 /* dx = conv_transpose(dy, w) (* (relu_mask > 0) if relu_mask != NULL: fuses the ReLU backward of the layer
  * that produced x).  dy bf16 [N,Ho,Wo,Cout_pad8]; dx bf16 [N,H,W,Cin]. accumulate: dx += instead of = . */
 int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed,

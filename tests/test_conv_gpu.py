@@ -165,3 +165,34 @@ def test_two_gib_activations_batch_equals_its_halves(N, H, W, Cin, Cout, dev):
     assert torch.equal(y[:h], ya) and torch.equal(y[h:], yb)
     assert torch.equal(dx[:h], dxa) and torch.equal(dx[h:], dxb)
     assert ((dw - dwa - dwb).abs().max() / dw.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 64, 64, 64), (1, 30, 62, 64, 64), (3, 32, 64, 64, 128), (2, 24, 64, 128, 128), (1, 31, 45, 128, 256),
+                                   (2, 32, 32, 256, 512), (1, 37, 29, 256, 512), (2, 10, 10, 512, 512), (1, 12, 12, 64, 32)])
+def test_conv_relu_with_fused_max_pool(shape, dev):
+    """danhip_conv2d_fwd_pool: the pooled map written by the conv epilogue (64->64 kernel, 8x32 and 16x16 halo tiles; other shapes
+    fall back to the pool kernel inside the call) is bit-identical to max_pool_2x2 of the conv output, ragged edges included,
+    and the gradient path is the unfused one."""
+    from dan_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(H * W + Cout)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    outs = []
+    for fused in (False, True):
+        xd = x.clone().requires_grad_(True)
+        wd = w.clone().requires_grad_(True)
+        bd = b.clone().requires_grad_(True)
+        y = ops.conv2d(xd, wd, bd, relu=True, pool=fused)
+        assert hasattr(y, "_dh_pooled") == fused
+        p = ops.max_pool_2x2(y)
+        gen = torch.Generator().manual_seed(7)
+        dp = torch.randn(p.shape, generator=gen).to(torch.bfloat16).to(dev)
+        p.backward(dp)
+        outs.append((y.detach(), p.detach(), xd.grad, wd.grad))
+    (y0, p0, dx0, dw0), (y1, p1, dx1, dw1) = outs
+    assert p1.shape == (N, (H + 1) // 2, (W + 1) // 2, Cout)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    assert torch.equal(dx0, dx1)
+    assert torch.allclose(dw0, dw1, rtol=1e-3, atol=1e-3 * dw0.abs().max().item())
