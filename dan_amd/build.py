@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdanhip.so")
 OUT_F16 = os.path.join(HERE, "libdanhip_f16.so")
 OBJ = os.path.join(CSRC, "_obj")
-FLAGS = (["-DDANHIP_HALO_EXPERIMENTS"] if os.environ.get("DANHIP_HALO_EXPERIMENTS") else []) + ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(a, deps):
