@@ -142,7 +142,7 @@ bool c8_eligible(const ConvArgs& a) {
 
 }  // namespace
 
-const char* danhip_conv_c8_label(const ConvArgs& a) { return c8_eligible(a) ? "conv3x3_c8_kernel" : nullptr; }
+const char* danhip_conv_c8_label(const ConvArgs& a) { return c8_eligible(a) ? "conv3x3_c8_kernel<true>" : nullptr; }
 
 int danhip_launch_conv_c8(const ConvArgs& a, hipStream_t s) {
   if (!c8_eligible(a)) return 1;

@@ -667,12 +667,14 @@ const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {
   if (!plan_halo(a, &p)) return nullptr;
   if (p.head) {
     if (dgrad) return nullptr;
-    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 1>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 1>";
+    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 1, false>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 1, false>";
   }
+  if (!dgrad && a.pool_y && danhip_conv_halo_pool_fusable(a))
+    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, false, 0, true>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, false, 0, true>";
   if (p.th == 8) {
-    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, false, 0>";
-    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, true, 0>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 0>";
+    if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, true, 0, false>" : "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, false, 0, false>";
+    return dgrad ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, true, 0, false>" : "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 0, false>";
   }
-  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, false, 0>";
-  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, true, 0>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 0>";
+  if (p.bn == 128) return dgrad ? "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, true, 0, false>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, false, 0, false>";
+  return dgrad ? "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, true, 0, false>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 0, false>";
 }

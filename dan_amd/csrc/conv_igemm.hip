@@ -383,11 +383,17 @@ ConvArgs bwd_args(const danhip_conv_desc* d) {
 // (matches the demangled name rocprofv3 reports) — used by bench.py to attribute measured time.
 extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which) {
   if (!d) return "";
-  const int cin = which == 0 ? d->Cin : round_up(d->Cout, 8);
-  const int cout = which == 0 ? d->Cout : d->Cin;
+  const int cin = (which == 0 || which == 4) ? d->Cin : round_up(d->Cout, 8);
+  const int cout = (which == 0 || which == 4) ? d->Cout : d->Cin;
   if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
   {
-    const ConvArgs a = which == 0 ? fwd_args(d) : bwd_args(d);
+    ConvArgs a = (which == 0 || which == 4) ? fwd_args(d) : bwd_args(d);
+    if (which == 4) {                                  // forward conv_relu with the fused 2x2 max-pool (danhip_conv2d_fwd_pool)
+      static const float one = 1.f;
+      static bf16_t dummy = 0;
+      a.bias = &one; a.relu = 1; a.pool_y = &dummy;
+      which = 0;
+    }
     if (which == 0 && danhip_conv_c8_label(a)) return danhip_conv_c8_label(a);
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;

@@ -219,7 +219,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
                  F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
-        _prof_end(e0, d, 0)
+        _prof_end(e0, d, 4 if pool_out is not None else 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
         ctx.xslot, ctx.yslot = xslot, yslot
         ctx.set_materialize_grads(False)

@@ -105,8 +105,9 @@ int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const
  * dy bf16 [M, C]; y bf16 [M, C] or NULL; db fp32 [C] or NULL. */
 int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_t M, int32_t C, void* stream);
 
-/* Kernel-instance label a forward (which=0) / data-gradient (which=1) call of this descriptor launches (the demangled
- * name rocprofv3 reports) — lets bench.py attribute measured time to a kernel. */
+/* Kernel-instance label a forward (which=0) / data-gradient (which=1) / forward-with-fused-pool (which=4,
+ * danhip_conv2d_fwd_pool) call of this descriptor launches (the demangled name rocprofv3 reports) — lets bench.py attribute
+ * measured time to a kernel. */
 const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
 /* Same for the weight-gradient call of this descriptor. */
 const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d);
