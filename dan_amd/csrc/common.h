@@ -24,6 +24,11 @@ typedef unsigned short bf16_t;  // raw bf16 storage
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
+// Zero-fill as an ordinary kernel launch (elementwise.hip).  Used instead of hipMemsetAsync for multi-megabyte scratch: a
+// 5.7 MB memset NODE recorded in a hipGraph did not take effect on replay (ROCm 7.2; found with rocgdb in
+// route_train_cell_kernel reading unset bucket counts), kernel nodes do.  ptr 16-byte aligned, bytes a multiple of 4.
+int danhip_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 // ---------------------------------------------------------------- error plumbing (never throws across the ABI)
 void danhip_set_error(const char* fmt, ...);
 #define DH_REQUIRE(cond, code, ...)                  \

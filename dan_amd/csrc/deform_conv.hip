@@ -287,7 +287,7 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
-  if (hipMemsetAsync(workspace, 0, sizeof(float) * nx, s) != hipSuccess) { danhip_set_error("deform_sample_bwd: memset failed"); return DANHIP_ELAUNCH; }
+  { const int zrc = danhip_zero_async(workspace, sizeof(float) * nx, s); if (zrc) return zrc; }
   if (C / deformable_group == 64) {
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);

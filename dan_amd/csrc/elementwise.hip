@@ -303,6 +303,27 @@ extern "C" int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float*
   return DANHIP_OK;
 }
 
+namespace {
+__global__ void zero_fill_kernel(uint4* __restrict__ p16, long n16, unsigned* __restrict__ tail, int ntail) {
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+}  // namespace
+
+int danhip_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return DANHIP_OK;
+  DH_REQUIRE(ptr && ((uintptr_t)ptr & 15) == 0 && (bytes & 3) == 0, DANHIP_EINVAL, "zero_async: pointer must be 16-byte aligned, size a multiple of 4");
+  const long n16 = (long)(bytes / 16);
+  const int ntail = (int)((bytes % 16) / 4);
+  long blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4*)ptr, n16, (unsigned*)((char*)ptr + n16 * 16), ntail);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
 extern "C" int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
   DH_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool2x2_fwd: bad arguments (C%%8)");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;

@@ -284,7 +284,7 @@ extern "C" int danhip_dynamic_anchor_routing_eval(const float* anchors, const fl
   DH_REQUIRE(workspace && workspace_bytes >= danhip_routing_workspace_bytes(N, B, 0), DANHIP_EWORKSPACE, "dynamic_anchor_routing_eval: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   unsigned long long* key = reinterpret_cast<unsigned long long*>(workspace);
-  if (hipMemsetAsync(key, 0, sizeof(unsigned long long) * (size_t)N * B, s) != hipSuccess) { danhip_set_error("routing: memset failed"); return DANHIP_ELAUNCH; }
+  { const int zrc = danhip_zero_async(key, sizeof(unsigned long long) * (size_t)N * B, s); if (zrc) return zrc; }
   dim3 grid((unsigned)grid1d(N), (unsigned)B);
   hipLaunchKernelGGL(route_eval_claim_kernel, grid, dim3(256), 0, s, anchors, labels, mask_in, key, (long)N, feat_height, feat_width, anchor_depth,
                      feat_strides);
@@ -310,7 +310,7 @@ extern "C" int danhip_dynamic_anchor_routing_train(const float* anchors, const f
   const size_t n = (size_t)N * B;
   int* ws = reinterpret_cast<int*>(workspace);
   int *matched = ws, *ignore_flag = ws + n, *cand = ws + 2 * n, *count = ws + 3 * n, *offset = ws + 4 * n, *cursor = ws + 5 * n, *bucket = ws + 6 * n;
-  if (hipMemsetAsync(ws, 0, sizeof(int) * 7 * n, s) != hipSuccess) { danhip_set_error("routing: memset failed"); return DANHIP_ELAUNCH; }
+  { const int zrc = danhip_zero_async(ws, sizeof(int) * 7 * n, s); if (zrc) return zrc; }
   dim3 grid((unsigned)grid1d(N), (unsigned)B);
   hipLaunchKernelGGL(route_train_pass1_kernel, grid, dim3(256), 0, s, anchors, gt_targets, labels, mask_in, matched, ignore_flag, cand, count, (long)N,
                      feat_height, feat_width, anchor_depth, feat_strides, thres, ignore_thres);

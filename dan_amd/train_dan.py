@@ -105,14 +105,6 @@ class DANTrainer(DetectorTrainer):
         self._routing_ctr = torch.zeros(1, dtype=torch.int64, device=dev)        # device-resident: advances inside a captured step too
         self._loc_scale2 = torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=dev)     # train_dan.py:452
 
-    def enable_graph(self, images_u8, *targets, warmup=2):
-        # OPEN ISSUE (round 1): the captured DAN step replays correctly at 128 x 128 (tests/test_train_models_gpu.py) but the
-        # bench-size capture (8 x 640 x 640) ended in a GPU memory access fault that the eager step does not have; until the
-        # faulting launch is identified the capture is refused above the validated size instead of risking the device.
-        if images_u8.shape[1] * images_u8.shape[2] > 256 * 256:
-            raise RuntimeError("DAN: hipGraph capture of the training step is validated up to 256x256 inputs only (open issue, see DESIGN.md)")
-        return super().enable_graph(images_u8, *targets, warmup=warmup)
-
     def loss_terms(self, images_u8, loc_targets, cls_targets, matched_gt):
         (loc1, cls1), (loc2, cls2), sizes = self.model.forward(images_u8)
         a = self.anchors
