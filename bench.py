@@ -149,19 +149,22 @@ def main():
     # resident images, outside the timed training region; every rank runs it, the slowest rank's time counts
     eval_out = None
     if not args.no_eval:
+        def timed(fn, n):
+            barrier()
+            e0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            et = time.perf_counter() - e0
+            if world > 1:
+                t = torch.tensor([et], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                et = float(t.item())
+            return et
+        n_eval = max(3, args.steps)
         for _ in range(2):
             model.predict(imgs, anchors)
-        barrier()
-        e0 = time.perf_counter()
-        n_eval = max(3, args.steps)
-        for _ in range(n_eval):
-            model.predict(imgs, anchors)
-        barrier()
-        et = time.perf_counter() - e0
-        if world > 1:
-            t = torch.tensor([et], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            et = float(t.item())
+        et = timed(lambda: model.predict(imgs, anchors), n_eval)
         eval_out = {"value": round(world * B * n_eval / et, 2), "unit": "images/sec", "batch_per_gpu": B, "ms_per_batch": round(et / n_eval * 1e3, 3),
                     "what": "single-scale inference graph (forward + softmax + box decode%s), %dx%d" % (", anchor routing" if args.model.startswith("dan") else "", S, S)}
 

@@ -49,7 +49,9 @@ class DANModel(object):
         score1 = torch.softmax(cls1, dim=-1)[..., -1]
         score2 = torch.softmax(cls2, dim=-1)[..., -1]
         boxes1 = enc.batch_decode_anchors(loc1, *anchors.anchors[:4])
-        scale = torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=loc2.device)       # eval_dan.py:384
+        if getattr(self, "_scale2", None) is None or self._scale2.device != loc2.device:
+            self._scale2 = torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=loc2.device)   # eval_dan.py:384 (kept: no per-call upload)
+        scale = self._scale2
         out_boxes, out_scores = [], []
         off = 0
         per_level = anchors.num_anchors_per_layer
