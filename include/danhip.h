@@ -182,7 +182,9 @@ int danhip_detection_loss_bwd(const float* cls, const float* loc, const float* l
                               int32_t A, void* stream);
 /* Fused multi-tensor momentum SGD over flat fp32 buffers (train_sfd.py:419-447): for element i of segment s
  * (seg_starts[s] <= i < seg_starts[s+1]): g' = (g*grad_scale + wd_coef[s]*w) * gmult[s]; v = m*v + g'; w -= lr*v.
- * l2_out (optional) += sum 0.5*wd_coef[s]*w^2 (the L2 loss term at the pre-update weights). */
+ * l2_out (optional) += sum 0.5*wd_coef[s]*w^2 (the L2 loss term at the pre-update weights).
+ * Layout contract: buffers 16-byte aligned, every seg_starts[s] and total a multiple of 4 (the trainer pads each variable to 64
+ * elements with zeros, which stay zero), so the kernel moves float4s that never straddle two variables. */
 int danhip_sgd_momentum_flat(float* w, const float* g, float* v, const int64_t* seg_starts, const float* gmult,
                              const float* wd_coef, int32_t nseg, int64_t total, float lr, float momentum, float grad_scale,
                              float* l2_out, void* stream);
