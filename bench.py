@@ -187,10 +187,16 @@ def main():
             t = json.load(open(tj)).get(label)
             if t:
                 traffic = round(t["hbm_bytes_per_launch"])
+        calib = None        # library-GEMM peak measured on a box of this pool (tools/calibrate_peaks.py), next to the datasheet peak
+        cj = os.path.join(ROOT, "profiles", "r1", "calibration.json")
+        if os.path.exists(cj):
+            cpk = max(json.load(open(cj)).get("gemm_bf16_4096_tflops", 0.0), json.load(open(cj)).get("gemm_bf16_8192_tflops", 0.0))
+            if cpk > 0:
+                calib = {"peak": cpk, "what": "hipBLASLt bf16 GEMM on this pool (profiles/r1/calibration.json)", "frac": round(achieved / cpk, 4)}
         roof = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": n // prof_steps,
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
-                "share_of_step_time": round(ms / prof_steps / (dt / args.steps * 1e3), 4)}
+                "share_of_step_time": round(ms / prof_steps / (dt / args.steps * 1e3), 4), "calibrated": calib}
         out = {
             "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
