@@ -60,6 +60,8 @@ SIGNATURES = {
     "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P, P,
                                             ctypes.c_size_t, P],
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
+    "danhip_augment_preprocess": [P, I32, I32, I32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float), I32, I32, I32, I32, I32, P, I32, I32,
+                                  P, ctypes.c_size_t, P],
     "danhip_resize_u8_linear": [P, I32, I32, P, I32, I32, I32, ctypes.c_double, ctypes.c_double, P],
     "danhip_bbox_vote": [P, P, I32, I32, ctypes.c_double, I32, P, P, P, ctypes.c_size_t, P],
     "danhip_deform_sample_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
@@ -110,6 +112,8 @@ def lib():
         L.danhip_routing_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_routing_workspace_bytes.argtypes = [I64, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_augment_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_augment_workspace_bytes.argtypes = []
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.argtypes = [I32, I32]

@@ -293,6 +293,19 @@ size_t danhip_bbox_vote_workspace_bytes(int32_t B, int32_t Nmax);
 int danhip_bbox_vote(const double* det, const int32_t* counts, int32_t B, int32_t Nmax, double iou_threshold, int32_t max_out,
                      float* out, int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* --------------------------------------------------------------------------------------------------
+ * On-device training input pipeline: the image half of preprocess_for_train
+ * (preprocessing/dan_preprocessing.py:677-733) in one pass from the decoded uint8 image [H,W,3] (RGB) to the network input
+ * [out_h,out_w,8] (16-bit, B-mean, G-mean, R-mean, 0 x5):  [0,1] conversion -> distort_color (:98-150) -> crop window with
+ * mean-colour fill (:410-565; the window may leave the image) -> legacy bilinear resize -> flip -> uint8 saturate -> means -> BGR.
+ * op_codes: 0 brightness (value = delta), 1 saturation (factor), 2 hue (delta), 3 contrast (factor; at most one), applied in
+ * the given order; the random draws themselves are the caller's (dan_amd/preprocessing/dan_preprocessing.py).
+ * ------------------------------------------------------------------------------------------------ */
+size_t danhip_augment_workspace_bytes(void);
+int danhip_augment_preprocess(const uint8_t* src, int32_t H, int32_t W, int32_t nops, const int32_t* op_codes, const float* op_values,
+                              int32_t win_y, int32_t win_x, int32_t win_h, int32_t win_w, int32_t flip, uint16_t* dst, int32_t out_h,
+                              int32_t out_w, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

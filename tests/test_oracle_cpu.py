@@ -221,3 +221,33 @@ def test_eval_host_logic_matches_oracle():
     f = io.StringIO()
     P.write_to_txt(f, det, "ev", "im")
     assert f.getvalue().splitlines() == E.format_detections(det, "ev/im.jpg")
+
+
+# ------------------------------------------------------------------------------------------------ training input pipeline
+def test_preprocess_oracle_kats():
+    """Hand-checkable facts of the restated tf.image ops and of the sampling rules (dan_preprocessing.py:98-150, 410-565, 609-733)."""
+    from oracle import preprocess as O
+    f = np.float32
+    px = np.asarray([[[1.0, 0.5, 0.25]]], f)
+    h, s, v = O.rgb_to_hsv(px[..., 0], px[..., 1], px[..., 2])
+    assert np.allclose([h[0, 0], s[0, 0], v[0, 0]], [(0.25 / 0.75) / 6, 0.75, 1.0])            # M = r: h = ((g-b)/c)/6
+    assert np.allclose(np.stack(O.hsv_to_rgb(h, s, v), -1), px, atol=1e-6)                      # round trip
+    assert np.allclose(O.adjust_saturation(px, 0.0), [[[1.0, 1.0, 1.0]]])                       # s = 0 -> grey at v
+    assert np.allclose(O.adjust_hue(px, 1.0 / 3), [[[0.25, 1.0, 0.5]]], atol=1e-6)              # +120 degrees rotates r -> g -> b
+    img = np.asarray([[[0.2, 0.4, 0.6], [0.4, 0.4, 0.2]]], f)
+    assert np.allclose(O.adjust_contrast(img, 2.0), [[[0.1, 0.4, 0.8], [0.5, 0.4, 0.0]]])       # about the per-channel mean
+    # legacy bilinear: 2 -> 4 samples at source positions 0, 0.5, 1, 1.5 (clamped)
+    ramp = np.asarray([[[0.0] * 3, [1.0] * 3]], f)
+    assert np.allclose(O.resize_bilinear_legacy(ramp, 1, 4)[0, :, 0], [0.0, 0.5, 1.0, 1.0])
+    # uint8 conversion truncates x * 255.5; means and BGR
+    assert np.array_equal(O.finish(np.asarray([[[1.0, 0.5, 0.0]]], f), False)[0, 0], [f(0) - f(103.94), f(127) - f(116.78), f(255) - f(123.68)])
+    # window rules: a window that leaves the image keeps the faces whose centre is inside, in window coordinates
+    boxes = np.asarray([[40., 40., 60., 60.], [5., 5., 15., 15.]], f)
+
+    class Fixed(O.Draws):
+        def __init__(self, ints): self.ints = list(ints)
+        def randint(self, lo, hi): v = self.ints.pop(0); assert lo <= v < max(hi, lo + 1), (lo, v, hi); return v
+    win, b = O.anchor_sample_window(100, 100, boxes, 0, 64, Fixed([-3, 20]))                    # xmin = -3 (pads 3 columns), ymin = 20
+    assert win == (20, -3, 64, 64) and b.tolist() == [[20.0, 43.0, 40.0, 63.0]]
+    flip_boxes = np.asarray([[10., 20., 30., 50.]], f)
+    assert np.array_equal(np.stack([flip_boxes[:, 0], 160 - 1. - flip_boxes[:, 3], flip_boxes[:, 2], 160 - 1. - flip_boxes[:, 1]], -1), [[10., 109., 30., 139.]])
