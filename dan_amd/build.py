@@ -51,6 +51,11 @@ def _build_variant(out, objdir, defines, force, verbose):
         r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+    import ctypes
+    try:                       # an address-space cast the host pass rejects silently leaves a kernel's host stub undefined: catch it here
+        ctypes.CDLL(out)
+    except OSError as e:
+        raise RuntimeError("%s does not load: %s" % (out, e))
     return out
 
 

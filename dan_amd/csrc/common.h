@@ -98,4 +98,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_base
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+// 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out of
+// range (0xFFFFFFFF) writes ZEROS to its LDS slot.
+__device__ __forceinline__ void bufdma16_lds(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -73,10 +73,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // FAST path tap walker (uniform): tile kt covers channels [c0, c0+64) of tap (ti, tj)
   int ti = 0, tj = 0, c0 = 0;
 
+  // FAST + stride-1 gather (every forward conv and every stride-1 data gradient): per staged row one 32-bit byte offset of the
+  // tap-(0,0) source pixel and a bit mask of the taps that fall inside the image; a tile then adds a wave-uniform tap/channel
+  // offset (computed on the scalar ALU) and selects 0xFFFFFFFF for padding taps (the buffer descriptor's range check zero-fills)
+  // — 4 VALU per row and tile instead of ~15 (64-bit address build + zero-page select).
+  const bool lean = FAST && a.dstride == 1 && a.taps <= 32;
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)((unsigned)(gridDim.y * BN) * (unsigned)a.Kpad * 2u), 0x00020000);
+  unsigned pbase[RA];
+  unsigned tmask[RA];
+  unsigned wvoff[RB];
+  if (lean) {
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      pbase[j] = (unsigned)((rn[j] + rh[j] * a.W + rw[j]) * a.C + schunk * 8) * 2u;        // may wrap for padding rows; exact for valid taps
+      unsigned mk = 0;
+      for (int t = 0; t < a.taps; ++t) {
+        const int i = (int)fdiv((unsigned)t, a.div_kw), jj = t - i * a.kw;
+        if ((unsigned)(rh[j] + i) < (unsigned)a.H && (unsigned)(rw[j] + jj) < (unsigned)a.W) mk |= 1u << t;
+      }
+      tmask[j] = mk;
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      int r = j * 32 + wave * 8 + srow;
+      if (BN < 32 && r >= BN) r = 0;
+      wvoff[j] = (unsigned)((n0 + r) * a.Kpad + schunk * 8) * 2u;
+    }
+  }
+  int tap = 0;
+
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + BM * 128;
-    if (FAST) {
+    if (FAST && lean) {
+      const unsigned toff = (unsigned)((ti * a.W + tj) * a.C + c0) * 2u;                  // wave-uniform
+      const unsigned tbit = 1u << tap;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        const unsigned voff = (tmask[j] & tbit) ? pbase[j] + toff : 0xFFFFFFFFu;
+        bufdma16_lds(rsrc_x, voff, 0u, sA + (j * 32 + wave * 8) * 128);
+      }
+    } else if (FAST) {
 #pragma unroll
       for (int j = 0; j < RA; ++j) {
         int hi = rh[j] + ti, wi = rw[j] + tj;
@@ -109,13 +149,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         glds16(src, sA + (j * 32 + wave * 8) * 128);
       }
     }
+    if (FAST && lean) {
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      if (BN >= 32 || (j * 32 + wave * 8) < BN) glds16(wrow[j] + kt * 64, sB + (j * 32 + wave * 8) * 128);
+      for (int j = 0; j < RB; ++j) {
+        if (BN >= 32 || (j * 32 + wave * 8) < BN)
+          bufdma16_lds(rsrc_w, wvoff[j], (unsigned)kt * 128u, sB + (j * 32 + wave * 8) * 128);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        if (BN >= 32 || (j * 32 + wave * 8) < BN) glds16(wrow[j] + kt * 64, sB + (j * 32 + wave * 8) * 128);
+      }
     }
     if (FAST) {                                         // advance the tap walker
       c0 += 64;
-      if (c0 == a.C) { c0 = 0; if (++tj == a.kw) { tj = 0; ++ti; } }
+      if (c0 == a.C) { c0 = 0; ++tap; if (++tj == a.kw) { tj = 0; ++ti; } }
     }
   };
 
