@@ -12,6 +12,19 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         """net/danet.py:339-380: as PyramidBox's LFPN but the fused 3x3 conv always has 256 filters."""
         return super().build_lfpn(feature_layers, skip_last, name, fused_channels=256)
 
+    def build_bi_lfpn(self, feature_layers, skip_last=3, name=None):
+        """net/danet.py:191-249 (defined on the backbone, used by no script): EVERY level but the last is merged with its
+        coarser neighbour — 1x1 'lateral' conv on the coarser map, bilinear resize to this level, add, 3x3 'fused_conv' to 256
+        channels; no activation anywhere; the last level passes through."""
+        name = name or "lfpn"
+        outs = []
+        for ind, featmap in enumerate(feature_layers[:-1]):
+            sc = "{}/fpn_{}".format(name, ind)
+            up = self.conv2d(feature_layers[ind + 1], featmap.shape[-1], (1, 1), 1, sc + "/lateral", relu=False)
+            merged = ops.resize_bilinear_add(up, featmap)                      # featmap + resize_bilinear(up, size(featmap))
+            outs.append(self.conv2d(merged, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
+        return outs + [feature_layers[-1]]
+
     def _cr(self, inputs, filters, ksize, name):
         return self.conv2d(inputs, filters, ksize, 1, name, relu=True)
 

@@ -138,6 +138,19 @@ def build_lfpn(P, feats, skip_last=3, name="lfpn", fused_channels=None):
     return list(reversed(outs)) + list(feats[skip_last:])
 
 
+def build_bi_lfpn(P, feats, skip_last=3, name="lfpn"):
+    """net/danet.py:191-249: every level but the last = fused_conv3x3->256 ( feat + resize(lateral1x1(next coarser level)) )."""
+    outs = []
+    for ind, f in enumerate(feats[:-1]):
+        sc = "{}/fpn_{}".format(name, ind)
+        up = conv(P, feats[ind + 1], f.shape[-1], (1, 1), 1, sc + "/lateral", relu=False)
+        m = f + T.resize_bilinear_legacy(up, f.shape[1], f.shape[2])
+        if P.emulate_bf16:
+            m = T.round_bf16(m, True, True)
+        outs.append(conv(P, m, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
+    return outs + [feats[-1]]
+
+
 def context_pred_module(P, feats):
     """PyramidBox CPM — net/pb_net.py:158-183 (hard-coded 1024 channels)."""
     def block(x, nc, last_div, name):
@@ -194,6 +207,23 @@ def se_inception_block_v2(P, x, name):
     d = conv(P, x, 256, (1, 1), 1, name + "/conv_1x1_down", relu=True)
     y = deform_conv_2d(P, d, 256, name + "/deform_conv", dg=4, no_bias=False)
     return conv(P, torch.relu(y), c, (1, 1), 1, name + "/conv_1x1_up", relu=True) + x
+
+
+def features_conv_only(P, feats, stage1=None, name=None):
+    """net/danet_deform.py:328-366: *_conv_only variants — (stage 2: the C//3 + (C - C//3) input mix, then) one deformable 3x3 + ReLU."""
+    outs = []
+    for i, f in enumerate(feats):
+        c = f.shape[-1]
+        if stage1 is None:
+            nm = "{}/predict_stage1_conv{}".format(name or "prediction_modules_stage1", i)
+        else:
+            n2 = name or "prediction_modules_stage2"
+            s1 = conv(P, stage1[i].detach(), c // 3, (1, 1), 1, "{}/satge1_conv_1x1_{}".format(n2, i), relu=True)
+            rs = conv(P, f, c - c // 3, (1, 1), 1, "{}/residual_conv_1x1_{}".format(n2, i), relu=True)
+            f = torch.cat([s1, rs], dim=-1)
+            nm = "{}/predict_stage2_conv{}".format(n2, i)
+        outs.append(torch.relu(deform_conv_2d(P, f, c, nm, dg=4, no_bias=False)))
+    return outs
 
 
 def get_features_stage1(P, feats, block, name="prediction_modules_stage1"):

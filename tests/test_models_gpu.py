@@ -141,3 +141,48 @@ def test_dan_forward_parity_ragged_sizes(h, w, dev):
     for got, want, name in ((l1, l1r, "stage1/loc"), (c1, c1r, "stage1/cls"), (l2, l2r, "stage2/loc"), (c2, c2r, "stage2/cls")):
         assert got.shape == want.shape
         _check(got, want, name, 0.04)
+
+
+def test_unused_variants_bi_lfpn_and_conv_only_heads(dev):
+    """SURVEY §8f row 4, the variants that need no new kernel: build_bi_lfpn (net/danet.py:191-249) and the *_conv_only deformable
+    heads (net/danet_deform.py:328-366) — forward parity against the oracle graph on identical weights."""
+    from dan_amd import synthetic
+    from dan_amd.net import danet_deform, sfd_net
+    from dan_amd.net.variables import VariableStore
+    imgs = synthetic.make_images(1, 64, 96, "cpu", seed=9)
+    x = ON.preprocess_synthetic(imgs)
+
+    def fwd(P, xx):
+        feats = ON.get_featmaps(P, xx)
+        bi = ON.build_bi_lfpn(P, feats, name="bi_lfpn")
+        s1 = ON.features_conv_only(P, bi)
+        s2 = ON.features_conv_only(P, bi, stage1=s1)
+        return bi, s1, s2
+    P = _weights(fwd, x, 41)
+    g = torch.Generator().manual_seed(6)
+    for n in P.t:                                  # non-zero offsets so the gather path is exercised
+        if "_conv" in n and n.endswith("/conv2d/kernel") and "predict_stage" in n:
+            P.t[n] = 0.004 * torch.randn(P.t[n].shape, generator=g)     # sub-pixel .. ~1 px offsets: their bf16 storage stays a small effect
+    with torch.no_grad():
+        bi_r, s1_r, s2_r = fwd(ON.Params(P.t, emulate_bf16=True), x.to(torch.bfloat16).float())
+    vs = VariableStore(device=dev)
+    b = danet_deform.VGG16Backbone("channels_last", variables=vs)
+    with torch.no_grad():
+        xin = sfd_net.prepare_input(imgs.to(dev))
+        def run():
+            feats = b.get_featmaps(xin, training=False)
+            bi = b.build_bi_lfpn(feats, name="bi_lfpn")
+            s1 = b.get_features_stage1_conv_only(bi)
+            s2 = b.get_features_stage2_conv_only(s1, bi)
+            return bi, s1, s2
+        run()                                      # creates the variables
+        vs.load_tf_named(P.t)
+        bi, s1, s2 = run()
+    assert set(n for n, _ in vs.named()) == set(P.t.keys())
+    for name, got, want in (("bi_lfpn", bi, bi_r), ("stage1_conv_only", s1, s1_r), ("stage2_conv_only", s2, s2_r)):
+        assert len(got) == len(want) == 6
+        for i, (a, r) in enumerate(zip(got, want)):
+            assert a.shape == r.shape
+            # the conv_only heads sample un-normalised LFPN outputs (no ReLU before them): 2304-term sums of bf16-rounded samples
+            # that largely cancel, so the error is judged against a looser fraction of the (small) output scale
+            _check(a.float(), r, "%s[%d]" % (name, i), 0.06 if name == "bi_lfpn" else 0.12)
