@@ -333,8 +333,11 @@ int check_desc(const danhip_conv_desc* d) {
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv: Cin=%d must be a multiple of 8 (pad the activation)", d->Cin);
   DH_REQUIRE(d->kh >= 1 && d->kh <= 7 && d->kw >= 1 && d->kw <= 7, DANHIP_EINVAL, "conv: kernel %dx%d unsupported", d->kh, d->kw);
   DH_REQUIRE(d->stride >= 1 && d->stride <= 4, DANHIP_EINVAL, "conv: stride %d unsupported", d->stride);
-  DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
-             "conv: Ho/Wo (%d,%d) != ceil(H/s),ceil(W/s) (TF SAME)", d->Ho, d->Wo);
+  {   // output size: TF 'same' (ceil(in / s); padding derived, more on the bottom / right) or 'valid' (floor((in - k) / s) + 1, no padding)
+    const bool same = d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride;
+    const bool valid = d->H >= d->kh && d->W >= d->kw && d->Ho == (d->H - d->kh) / d->stride + 1 && d->Wo == (d->W - d->kw) / d->stride + 1;
+    DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
+  }
   DH_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * (int64_t)((d->Cout + 7) / 8 * 8) < (1ll << 31),
              DANHIP_EINVAL, "conv: tensor exceeds 2^31 elements");
   return DANHIP_OK;

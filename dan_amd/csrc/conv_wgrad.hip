@@ -236,8 +236,11 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
-  DH_REQUIRE(d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride, DANHIP_EINVAL,
-             "conv2d_bwd_weight: Ho/Wo mismatch");
+  {   // output size: TF 'same' (ceil(in / s); padding derived, more on the bottom / right) or 'valid' (floor((in - k) / s) + 1, no padding)
+    const bool same = d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride;
+    const bool valid = d->H >= d->kh && d->W >= d->kw && d->Ho == (d->H - d->kh) / d->stride + 1 && d->Wo == (d->W - d->kw) / d->stride + 1;
+    DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
+  }
   {
     const int hr = danhip_launch_wgrad_halo(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
     if (hr <= 0) return hr;

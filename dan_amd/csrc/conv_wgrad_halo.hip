@@ -391,7 +391,7 @@ int launch_wg_halo(WgHaloArgs& a, hipStream_t s) {
 }  // namespace
 
 static bool wg_halo_eligible(const danhip_conv_desc* d) {
-  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1)) return false;
+  if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W)) return false;      // 'same' 3x3 only
   const int co8 = (d->Cout + 7) / 8 * 8;
   if (d->Cin % 64 != 0 || (co8 % 64 != 0 && co8 > 64)) return false;      // thin heads (co8 < 64) run as one zero-padded 64-wide tile
   const int th = 4, tw = 32;

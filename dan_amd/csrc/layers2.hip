@@ -385,3 +385,101 @@ extern "C" int danhip_batchnorm_bwd(const uint16_t* x, const uint16_t* dy, const
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ 3x3 / stride-2 'same' max-pool
+// tf.layers.max_pooling2d([3,3],[2,2],'same') — the ResNet stem's pool_1 (net/resnet_danet.py:129).  TF 'same': out = ceil(in/2),
+// pad_before = max((out-1)*2 + 3 - in, 0) / 2; positions outside the image do not take part.  Backward (gather form, no atomics):
+// an input pixel collects dy of every window whose FIRST maximum (window scan order) it is.
+namespace {
+__device__ __forceinline__ int pool3_pad(int in, int out) { int t = (out - 1) * 2 + 3 - in; return t > 0 ? t / 2 : 0; }
+
+__global__ void maxpool3x3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int cg = C / 8, pt = pool3_pad(H, Ho), pl = pool3_pad(W, Wo);
+  const long total = (long)N * Ho * Wo * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % cg);
+    long p = idx / cg;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+    for (int dh = 0; dh < 3; ++dh)
+      for (int dw = 0; dw < 3; ++dw) {
+        const int h = ho * 2 - pt + dh, w = wo * 2 - pl + dw;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          float f[8];
+          unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + h) * W + w) * C + g * 8), f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], f[i]);
+        }
+      }
+    *reinterpret_cast<uint4*>(y + idx * 8) = pack8(m);
+  }
+}
+
+__global__ void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H, int W,
+                                        int C, int Ho, int Wo) {
+  const int cg = C / 8, pt = pool3_pad(H, Ho), pl = pool3_pad(W, Wo);
+  const long total = (long)N * H * W * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % cg);
+    long p = idx / cg;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // windows containing (h, w): ho with ho*2 - pt <= h <= ho*2 - pt + 2
+    for (int ho = (h + pt - 2 + 1) / 2; ho <= (h + pt) / 2; ++ho) {
+      if (ho < 0 || ho >= Ho) continue;
+      for (int wo = (w + pl - 2 + 1) / 2; wo <= (w + pl) / 2; ++wo) {
+        if (wo < 0 || wo >= Wo) continue;
+        float best[8];
+        int bidx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bidx[i] = -1; }
+        int mine = -1;
+        for (int dh = 0; dh < 3; ++dh)
+          for (int dw = 0; dw < 3; ++dw) {
+            const int hh = ho * 2 - pt + dh, ww = wo * 2 - pl + dw;
+            if ((unsigned)hh >= (unsigned)H || (unsigned)ww >= (unsigned)W) continue;
+            if (hh == h && ww == w) mine = dh * 3 + dw;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + hh) * W + ww) * C + g * 8), f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (f[i] > best[i]) { best[i] = f[i]; bidx[i] = dh * 3 + dw; }
+          }
+        float gy[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + ((((long)n * Ho + ho) * Wo + wo) * C + g * 8)), gy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (bidx[i] == mine) acc[i] += gy[i];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + idx * 8) = pack8(acc);
+  }
+}
+}  // namespace
+
+extern "C" int danhip_maxpool3x3s2_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+  DH_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool3x3s2_fwd: bad arguments (C%%8)");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_maxpool3x3s2_same_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            void* stream) {
+  DH_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "maxpool3x3s2_bwd: bad arguments (C%%8)");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long total = (long)N * H * W * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}

@@ -13,10 +13,13 @@ from . import _lib
 from ._lib import ACT_DTYPE as ACT, BF16, F32, ConvDesc, call, ptr, stream
 
 
-def _desc(N, H, W, Cin, Cout, kh, kw, stride):
+def _desc(N, H, W, Cin, Cout, kh, kw, stride, valid=False):
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride = N, H, W, Cin, Cout, kh, kw, stride
-    d.Ho, d.Wo = -(-H // stride), -(-W // stride)
+    if valid:                       # padding='valid': no padding, floor((in - k) / s) + 1 outputs
+        d.Ho, d.Wo = (H - kh) // stride + 1, (W - kw) // stride + 1
+    else:                           # padding='same' (TF): ceil(in / s) outputs, padding derived by the library
+        d.Ho, d.Wo = -(-H // stride), -(-W // stride)
     return d
 
 
@@ -201,12 +204,12 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
         assert C % 8 == 0 and cin_real <= C
-        d = _desc(N, H, W, C, cout, kh, kw, stride)
+        d = _desc(N, H, W, C, cout, kh, kw, stride, valid)
         need_bwd = w.requires_grad or x.requires_grad
         wf, wb = packed_weights(d, w, w_param, need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
@@ -264,7 +267,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 12
+            return (None,) * 13
         db_in_wgrad = need_db and ctx.needs_input_grad[1]       # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -297,10 +300,10 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False):
+def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same"):
     """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up."""
     wp = w if isinstance(w, torch.nn.Parameter) else None
     bp = b if isinstance(b, torch.nn.Parameter) else None
@@ -309,7 +312,9 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
         raise NotImplementedError("relu + fused residual needs a separate ReLU mask in backward (y > 0 is not the mask)")
     yslot = GradSlot.__new__(GradSlot) if (track and not out_f32) else None
     pool_out = [] if (pool and relu and not out_f32 and residual is None and b is not None and w.shape[-1] % 8 == 0) else None
-    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out)
+    if padding not in ("same", "valid"):
+        raise ValueError("padding must be 'same' or 'valid'")
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out, padding == "valid")
     if yslot is not None:
         yslot.__init__(y, relu)
         y._dh_slot = yslot
@@ -370,6 +375,30 @@ def max_pool_2x2(x):
         yslot.__init__(y, xs.is_relu if xs is not None else False)
         y._dh_slot = yslot
     return y
+
+
+class _MaxPool3x3S2(torch.autograd.Function):
+    """tf.layers.max_pooling2d([3,3],[2,2],'same') — net/resnet_danet.py:129."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
+        call("danhip_maxpool3x3s2_same_fwd", ptr(x), ptr(y), N, H, W, C, stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        call("danhip_maxpool3x3s2_same_bwd", ptr(x), ptr(dy.contiguous()), ptr(dx), N, H, W, C, stream())
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool3x3S2.apply(x)
 
 
 class _L2Norm(torch.autograd.Function):

@@ -56,7 +56,8 @@ int danhip_act_dtype(void);   /* DANHIP_BF16 or DANHIP_F16 */
 typedef struct {
   int32_t N, H, W, Cin;      /* input  [N,H,W,Cin]   (Cin multiple of 8: pad the tensor otherwise)     */
   int32_t Ho, Wo, Cout;      /* output [N,Ho,Wo,Cout]                                                  */
-  int32_t kh, kw, stride;    /* TF SAME padding is derived: pad_before = max((Ho-1)*s+kh-H,0)/2        */
+  int32_t kh, kw, stride;    /* Ho/Wo = ceil(in/s): TF 'same' (pad_before = max((Ho-1)*s+kh-H,0)/2 derived);
+                                Ho/Wo = floor((in-k)/s)+1: 'valid' (no padding)                          */
 } danhip_conv_desc;
 
 /* rows/cols of the packed forward (which=0) or data-gradient (which=1) weight matrix */
@@ -278,6 +279,12 @@ int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_ta
  * boxes_sorted fp32 [B,K,4]; keep_idx int32 [B,max_out] = kept positions (-1 padded); num_keep int32 [B]. */
 int danhip_nms(const float* boxes_sorted, int32_t B, int32_t K, int32_t max_out, float iou_threshold, int32_t* keep_idx,
                int32_t* num_keep, void* stream);
+
+/* tf.layers.max_pooling2d([3,3],[2,2],'same') — the ResNet stem's pool_1 (net/resnet_danet.py:129).
+ * y [N,ceil(H/2),ceil(W/2),C]; backward routes each window's gradient to its first maximum (gather form, dx overwritten). */
+int danhip_maxpool3x3s2_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int danhip_maxpool3x3s2_same_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 void* stream);
 
 /* --------------------------------------------------------------------------------------------------
  * Test-time pipeline of eval_dan.py / eval_sfd.py

@@ -9,6 +9,7 @@ TF variable names (without the model scope), e.g. "conv1/conv1_1/conv2d/kernel" 
 synthetic weights of SURVEY §8(d) are made.
 """
 import torch
+import torch.nn.functional as F
 
 from . import tf_ops as T
 from .deform import deform_conv_forward
@@ -240,6 +241,63 @@ def get_features_stage2(P, stage1, feats, block, name="prediction_modules_stage2
         rs = conv(P, f, c - c // 3, (1, 1), 1, "{}/residual_conv_1x1_{}".format(name, i), relu=True)
         outs.append(block(P, torch.cat([s1, rs], dim=-1), "{}/predict_stage2_{}".format(name, i)))
     return outs
+
+
+# ------------------------------------------------------------------ ResNet backbone (net/resnet_danet.py:92-228), unused by the scripts
+RESNET_UNITS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def _bn(P, x, scope, training, eps=1e-5):
+    c = x.shape[-1]
+    gamma, beta = P.get(scope + "/bn/gamma", (c,), 1.0), P.get(scope + "/bn/beta", (c,), "zeros")
+    mm, mv = P.get(scope + "/bn/moving_mean", (c,), "zeros"), P.get(scope + "/bn/moving_variance", (c,), 1.0)
+    y = T.batch_norm_train(x, gamma, beta, eps)[0] if training else T.batch_norm_infer(x, gamma, beta, mm, mv, eps)
+    return T.round_bf16(y, True, True) if P.emulate_bf16 else y
+
+
+def conv_bn(P, x, filters, ksize, stride, scope, training, padding="same", relu=False):
+    """conv_bn / conv_bn_relu (net/resnet_danet.py:176-218): conv without bias -> batch_normalization -> (relu)."""
+    w = P.get(scope + "/conv2d/kernel", (ksize[0], ksize[1], x.shape[-1], filters), "glorot")
+    if P.emulate_bf16:
+        w = T.round_bf16(w, True, False)
+    y = (T.conv2d_valid if padding == "valid" else T.conv2d_same)(x, w, None, stride=stride)
+    if P.emulate_bf16:
+        y = T.round_bf16(y, True, True)
+    y = _bn(P, y, scope, training)
+    return torch.relu(y) if relu else y
+
+
+def bottleneck_block(P, x, filters, scope, training, need_reduce=True, is_root=False):
+    """net/resnet_danet.py:157-173."""
+    s = 1 if (not need_reduce) or is_root else 2
+    shortcut = conv_bn(P, x, filters * 2, (1, 1), s, scope + "/shortcut", training, "valid") if need_reduce else x
+    y = conv_bn(P, x, filters // 2, (1, 1), s, scope + "/reduce", training, "valid", relu=True)
+    y = conv_bn(P, F.pad(y, (0, 0, 1, 1, 1, 1)), filters // 2, (3, 3), 1, scope + "/block_3x3", training, "valid", relu=True)
+    y = conv_bn(P, y, filters * 2, (1, 1), 1, scope + "/increase", training)
+    out = torch.relu(y + shortcut)
+    return T.round_bf16(out, True, True) if P.emulate_bf16 else out
+
+
+def resnet_get_featmaps(P, x, depth=50, training=False):
+    """ResNetBackbone.get_featmaps (net/resnet_danet.py:114-155; freeze=False): 7x7/2 stem on the explicitly padded image, 3x3/2
+    max-pool, four bottleneck stages, two extra stride-2 stages -> six maps of 256/512/1024/2048/512/256 channels."""
+    input_depth = [128, 256, 512, 1024]
+    y = conv_bn(P, F.pad(x, (0, 0, 3, 3, 3, 3)), input_depth[0] // 2, (7, 7), 2, "block_0/conv_1", training, "valid", relu=True)
+    y = T.max_pool_3x3_s2_same(y)
+    feats, is_root = [], True
+    for ind, n_units in enumerate(RESNET_UNITS[depth]):
+        need_reduce = True
+        for u in range(1, n_units + 1):
+            y = bottleneck_block(P, y, input_depth[ind], "block_{}/conv_{}".format(ind + 1, u), training, need_reduce, is_root)
+            need_reduce, is_root = False, False
+        feats.append(y)
+    y = conv_bn(P, y, 512, (1, 1), 1, "additional_layers/conv6_1", training, relu=True)
+    y = conv_bn(P, y, 512, (3, 3), 2, "additional_layers/conv6_2", training, relu=True)
+    feats.append(y)
+    y = conv_bn(P, y, 128, (1, 1), 1, "additional_layers/conv7_1", training, relu=True)
+    y = conv_bn(P, y, 256, (3, 3), 2, "additional_layers/conv7_2", training, relu=True)
+    feats.append(y)
+    return feats
 
 
 def flatten_preds(preds, k):

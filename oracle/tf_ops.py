@@ -42,6 +42,23 @@ def conv2d_same(x, w_hwio, bias=None, stride=1, relu=False):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+def conv2d_valid(x, w_hwio, bias=None, stride=1, relu=False):
+    """tf.layers.conv2d(padding='valid'): no padding, floor((in - k) / s) + 1 outputs (net/resnet_danet.py:127,161-172)."""
+    y = F.conv2d(x.permute(0, 3, 1, 2), w_hwio.permute(3, 2, 0, 1), bias, stride=stride)
+    if relu:
+        y = torch.relu(y)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def max_pool_3x3_s2_same(x):
+    """tf.layers.max_pooling2d(x, [3,3], [2,2], 'same') — net/resnet_danet.py:129: out = ceil(in/2), TF-SAME padding with -inf."""
+    n, h, w, c = x.shape
+    pt, pb, _ = same_pad(h, 3, 2)
+    pl, pr, _ = same_pad(w, 3, 2)
+    xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb), value=float("-inf"))
+    return F.max_pool2d(xn, 3, 2).permute(0, 2, 3, 1).contiguous()
+
+
 def max_pool_2x2_same(x):
     """tf.layers.max_pooling2d(x, [2,2], [2,2], 'same') — net/sfd_net.py:132-143.
 

@@ -251,3 +251,17 @@ def test_preprocess_oracle_kats():
     assert win == (20, -3, 64, 64) and b.tolist() == [[20.0, 43.0, 40.0, 63.0]]
     flip_boxes = np.asarray([[10., 20., 30., 50.]], f)
     assert np.array_equal(np.stack([flip_boxes[:, 0], 160 - 1. - flip_boxes[:, 3], flip_boxes[:, 2], 160 - 1. - flip_boxes[:, 1]], -1), [[10., 109., 30., 139.]])
+
+
+def test_resnet_stem_op_kats():
+    """'valid' convolution and the 3x3/2 'same' max-pool of the ResNet stem (net/resnet_danet.py:120-129), by hand."""
+    from oracle import tf_ops as T
+    x = torch.arange(25, dtype=torch.float32).reshape(1, 5, 5, 1)
+    w = torch.ones((3, 3, 1, 1))
+    y = T.conv2d_valid(x, w, None, stride=2)                       # floor((5-3)/2)+1 = 2 outputs per side, no padding
+    assert y.shape == (1, 2, 2, 1) and y.flatten().tolist() == [54.0, 72.0, 144.0, 162.0]
+    p = T.max_pool_3x3_s2_same(x)                                  # odd size: pad 1 before / 1 after -> windows centred on 0, 2, 4
+    assert p.shape == (1, 3, 3, 1) and p.flatten().tolist() == [6.0, 8.0, 9.0, 16.0, 18.0, 19.0, 21.0, 23.0, 24.0]
+    x4 = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4, 1)
+    p4 = T.max_pool_3x3_s2_same(x4)                                # even size: pad 0 before / 1 after -> windows start at 0, 2
+    assert p4.flatten().tolist() == [10.0, 11.0, 14.0, 15.0]
