@@ -62,6 +62,8 @@ SIGNATURES = {
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
     "danhip_augment_preprocess": [P, I32, I32, I32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float), I32, I32, I32, I32, I32, P, I32, I32,
                                   P, ctypes.c_size_t, P],
+    "danhip_deform_psroi_pool_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, FL, FL, I32, I32, P],
+    "danhip_deform_psroi_pool_bwd": [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, FL, FL, I32, I32, P],
     "danhip_maxpool3x3s2_same_fwd": [P, P, I32, I32, I32, I32, P],
     "danhip_maxpool3x3s2_same_bwd": [P, P, P, I32, I32, I32, I32, P],
     "danhip_resize_u8_linear": [P, I32, I32, P, I32, I32, I32, ctypes.c_double, ctypes.c_double, P],

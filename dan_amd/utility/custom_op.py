@@ -88,3 +88,47 @@ def deform_conv_2d(inputs, num_outputs, kernel_size_h=3, kernel_size_w=3, stride
     kernel = variables.get(name + "/kernel", (num_outputs, cin, kernel_size_h, kernel_size_w), kernel_initializer)
     bias = None if no_bias else variables.get(name + "/bias", (num_outputs,), "zeros")
     return deform_conv_op(inputs, kernel, offset, [1, 1, dilate_rate, dilate_rate], "SAME", [1, 1, stride, stride], 1, deformable_group, bias=bias, relu=relu)
+
+
+class _DeformPSROIPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, rois, trans, cfg):
+        spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std, no_trans = cfg
+        B, C, H, W = data.shape
+        R = rois.shape[0]
+        ncls = 1 if no_trans else trans.shape[1] // 2
+        top = torch.empty((R, output_dim, pooled_size, pooled_size), dtype=torch.float32, device=data.device)
+        cnt = torch.empty_like(top)
+        call("danhip_deform_psroi_pool_fwd", ptr(data), ptr(rois), ptr(trans), ptr(top), ptr(cnt), R, C, H, W, output_dim, group_size, pooled_size,
+             part_size, sample_per_part, float(spatial_scale), float(trans_std), int(no_trans), ncls, stream())
+        ctx.save_for_backward(data, rois, trans, cnt)
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(cnt)
+        return top, cnt
+
+    @staticmethod
+    def backward(ctx, grad, _):
+        data, rois, trans, cnt = ctx.saved_tensors
+        spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std, no_trans = ctx.cfg
+        B, C, H, W = data.shape
+        R = rois.shape[0]
+        ncls = 1 if no_trans else trans.shape[1] // 2
+        dd = torch.empty_like(data)
+        dt = torch.empty_like(trans)
+        call("danhip_deform_psroi_pool_bwd", ptr(grad.contiguous()), ptr(cnt), ptr(data), ptr(rois), ptr(trans), ptr(dd), ptr(dt), B, R, C, H, W,
+             output_dim, group_size, pooled_size, part_size, sample_per_part, float(spatial_scale), float(trans_std), int(no_trans), ncls, stream())
+        return dd, None, (None if no_trans else dt), None
+
+
+def deform_psroi_pool(data, rois, trans, spatial_scale, output_dim, group_size, pooled_size, part_size=0, sample_per_part=1, trans_std=0.0,
+                      no_trans=False):
+    """custom_op.deform_psroi_pool (utility/custom_op.py:93; DeformPSROIPool cpp/Deform/deform_psroi_pooling_op.cc:37-79) with the TF op's
+    tensors: data fp32 NCHW, rois fp32 [R,5], trans fp32 [R,2*num_classes,part_size,part_size] -> (top_data, mapping_channel); gradients
+    w.r.t. data and trans as registered at custom_op.py:97-126 (none for rois)."""
+    for t, nd, what in ((data, 4, "data"), (rois, 2, "rois"), (trans, 4, "trans")):
+        if t.dim() != nd:
+            raise ValueError("%s must be %d-dimensional (deform_psroi_pooling_op.cc:182-192)" % (what, nd))
+    if data.dtype != torch.float32 or rois.dtype != torch.float32 or trans.dtype != torch.float32:
+        raise ValueError("deform_psroi_pool: float32 tensors (the op's T)")
+    cfg = (float(spatial_scale), int(output_dim), int(group_size), int(pooled_size), int(part_size), int(sample_per_part), float(trans_std), bool(no_trans))
+    return _DeformPSROIPool.apply(data.contiguous(), rois.contiguous(), trans.contiguous(), cfg)

@@ -280,6 +280,19 @@ int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_ta
 int danhip_nms(const float* boxes_sorted, int32_t B, int32_t K, int32_t max_out, float iou_threshold, int32_t* keep_idx,
                int32_t* num_keep, void* stream);
 
+/* DeformPSROIPool / DeformPSROIPoolGrad (cpp/Deform/deform_psroi_pooling_op.cc:37-97; utility/custom_op.py:93-126):
+ * the TF op's tensors and attributes as they are — data fp32 NCHW [B,C,H,W], rois fp32 [R,5] (batch index, x1, y1, x2, y2), trans fp32
+ * [R,2*num_classes,part_size,part_size] (NULL allowed when no_trans) -> top_data, mapping_channel (sample count) fp32
+ * [R,output_dim,pooled_size,pooled_size]; num_classes = no_trans ? 1 : trans.dim(1)/2.  The backward zeroes data_diff [B,C,H,W] /
+ * trans_diff and scatters with fp32 atomics like the reference.  Buffers 16-byte aligned. */
+int danhip_deform_psroi_pool_fwd(const float* data, const float* rois, const float* trans, float* top_data, float* mapping_channel, int32_t R,
+                                 int32_t C, int32_t H, int32_t W, int32_t output_dim, int32_t group_size, int32_t pooled_size, int32_t part_size,
+                                 int32_t sample_per_part, float spatial_scale, float trans_std, int32_t no_trans, int32_t num_classes, void* stream);
+int danhip_deform_psroi_pool_bwd(const float* top_diff, const float* mapping_channel, const float* data, const float* rois, const float* trans,
+                                 float* data_diff, float* trans_diff, int32_t B, int32_t R, int32_t C, int32_t H, int32_t W, int32_t output_dim,
+                                 int32_t group_size, int32_t pooled_size, int32_t part_size, int32_t sample_per_part, float spatial_scale,
+                                 float trans_std, int32_t no_trans, int32_t num_classes, void* stream);
+
 /* tf.layers.max_pooling2d([3,3],[2,2],'same') — the ResNet stem's pool_1 (net/resnet_danet.py:129).
  * y [N,ceil(H/2),ceil(W/2),C]; backward routes each window's gradient to its first maximum (gather form, dx overwritten). */
 int danhip_maxpool3x3s2_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

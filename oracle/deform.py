@@ -177,3 +177,124 @@ def deform_conv_backward(x, w_oihw, offset, dy, stride=1, dilation=1, dg=1):
     col = deform_im2col(x, offset, kh, kw, stride, dilation, dg).reshape(B, C * T, Ho * Wo)
     dw = torch.einsum("bon,bkn->ok", dy.reshape(B, co, Ho * Wo), col).reshape(co, ci, kh, kw)
     return dx, dw, doffset
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Deformable PS-ROI pooling — cpp/Deform/deform_psroi_pooling_op_gpu.cu:47-125 (forward), :187-300 (backward); numpy, one output
+# element at a time, the float / double promotions of the CUDA source kept (float data, double-typed literals, C round()).
+def _psroi_bin(rois, trans, n, ctop, ph, pw, at, backward):
+    import numpy as np
+    f = np.float32
+    r = rois[n]
+    rnd = lambda v: f(np.floor(abs(float(v)) + 0.5) * (1.0 if v >= 0 else -1.0))             # C round(): half away from zero
+    scale = f(at["spatial_scale"])
+    roi_start_w = f(np.float64(f(rnd(r[1]) * scale)) - 0.5)
+    roi_start_h = f(np.float64(f(rnd(r[2]) * scale)) - 0.5)
+    roi_end_w = f(np.float64(f(f(np.float64(rnd(r[3])) + 1.) * scale)) - 0.5)
+    roi_end_h = f(np.float64(f(f(np.float64(rnd(r[4])) + 1.) * scale)) - 0.5)
+    if backward:
+        roi_w, roi_h = max(f(roi_end_w - roi_start_w), f(0.1)), max(f(roi_end_h - roi_start_h), f(0.1))
+    else:
+        roi_w, roi_h = f(max(np.float64(f(roi_end_w - roi_start_w)), 0.1)), f(max(np.float64(f(roi_end_h - roi_start_h)), 0.1))
+    P, spp, part, G = at["pooled_size"], at["sample_per_part"], at["part_size"], at["group_size"]
+    bin_h, bin_w = f(roi_h / f(P)), f(roi_w / f(P))
+    sub_h, sub_w = f(bin_h / f(spp)), f(bin_w / f(spp))
+    part_h = int(np.floor(f(f(f(ph) / f(P)) * f(part))))
+    part_w = int(np.floor(f(f(f(pw) / f(P)) * f(part))))
+    ncls = at["num_classes"]
+    class_id = ctop // (at["output_dim"] // ncls)
+    if at["no_trans"]:
+        tx = ty = f(0)
+    else:
+        tx = f(trans[n, class_id * 2, part_h, part_w] * f(at["trans_std"]))
+        ty = f(trans[n, class_id * 2 + 1, part_h, part_w] * f(at["trans_std"]))
+    wstart = f(f(f(pw) * bin_w) + roi_start_w)
+    wstart = f(wstart + f(tx * roi_w))
+    hstart = f(f(f(ph) * bin_h) + roi_start_h)
+    hstart = f(hstart + f(ty * roi_h))
+    gw = min(max(int(np.floor(f(f(f(pw) * f(G)) / f(P)))), 0), G - 1)
+    gh = min(max(int(np.floor(f(f(f(ph) * f(G)) / f(P)))), 0), G - 1)
+    return dict(b=int(r[0]), roi_w=roi_w, roi_h=roi_h, wstart=wstart, hstart=hstart, sub_w=sub_w, sub_h=sub_h, part_h=part_h, part_w=part_w,
+                class_id=class_id, gw=gw, gh=gh)
+
+
+def _psroi_samples(bn, at, H, W):
+    import numpy as np
+    f = np.float32
+    for ih in range(at["sample_per_part"]):
+        for iw in range(at["sample_per_part"]):
+            w = f(bn["wstart"] + f(f(iw) * bn["sub_w"]))
+            h = f(bn["hstart"] + f(f(ih) * bn["sub_h"]))
+            if float(w) < -0.5 or float(w) > W - 0.5 or float(h) < -0.5 or float(h) > H - 0.5:
+                continue
+            w = f(min(max(float(w), 0.), W - 1.))
+            h = f(min(max(float(h), 0.), H - 1.))
+            yield w, h
+
+
+def deform_psroi_pool_forward(data, rois, trans, **at):
+    """data [B,C,H,W], rois [R,5], trans [R,2*ncls,part,part] (float32 numpy) -> (top_data, mapping_channel) [R,output_dim,P,P]."""
+    import numpy as np
+    f = np.float32
+    B, C, H, W = data.shape
+    R, P, OD, G = rois.shape[0], at["pooled_size"], at["output_dim"], at["group_size"]
+    at = dict(at, num_classes=1 if at["no_trans"] else trans.shape[1] // 2)
+    top, cnt = np.zeros((R, OD, P, P), f), np.zeros((R, OD, P, P), f)
+    for n in range(R):
+        for ctop in range(OD):
+            for ph in range(P):
+                for pw in range(P):
+                    bn = _psroi_bin(rois, trans, n, ctop, ph, pw, at, False)
+                    d = data[bn["b"], (ctop * G + bn["gh"]) * G + bn["gw"]]
+                    s, c = f(0), 0
+                    for w, h in _psroi_samples(bn, at, H, W):
+                        x1, x2, y1, y2 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
+                        dx, dy = f(w - f(x1)), f(h - f(y1))
+                        o = f(1)
+                        val = f(f(f(f(o - dx) * f(o - dy)) * d[y1, x1]) + f(f(f(o - dx) * dy) * d[y2, x1]))
+                        val = f(val + f(f(dx * f(o - dy)) * d[y1, x2]))
+                        val = f(val + f(f(dx * dy) * d[y2, x2]))
+                        s = f(s + val)
+                        c += 1
+                    top[n, ctop, ph, pw] = f(0) if c == 0 else f(s / f(c))
+                    cnt[n, ctop, ph, pw] = c
+    return top, cnt
+
+
+def deform_psroi_pool_backward(data, rois, trans, top_count, top_diff, **at):
+    """-> (data_diff [B,C,H,W], trans_diff like trans); float64 accumulation (the device uses fp32 atomics in arbitrary order)."""
+    import numpy as np
+    f = np.float32
+    B, C, H, W = data.shape
+    R, P, OD, G = rois.shape[0], at["pooled_size"], at["output_dim"], at["group_size"]
+    at = dict(at, num_classes=1 if at["no_trans"] else trans.shape[1] // 2)
+    dd = np.zeros(data.shape, np.float64)
+    dt = np.zeros(trans.shape, np.float64)
+    for n in range(R):
+        for ctop in range(OD):
+            for ph in range(P):
+                for pw in range(P):
+                    if top_count[n, ctop, ph, pw] <= 0:
+                        continue
+                    bn = _psroi_bin(rois, trans, n, ctop, ph, pw, at, True)
+                    dv = f(top_diff[n, ctop, ph, pw] / top_count[n, ctop, ph, pw])
+                    c = (ctop * G + bn["gh"]) * G + bn["gw"]
+                    d = data[bn["b"], c]
+                    for w, h in _psroi_samples(bn, at, H, W):
+                        x0, x1, y0, y1 = int(np.floor(w)), int(np.ceil(w)), int(np.floor(h)), int(np.ceil(h))
+                        dx, dy = f(w - f(x0)), f(h - f(y0))
+                        o = f(1)
+                        dd[bn["b"], c, y0, x0] += f(f(f(o - dx) * f(o - dy)) * dv)
+                        dd[bn["b"], c, y1, x0] += f(f(f(o - dx) * dy) * dv)
+                        dd[bn["b"], c, y0, x1] += f(f(dx * f(o - dy)) * dv)
+                        dd[bn["b"], c, y1, x1] += f(f(dx * dy) * dv)
+                        if at["no_trans"]:
+                            continue
+                        U00, U01, U10, U11 = d[y0, x0], d[y1, x0], d[y0, x1], d[y1, x1]
+                        gx = f(f(f(f(f(f(U11 * dy) + f(U10 * f(o - dy))) - f(U01 * dy)) - f(U00 * f(o - dy))) * f(at["trans_std"])) * dv)
+                        gx = f(gx * bn["roi_w"])
+                        gy = f(f(f(f(f(f(U11 * dx) + f(U01 * f(o - dx))) - f(U10 * dx)) - f(U00 * f(o - dx))) * f(at["trans_std"])) * dv)
+                        gy = f(gy * bn["roi_h"])
+                        dt[n, bn["class_id"] * 2, bn["part_h"], bn["part_w"]] += gx
+                        dt[n, bn["class_id"] * 2 + 1, bn["part_h"], bn["part_w"]] += gy
+    return dd.astype(f), dt.astype(f)

@@ -265,3 +265,25 @@ def test_resnet_stem_op_kats():
     x4 = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4, 1)
     p4 = T.max_pool_3x3_s2_same(x4)                                # even size: pad 0 before / 1 after -> windows start at 0, 2
     assert p4.flatten().tolist() == [10.0, 11.0, 14.0, 15.0]
+
+
+def test_psroi_pool_oracle_kat():
+    """DeformPSROIPool by hand (deform_psroi_pooling_op_gpu.cu:47-125): one ROI over a 2x2 map, one bin."""
+    from oracle import deform as OD
+    data = np.asarray([[[[1., 2.], [3., 4.]]]], np.float32)
+    rois = np.asarray([[0., 0., 0., 1., 1.]], np.float32)
+    trans = np.zeros((1, 2, 1, 1), np.float32)
+    at = dict(spatial_scale=1.0, output_dim=1, group_size=1, pooled_size=1, part_size=1, trans_std=0.0, no_trans=True)
+    # ROI [-0.5, 1.5): one sample at (-0.5, -0.5) -> clamped to pixel (0, 0)
+    top, cnt = OD.deform_psroi_pool_forward(data, rois, trans, sample_per_part=1, **at)
+    assert top.flatten().tolist() == [1.0] and cnt.flatten().tolist() == [1.0]
+    # 2x2 samples at {-0.5 -> 0, 0.5}: 1, 1.5, 2, 2.5 -> mean 1.75
+    top, cnt = OD.deform_psroi_pool_forward(data, rois, trans, sample_per_part=2, **at)
+    assert top.flatten().tolist() == [1.75] and cnt.flatten().tolist() == [4.0]
+    # a shift of +0.25 roi widths in x (trans_std 1): samples at x = 0, 1 -> 1, 2, 2, 3 -> mean 2... with y in {0, 0.5}: (1+2+2+3)/4
+    at2 = dict(at, no_trans=False, trans_std=1.0)
+    trans[0, 0, 0, 0] = 0.25
+    top, cnt = OD.deform_psroi_pool_forward(data, rois, trans, sample_per_part=2, **at2)
+    assert top.flatten().tolist() == [2.0]
+    dd, dt = OD.deform_psroi_pool_backward(data, rois, trans, cnt, np.ones_like(top), sample_per_part=2, **at2)
+    assert np.allclose(dd[0, 0], [[0.375, 0.375], [0.125, 0.125]]) and np.isclose(dd.sum(), 1.0)
