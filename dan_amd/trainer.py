@@ -147,10 +147,14 @@ def init_distributed():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # DANHIP_DIST_BACKEND=gloo: the test hook that runs several ranks on ONE GPU (RCCL refuses duplicate devices; gloo stages
+        # CUDA tensors through the host), tests/test_ddp_gpu.py
+        backend = os.environ.get("DANHIP_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
     return rank, world, local
