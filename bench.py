@@ -168,6 +168,23 @@ def main():
         eval_out = {"value": round(world * B * n_eval / et, 2), "unit": "images/sec", "batch_per_gpu": B, "ms_per_batch": round(et / n_eval * 1e3, 3),
                     "what": "single-scale inference graph (forward + softmax + box decode%s), %dx%d" % (", anchor routing" if args.model.startswith("dan") else "", S, S)}
 
+    # ---- target-encoder leg (rank 0): anchor_encoder_fn for the batch the step consumes (the reference runs it per image in tf.data on
+    # the CPU; here it is one library call per batch that a pipeline would issue on a side stream).  Not part of `value`.
+    enc_out = None
+    if rank == 0 and not args.no_eval:
+        enc_fn = {"sfd": lambda: anchors.encode_batch(gts)}.get(args.model)
+        if enc_fn is not None:
+            for _ in range(3):
+                enc_fn()
+            torch.cuda.synchronize()
+            e0 = time.perf_counter()
+            for _ in range(20):
+                enc_fn()
+            torch.cuda.synchronize()
+            et = (time.perf_counter() - e0) / 20
+            enc_out = {"value": round(B / et, 1), "unit": "images/sec", "ms_per_batch": round(et * 1e3, 3), "gt_boxes_in_batch": int(sum(g.shape[0] for g in gts)),
+                       "what": "IoU + small-mining match + target encode for the batch, one call (danhip_encode_anchors_batched), bit-exact index work"}
+
     if rank == 0:
         lv = trainer.loss_values()
         first = [k for k in lv if k not in ("l2", "total")][0]
@@ -210,6 +227,8 @@ def main():
         }
         if eval_out:
             out["eval"] = eval_out
+        if enc_out:
+            out["target_encode"] = enc_out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -85,6 +85,8 @@ SIGNATURES = {
     "danhip_small_mining_match": [P, I32, I32, FL, FL, FL, I32, FL, P, P, P, ctypes.c_size_t, P],
     "danhip_encode_anchors": [P, P, P, P, P, P, P, P, P, I32, FL, FL, FL, FL, FL, P],
     "danhip_decode_anchors": [P, P, P, P, P, P, I32, I32, FL, FL, FL, FL, P],
+    "danhip_encode_anchors_batched": [P] * 11 + [I32, I32, I32, I32, I32, FL, FL, FL, I32, FL, FL, FL, FL, FL, FL, P, P, P, P, P,
+                                                 ctypes.c_size_t, P],
 }
 
 _lib = None
@@ -113,6 +115,8 @@ def lib():
         L.danhip_conv_wgrad_kernel_label.restype = ctypes.c_char_p
         L.danhip_conv_wgrad_kernel_label.argtypes = [DESC]
         L.danhip_match_workspace_bytes.argtypes = [I32, I32]
+        L.danhip_encode_anchors_batched_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_encode_anchors_batched_workspace_bytes.argtypes = [I32, I32, I32]
         L.danhip_routing_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_routing_workspace_bytes.argtypes = [I64, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t

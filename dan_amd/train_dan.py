@@ -128,8 +128,5 @@ class DANTrainer(DetectorTrainer):
 def encode_batch_dan(anchors, gt_boxes_list):
     """anchor_encoder_fn of train_dan.py:206 per image -> (loc_targets [B,A,4], cls_targets [B,A] int32, matched_gt [B,A,4])."""
     ymin, xmin, ymax, xmax, inside = anchors.anchors
-    loc, cls, mgt = [], [], []
-    for b in gt_boxes_list:
-        t, l, _, m = anchors.enc.encode_anchors(b.to(ymin.device), ymin, xmin, ymax, xmax, inside, match_mining=False)
-        loc.append(t); cls.append(l); mgt.append(m)
-    return torch.stack(loc), torch.stack(cls), torch.stack(mgt)
+    t, l, _, m = anchors.enc.encode_anchors_batch(gt_boxes_list, ymin, xmin, ymax, xmax, inside, match_mining=False)
+    return t, l, m

@@ -51,17 +51,11 @@ class PBAnchorTargets(object):
 
     def encode_batch(self, gt_boxes_list):
         enc = self.face.enc
-        out = {k: ([], [], []) for k in ("face", "head", "body")}
         fa, ha, ba = self.face.anchors, self._sub(self.head_off), self._sub(self.body_off)
-        for b in gt_boxes_list:
-            b = b.to(self.device)
-            t, l, s, _ = enc.encode_anchors(b, *fa, match_mining=True)
-            out["face"][0].append(t); out["face"][1].append(l); out["face"][2].append(s)
-            t, l, s, _ = enc.encode_pa_anchors(b, *ha, 0.35, 0.35, match_mining=False, scale=2.)       # train_pb.py:218
-            out["head"][0].append(t); out["head"][1].append(l); out["head"][2].append(s)
-            t, l, s, _ = enc.encode_pa_anchors(b, *ba, 0.35, 0.35, match_mining=False, scale=4.)       # train_pb.py:223
-            out["body"][0].append(t); out["body"][1].append(l); out["body"][2].append(s)
-        return {k: tuple(torch.stack(v) for v in out[k]) for k in out}
+        gts = [b.to(self.device) for b in gt_boxes_list]
+        return {"face": enc.encode_anchors_batch(gts, *fa, match_mining=True)[:3],
+                "head": enc.encode_pa_anchors_batch(gts, *ha, 0.35, 0.35, match_mining=False, scale=2.)[:3],       # train_pb.py:218
+                "body": enc.encode_pa_anchors_batch(gts, *ba, 0.35, 0.35, match_mining=False, scale=4.)[:3]}       # train_pb.py:223
 
 
 from .train_sfd import DetectorTrainer  # noqa: E402

@@ -44,11 +44,8 @@ class AnchorConfig(object):
     def encode_batch(self, gt_boxes_list, match_mining=True):
         """anchor_encoder_fn of train_sfd.py:206 applied per image -> loc_targets [B,A,4], cls_targets [B,A] int32, match_scores [B,A]."""
         ymin, xmin, ymax, xmax, inside = self.anchors
-        loc, cls, sc = [], [], []
-        for b in gt_boxes_list:
-            t, l, s, _ = self.enc.encode_anchors(b.to(ymin.device), ymin, xmin, ymax, xmax, inside, match_mining=match_mining)
-            loc.append(t); cls.append(l); sc.append(s)
-        return torch.stack(loc), torch.stack(cls), torch.stack(sc)
+        t, l, s, _ = self.enc.encode_anchors_batch(gt_boxes_list, ymin, xmin, ymax, xmax, inside, match_mining=match_mining)
+        return t, l, s
 
 
 class SFDModel(object):

@@ -118,6 +118,58 @@ class AnchorEncoder(object):
              ps[0], ps[1], ps[2], ps[3], float(scale), stream())
         return targets, labels, scores, mgt
 
+    def _encode_batch(self, bboxes_list, anchors4, match_anchors4, inside_mask, ignore_thr, pos_thr, match_mining, scale):
+        """The per-image map of anchor_encoder_fn over a batch as ONE library call (danhip_encode_anchors_batched): the images'
+        sequential hard-face compensation passes run side by side.  Row b equals _encode(bboxes_list[b], ...) bit for bit."""
+        B = len(bboxes_list)
+        rows = []
+        for b in bboxes_list:
+            b = torch.as_tensor(b, dtype=torch.float32).reshape(-1, 4)
+            rows.append(b if b.shape[0] > 0 else torch.tensor([[0., 0., 1., 1.]], dtype=torch.float32, device=b.device))  # :286 / :347
+        counts = [int(r.shape[0]) for r in rows]
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        gt = torch.cat([r.to(self.device) for r in rows]).contiguous()
+        goff = torch.tensor(offs, dtype=torch.int32).to(self.device, non_blocking=True)
+        ymin, xmin, ymax, xmax = [t.contiguous() for t in anchors4]
+        m4 = [None] * 4 if match_anchors4 is anchors4 else [t.contiguous() for t in match_anchors4]
+        A = ymin.numel()
+        im = inside_mask.to(torch.uint8).contiguous() if inside_mask is not None else None
+        targets = torch.empty((B, A, 4), dtype=torch.float32, device=self.device)
+        labels = torch.empty((B, A), dtype=torch.int32, device=self.device)
+        scores = torch.empty((B, A), dtype=torch.float32, device=self.device)
+        mgt = torch.empty((B, A, 4), dtype=torch.float32, device=self.device)
+        n = _lib.lib().danhip_encode_anchors_batched_workspace_bytes(B, A, offs[-1])
+        ws = torch.empty((n + 7) // 8, dtype=torch.int64, device=self.device)
+        ps = self._prior_scaling
+        call("danhip_encode_anchors_batched", ptr(ymin), ptr(xmin), ptr(ymax), ptr(xmax), ptr(m4[0]), ptr(m4[1]), ptr(m4[2]), ptr(m4[3]), ptr(im),
+             ptr(gt), ptr(goff), B, A, offs[-1], max(counts), int(bool(match_mining)), 0., float(ignore_thr), float(pos_thr), 6, 0.3, ps[0], ps[1],
+             ps[2], ps[3], float(scale), ptr(targets), ptr(labels), ptr(scores), ptr(mgt), ptr(ws), n, stream())
+        return targets, labels, scores, mgt
+
+    def encode_anchors_batch(self, bboxes_list, anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax, inside_mask, match_mining=False):
+        """encode_anchors (anchor_manipulator.py:275-326) for a list of images -> ([B,A,4], [B,A] int32, [B,A], [B,A,4])."""
+        a4 = (anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax)
+        return self._encode_batch(bboxes_list, a4, a4, inside_mask, self._ignore_threshold, self._positive_threshold, match_mining, 1.0)
+
+    def encode_pa_anchors_batch(self, bboxes_list, anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax, inside_mask, ignore_threshold,
+                                positive_threshold, match_mining=True, scale=1.):
+        """encode_pa_anchors (anchor_manipulator.py:328-387) for a list of images."""
+        a4 = (anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax)
+        return self._encode_batch(bboxes_list, a4, self._pa_match_anchors(a4, scale), inside_mask, ignore_threshold, positive_threshold,
+                                  match_mining, scale)
+
+    @staticmethod
+    def _pa_match_anchors(a4, scale):
+        anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax = a4
+        h = anchors_ymax - anchors_ymin + 1.0
+        w = anchors_xmax - anchors_xmin + 1.0
+        cy = (anchors_ymin + anchors_ymax) / 2.0
+        cx = (anchors_xmin + anchors_xmax) / 2.0
+        hs, ws = h / float(scale), w / float(scale)
+        return (cy - (hs - 1.0) / 2.0, cx - (ws - 1.0) / 2.0, cy + (hs - 1.0) / 2.0, cx + (ws - 1.0) / 2.0)
+
     def encode_anchors(self, bboxes, anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax, inside_mask, match_mining=False, debug=False):
         """anchor_manipulator.py:275-326 -> (gt_targets [A,4], gt_labels [A] int32 in {1,0,-1}, gt_scores [A], matched_gt [A,4])."""
         a4 = (anchors_ymin, anchors_xmin, anchors_ymax, anchors_xmax)

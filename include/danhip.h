@@ -212,6 +212,22 @@ int danhip_small_mining_match(const float* overlaps, int32_t A, int32_t G, float
 int danhip_encode_anchors(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const float* gt_boxes,
                           const int32_t* match_indices, float* targets, int32_t* labels, float* matched_gt, int32_t A,
                           float ps0, float ps1, float ps2, float ps3, float scale, void* stream);
+/* anchor_encoder_fn over a whole batch in one call (the reference maps encode_anchors / encode_pa_anchors per image inside tf.data:
+ * train_sfd.py:206, train_dan.py:243-249; anchor_manipulator.py:275-387): IoU x inside_mask -> small_mining_match (match_mining=1:
+ * negative_low_thres, ignore_thres, positive_thres, min_match, stop_positive_thres as the op's attrs) or do_dual_max_match
+ * (match_mining=0: low=ignore_thres, high=positive_thres) -> encode.  gt_boxes [total_gt,4] is the concatenation of the images' gt rows,
+ * gt_offsets [B+1] int32 (device) their row ranges; every image needs >= 1 row (the reference substitutes [[0,0,1,1]] for an empty
+ * list, anchor_manipulator.py:286 / :347).  match_* = anchors used for matching (NULL: the encode anchors; encode_pa_anchors passes the
+ * shrunk set and `scale`).  Outputs targets [B,A,4], labels [B,A] in {1,0,-1}, scores [B,A], matched_gt [B,A,4] or NULL.
+ * Images are independent, so the B sequential hard-face compensation passes run side by side (one workgroup each). */
+size_t danhip_encode_anchors_batched_workspace_bytes(int32_t B, int32_t A, int32_t total_gt);
+int danhip_encode_anchors_batched(const float* ymin, const float* xmin, const float* ymax, const float* xmax, const float* match_ymin,
+                                  const float* match_xmin, const float* match_ymax, const float* match_xmax, const uint8_t* inside_mask,
+                                  const float* gt_boxes, const int32_t* gt_offsets, int32_t B, int32_t A, int32_t total_gt, int32_t max_gt,
+                                  int32_t match_mining, float negative_low_thres, float ignore_thres, float positive_thres,
+                                  int32_t min_match, float stop_positive_thres, float ps0, float ps1, float ps2, float ps3, float scale,
+                                  float* targets, int32_t* labels, float* scores, float* matched_gt, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 /* batch_decode_anchors / decode_anchors (anchor_manipulator.py:389-424). pred [B,A,4] -> boxes [B,A,4]. */
 int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmin, const float* ymax, const float* xmax,
                           float* boxes, int32_t B, int32_t A, float ps0, float ps1, float ps2, float ps3, void* stream);

@@ -125,3 +125,35 @@ def test_encode_decode(mining, dev):
     d_ref = OA.decode_anchors(p, ref[:4], [0.1, 0.1, 0.2, 0.2])
     d = cfg.enc.batch_decode_anchors(torch.from_numpy(p).to(dev), *cfg.anchors[:4]).cpu().numpy()
     assert np.allclose(d, d_ref, rtol=3e-7, atol=2e-4)               # expf last-ulp differences scaled by anchor size
+
+
+@pytest.mark.parametrize("mining", [True, False])
+def test_batched_encode_equals_the_per_image_calls_bit_for_bit(mining, dev):
+    """danhip_encode_anchors_batched (one call, images side by side) against the per-image entry points the oracle tests above pin:
+    ragged gt lists, an empty list (the [[0,0,1,1]] substitute of anchor_manipulator.py:286), many tiny faces (hard-face compensation
+    with ties), and a 100-face image."""
+    from dan_amd.train_sfd import AnchorConfig
+    h = w = 320
+    cfg = AnchorConfig(h, w, dev, match_threshold=0.4 if mining else 0.35, neg_threshold=0.4 if mining else 0.35)
+    rs = np.random.RandomState(17)
+    tiny = np.stack([np.array([y, x, y + s, x + s], np.float32) for y, x, s in zip(rs.randint(0, 300, 30), rs.randint(0, 300, 30), rs.randint(3, 14, 30))])
+    gts = [_gt(12, h, w, 5), np.zeros((0, 4), np.float32), tiny, _gt(1, h, w, 6), _gt(100, h, w, 7), tiny[:3].repeat(2, axis=0)]
+    gts = [torch.from_numpy(g).to(dev) for g in gts]
+    T, L, S, M = cfg.enc.encode_anchors_batch(gts, *cfg.anchors, match_mining=mining)
+    for b, g in enumerate(gts):
+        t, l, s, m = cfg.enc.encode_anchors(g, *cfg.anchors, match_mining=mining)
+        assert torch.equal(L[b], l) and torch.equal(S[b], s) and torch.equal(M[b], m) and torch.equal(T[b], t), b
+    assert (L[2] == 1).sum().item() > 0
+
+
+def test_batched_pa_encode_equals_the_per_image_calls(dev):
+    from dan_amd.train_sfd import AnchorConfig
+    h = w = 320
+    cfg = AnchorConfig(h, w, dev)
+    n0 = cfg.num_anchors_per_layer[0]
+    sub = tuple(t[n0:].contiguous() for t in cfg.anchors)
+    gts = [torch.from_numpy(_gt(n, h, w, 20 + n)).to(dev) for n in (7, 1, 33)] + [torch.zeros((0, 4), device=dev)]
+    T, L, S, M = cfg.enc.encode_pa_anchors_batch(gts, *sub, 0.35, 0.35, match_mining=False, scale=2.)
+    for b, g in enumerate(gts):
+        t, l, s, m = cfg.enc.encode_pa_anchors(g, *sub, 0.35, 0.35, match_mining=False, scale=2.)
+        assert torch.equal(L[b], l) and torch.equal(S[b], s) and torch.equal(M[b], m) and torch.equal(T[b], t), b
