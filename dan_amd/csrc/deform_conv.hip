@@ -224,6 +224,224 @@ __global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Atomic-free backward for the shape the context modules use (3x3 taps, stride 1, C / deformable_group == 64).
+// L2 float atomics run at ~1.4 TB/s on this part and the scatter issues 36 of them (256 B each) per output pixel and group, so the
+// col2im is turned around: a wave owns one INPUT pixel (x 64 channels), enumerates the (output pixel, tap) pairs whose nominal sampling
+// position lies within +-R pixels, evaluates get_gradient_weight for each in one lane, and accumulates the matching dS rows — a
+// deterministic gather.  Corners further than R from their nominal position (offsets beyond ~R-1 px) keep the memory atomic
+// (`far` below); the two sets are complementary by construction.  dOffset needs no atomics at all: one wave per (output pixel, group)
+// has all nine taps' loads in flight and reduces the 18 sums with a transposing butterfly (29 shuffles instead of 108).
+constexpr int DEFORM_R = 2;
+
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+struct CornerSet {
+  int rh[4], rw[4];
+  float wg[4];
+  bool ok[4];
+};
+// get_gradient_weight (deform_conv.cu:130-173) + the guards of deformable_col2im_gpu_kernel (:311-326) for one sampling position
+__device__ __forceinline__ CornerSet corner_set(float inv_h, float inv_w, int H, int W) {
+  CornerSet cs;
+  const bool in = !(inv_h < 0 || inv_h > (float)H || inv_w < 0 || inv_w > (float)W);
+  float ah = fmaxf(inv_h, 0.f), aw = fmaxf(inv_w, 0.f);
+  if (!in) { ah = 0.f; aw = 0.f; }
+  int hl = (int)ah, wl = (int)aw, hh, wh;
+  const bool ch = hl >= H - 1, cw = wl >= W - 1;
+  if (ch) { hh = hl = H - 1; ah = (float)hl; } else hh = hl + 1;
+  if (cw) { wh = wl = W - 1; aw = (float)wl; } else wh = wl + 1;
+  cs.rh[0] = hl; cs.rh[1] = hl; cs.rh[2] = hh; cs.rh[3] = hh;
+  cs.rw[0] = wl; cs.rw[1] = wh; cs.rw[2] = wl; cs.rw[3] = wh;
+  cs.wg[0] = ((float)(hl + 1) - ah) * ((float)(wl + 1) - aw);
+  cs.wg[1] = ((float)(hl + 1) - ah) * (aw + 1.f - (float)wh);
+  cs.wg[2] = (ah + 1.f - (float)hh) * ((float)(wl + 1) - aw);
+  cs.wg[3] = (ah + 1.f - (float)hh) * (aw + 1.f - (float)wh);
+  const bool dup[4] = {false, cw, ch, ch || cw};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    cs.ok[k] = in && !dup[k] && fabsf(inv_h - (float)cs.rh[k]) < 1.f && fabsf(inv_w - (float)cs.rw[k]) < 1.f && cs.rh[k] >= 0 && cs.rh[k] < H &&
+               cs.rw[k] >= 0 && cs.rw[k] < W;
+  return cs;
+}
+
+// The weight corner_set() gives the corner that IS pixel (h, w), or 0: wg[k] and ok[k] factor into a row part and a column part
+// (dup[1] = cw, dup[2] = ch, dup[3] = ch || cw), so the gather evaluates the two 1-D factors directly.
+__device__ __forceinline__ float axis_factor(float inv, int target, int L) {
+  float a = fmaxf(inv, 0.f);
+  int lo = (int)a, hi;
+  const bool clamp = lo >= L - 1;
+  if (clamp) { hi = lo = L - 1; a = (float)lo; } else hi = lo + 1;
+  const bool near = fabsf(inv - (float)target) < 1.f;
+  float f = 0.f;
+  if (target == lo) f = (float)(lo + 1) - a;                 // corners 0/1 (rows) or 0/2 (columns)
+  else if (target == hi && !clamp) f = a + 1.f - (float)hi;  // the high corner, unless it duplicates the low one
+  return near ? f : 0.f;
+}
+__device__ __forceinline__ float corner_weight_at(float inv_h, float inv_w, int h, int w, int H, int W) {
+  if (inv_h < 0 || inv_h > (float)H || inv_w < 0 || inv_w > (float)W) return 0.f;
+  return axis_factor(inv_h, h, H) * axis_factor(inv_w, w, W);
+}
+
+// dOffset (+ the far corners' atomics into the fp32 side buffer): one wave per (output pixel, group).  The sampling geometry of the
+// nine taps is wave-uniform, and this ISA has no scalar float unit: it is therefore computed ONCE, tap t in lane t, and handed to the
+// whole wave through readlane (corner element offsets land in SGPRs, so the 45 loads use scalar base + lane addressing).
+__global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                                   const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                                   bf16_t* __restrict__ doffs, DeformGeom g) {
+  const int offc = g.dg * 18;
+  const int lane = threadIdx.x & 63;
+  const long nwork = (long)g.N * g.Ho * g.Wo * g.dg;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const float Hf = (float)g.H, Wf = (float)g.W;
+  const int tl = lane < 9 ? lane : 0;                                   // this lane's tap during the geometry phase
+  for (long wk = wave0; wk < nwork; wk += nwaves) {
+    const int grp = (int)(wk % g.dg);
+    const long m = wk / g.dg;
+    const int wo = (int)(m % g.Wo);
+    const int ho = (int)((m / g.Wo) % g.Ho);
+    const int n = (int)(m / ((long)g.Wo * g.Ho));
+    const int h_in = ho - g.pad_t, w_in = wo - g.pad_l;
+    const bf16_t* ub = x + ((long)n * g.H * g.W) * g.C + grp * 64;      // wave-uniform bases
+    const bf16_t* ud = dS + m * 9 * g.C + grp * 64;
+    // ---- geometry, lane = tap
+    const unsigned oraw = *reinterpret_cast<const unsigned*>(offs + m * offc + grp * 18 + 2 * tl);
+    const float off_h = bf2f((bf16_t)(oraw & 0xffffu)), off_w = bf2f((bf16_t)(oraw >> 16));
+    const float inv_h = (float)(h_in + (tl / 3) * g.dil) + off_h, inv_w = (float)(w_in + (tl % 3) * g.dil) + off_w;
+    const bool in = !(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf);
+    float ih = in ? inv_h : 0.f, iw = in ? inv_w : 0.f;
+    int hl = (int)ih, wl = (int)iw, hh, wh;
+    if (hl >= g.H - 1) { hh = hl = g.H - 1; ih = (float)hl; } else hh = hl + 1;
+    if (wl >= g.W - 1) { wh = wl = g.W - 1; iw = (float)wl; } else wh = wl + 1;
+    const int o00 = (hl * g.W + wl) * g.C, o01 = (hl * g.W + wh) * g.C, o10 = (hh * g.W + wl) * g.C, o11 = (hh * g.W + wh) * g.C;
+    const float ca_w = in ? (float)(wl + 1) - iw : 0.f, cb_w = in ? iw - (float)wl : 0.f;      // get_coordinate_weight (:177-221)
+    const float ca_h = in ? (float)(hl + 1) - ih : 0.f, cb_h = in ? ih - (float)hl : 0.f;
+    // ---- all 45 loads of the nine taps in flight, lane = channel
+    bf16_t v[9][4], cgr[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      v[t][0] = (ub + __builtin_amdgcn_readlane(o00, t))[lane];
+      v[t][1] = (ub + __builtin_amdgcn_readlane(o01, t))[lane];
+      v[t][2] = (ub + __builtin_amdgcn_readlane(o10, t))[lane];
+      v[t][3] = (ub + __builtin_amdgcn_readlane(o11, t))[lane];
+      cgr[t] = (ud + t * g.C)[lane];
+    }
+    float sv[18];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float cg = bf2f(cgr[t]);
+      const float vll = bf2f(v[t][0]), vlh = bf2f(v[t][1]), vhl = bf2f(v[t][2]), vhh = bf2f(v[t][3]);
+      const float a_w = lane_f(ca_w, t), b_w = lane_f(cb_w, t), a_h = lane_f(ca_h, t), b_h = lane_f(cb_h, t);
+      sv[2 * t] = (-1.f * a_w * vll + -1.f * b_w * vlh + a_w * vhl + b_w * vhh) * cg;
+      sv[2 * t + 1] = (-1.f * a_h * vll + a_h * vlh + -1.f * b_h * vhl + b_h * vhh) * cg;
+    }
+    // 16 of the 18 sums: transposing butterfly — after the step with partner distance d a lane keeps the half its bit selects
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float r8[8], r4[4], r2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r8[j] = (b0 ? sv[j + 8] : sv[j]) + __shfl_xor(b0 ? sv[j] : sv[j + 8], 1, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r4[j] = (b1 ? r8[j + 4] : r8[j]) + __shfl_xor(b1 ? r8[j] : r8[j + 4], 2, 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r2[j] = (b2 ? r4[j + 2] : r4[j]) + __shfl_xor(b2 ? r4[j] : r4[j + 2], 4, 64);
+    float r1 = (b3 ? r2[1] : r2[0]) + __shfl_xor(b3 ? r2[0] : r2[1], 8, 64);
+    r1 += __shfl_xor(r1, 16, 64);
+    r1 += __shfl_xor(r1, 32, 64);
+    float e0 = sv[16], e1 = sv[17];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); }
+    bf16_t* dp = doffs + m * offc + grp * 18;
+    if (lane < 16) dp[(b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)] = f2bf(r1);
+    if (lane == 16) dp[16] = f2bf(e0);
+    if (lane == 17) dp[17] = f2bf(e1);
+    // ---- far corners: not reachable by the gather kernel's +-R enumeration.  A corner sits floor(o) or floor(o)+1 from the nominal
+    // position (one less under the high-edge clamp), so offsets in [-(R-1), R-1) cannot produce one: skip the whole search then
+    const float lim = (float)(DEFORM_R - 1);
+    if (!__any(lane < 9 && (off_h < -lim || off_h >= lim || off_w < -lim || off_w >= lim))) continue;
+    const int c = grp * 64 + lane;
+    for (int t = 0; t < 9; ++t) {
+      const int nh = h_in + (t / 3) * g.dil, nw = w_in + (t % 3) * g.dil;
+      const CornerSet cs = corner_set(lane_f(inv_h, t), lane_f(inv_w, t), g.H, g.W);
+      const float cg = bf2f((ud + t * g.C)[lane]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool far = abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R;
+        if (cs.ok[k] && far) atomicAdd(far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + c, cs.wg[k] * cg);
+      }
+    }
+  }
+}
+
+// dX: one wave per (input pixel, group), lane = candidate during the enumeration, lane = channel during the accumulation
+__global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                                        const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
+                                                                        int accumulate) {
+  constexpr int R = DEFORM_R, D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 63) / 64;
+  const int offc = g.dg * 18;
+  const int lane = threadIdx.x & 63;
+  const long nwork = (long)g.N * g.H * g.W * g.dg;
+  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  for (long wk = wave0; wk < nwork; wk += nwaves) {
+    const int grp = (int)(wk % g.dg);
+    const long p = wk / g.dg;
+    const int w = (int)(p % g.W);
+    const int h = (int)((p / g.W) % g.H);
+    const int n = (int)(p / ((long)g.W * g.H));
+    const int c = grp * 64 + lane;
+    unsigned oraw[ROUNDS];
+    int row[ROUNDS], nhv[ROUNDS], nwv[ROUNDS];
+    bool valid[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int cand = r * 64 + lane;
+      const int t = cand % 9, pos = cand / 9;
+      nhv[r] = h + pos / D - R;
+      nwv[r] = w + pos % D - R;
+      const int ho = nhv[r] + g.pad_t - (t / 3) * g.dil, wo = nwv[r] + g.pad_l - (t % 3) * g.dil;     // stride 1
+      valid[r] = cand < NC && ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo;
+      const long m = valid[r] ? ((long)n * g.Ho + ho) * g.Wo + wo : 0;
+      row[r] = (int)(m * 9 + t);
+      oraw[r] = *reinterpret_cast<const unsigned*>(offs + m * offc + (grp * 9 + t) * 2);
+    }
+    float wgt[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const float inv_h = (float)nhv[r] + bf2f((bf16_t)(oraw[r] & 0xffffu)), inv_w = (float)nwv[r] + bf2f((bf16_t)(oraw[r] >> 16));
+      const float wv = corner_weight_at(inv_h, inv_w, h, w, g.H, g.W);
+      wgt[r] = valid[r] ? wv : 0.f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      unsigned long long mask = __ballot(wgt[r] != 0.f);
+      while (mask) {                                                    // four dS rows in flight per trip
+        float w4[4];
+        int r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            w4[q] = lane_f(wgt[r], b);
+            r4[q] = __builtin_amdgcn_readlane(row[r], b);
+          } else { w4[q] = 0.f; r4[q] = 0; }
+        }
+        bf16_t d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d4[q] = (dS + (long)r4[q] * g.C + grp * 64)[lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += w4[q] * bf2f(d4[q]);
+      }
+    }
+    const long o = p * g.C + c;
+    float out = acc + far_dx[o];
+    if (accumulate) out += bf2f(dx[o]);
+    dx[o] = f2bf(out);
+  }
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
@@ -288,6 +506,14 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
   { const int zrc = danhip_zero_async(workspace, sizeof(float) * nx, s); if (zrc) return zrc; }
+  if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31)) {
+    const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
+    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, dim3(grid_for((ng + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, offsets, dS, workspace, dx, g,
+                       accumulate);
+    DH_LAUNCH_CHECK();
+    return DANHIP_OK;
+  }
   if (C / deformable_group == 64) {
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);

@@ -19,7 +19,7 @@ def _case(seed, N, H, W, C, Cout, dg, off_scale):
 
 
 @pytest.mark.parametrize("seed,N,H,W,C,Cout,dg,off_scale", [(0, 1, 8, 8, 64, 64, 4, 0.0), (1, 2, 9, 7, 64, 32, 4, 1.5), (2, 1, 12, 12, 128, 64, 2, 4.0),
-                                                            (3, 1, 6, 10, 256, 256, 4, 0.7)])
+                                                            (3, 1, 6, 10, 256, 256, 4, 0.7), (4, 2, 20, 27, 128, 64, 2, 1.0), (5, 1, 17, 9, 64, 64, 1, 6.0)])
 def test_deform_conv_forward_backward(seed, N, H, W, C, Cout, dg, off_scale, dev):
     from dan_amd.utility import custom_op
     x, w, off = _case(seed, N, H, W, C, Cout, dg, off_scale)
