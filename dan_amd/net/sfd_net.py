@@ -125,7 +125,12 @@ class VGG16Backbone(object):
             bl = self.vs.get("{}/loc_{}/bias".format(name, ind), (4,), "zeros")
             wc = self.vs.get("{}/cls_{}/kernel".format(name, ind), (3, 3, c, ncls), "glorot")
             bc = self.vs.get("{}/cls_{}/bias".format(name, ind), (ncls,), "zeros")
-            h = ops.conv2d(feat, torch.cat([wl, wc], dim=3).contiguous(), torch.cat([bl, bc]), stride=1, relu=False, out_f32=True)
+            pre = "{}/loc_{}/".format(name, ind), "{}/cls_{}/".format(name, ind)
+            wf = self.vs.fuse((pre[0] + "kernel", pre[1] + "kernel"), axis=3)          # one block in the trainer's flat buffer, or None
+            bf = self.vs.fuse((pre[0] + "bias", pre[1] + "bias"), axis=0)
+            if wf is None or bf is None:
+                wf, bf = torch.cat([wl, wc], dim=3).contiguous(), torch.cat([bl, bc])
+            h = ops.conv2d(feat, wf, bf, stride=1, relu=False, out_f32=True)
             loc, cls = ops.head_split(h, loc, cls, neg_maxout[ind], pos_maxout[ind], off)
             off += feat.shape[1] * feat.shape[2]
         return loc, cls

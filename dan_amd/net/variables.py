@@ -14,6 +14,8 @@ class VariableStore(torch.nn.Module):
         self.gen = torch.Generator(device="cpu").manual_seed(seed)
         self.vars = torch.nn.ParameterDict()
         self.order = []
+        self.fuse_groups = []       # [(names, axis)]: variables a layer consumes concatenated along `axis` (loc_i | cls_i heads)
+        self.fused = {}             # names tuple -> concatenated tensor living in the trainer's flat buffer (FlatParams)
 
     @staticmethod
     def _key(name):
@@ -41,6 +43,15 @@ class VariableStore(torch.nn.Module):
         assert tuple(p.shape) == tuple(shape), (name, tuple(p.shape), tuple(shape))
         return p
 
+    def fuse(self, names, axis=-1):
+        """Declares that `names` are consumed concatenated along `axis` (one conv for loc_i | cls_i).  Returns the concatenated
+        tensor once FlatParams has laid the members out as strided views of one block (no cat / split / re-packing per step), else
+        None and the caller concatenates."""
+        key = tuple(names)
+        if all(key != k for k, _ in self.fuse_groups):
+            self.fuse_groups.append((key, axis))
+        return self.fused.get(key)
+
     def buffer(self, name, shape, init):
         """Non-trainable state (batch-norm moving averages): a plain device tensor kept under its TF name."""
         if not hasattr(self, "bufs"):
@@ -60,6 +71,9 @@ class VariableStore(torch.nn.Module):
             if k in self.vars:
                 with torch.no_grad():
                     self.vars[k].copy_(t.to(self.device))
+                if self.fused:                       # members of a fused block are views: cached bf16 packings key on the block
+                    from .. import ops
+                    ops.WEIGHT_EPOCH += 1
             else:
                 self.vars[k] = torch.nn.Parameter(t.to(self.device).clone())
                 self.order.append(n)

@@ -127,6 +127,12 @@ def _grad_sink(p):
     return getattr(p, "_danhip_grad", None)
 
 
+def _sink_trainable(t):
+    """A fused block (not a leaf itself) whose member parameters are being trained."""
+    ms = getattr(t, "_danhip_members", None)
+    return ms is not None and any(m.requires_grad for m in ms)
+
+
 # Optional per-kernel timing (bench.py): when PROFILE is a dict, every conv forward / stride-1 data-gradient launch is
 # bracketed by events on the launch stream and recorded under its kernel-instance label with its algorithmic FLOPs.
 PROFILE = None
@@ -204,13 +210,13 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
         assert C % 8 == 0 and cin_real <= C
         d = _desc(N, H, W, C, cout, kh, kw, stride, valid)
-        need_bwd = w.requires_grad or x.requires_grad
+        need_bwd = w.requires_grad or x.requires_grad or bool(block_grads)
         wf, wb = packed_weights(d, w, w_param, need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
         e0 = _prof_begin()
@@ -230,6 +236,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.w_param, ctx.b_param = w_param, b_param
         ctx.save_for_backward(x, wb, y if relu else None)
         ctx.has_bias = b is not None
+        ctx.block_w, ctx.block_b = bool(block_grads & 1), bool(block_grads & 2)   # fused parameter blocks: not autograd leaves themselves
         return y
 
     @staticmethod
@@ -239,7 +246,8 @@ class _Conv2d(torch.autograd.Function):
         co8 = (d.Cout + 7) // 8 * 8
         M = d.N * d.Ho * d.Wo
         wp, bp = ctx.w_param, ctx.b_param
-        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        need_dw = ctx.needs_input_grad[1] or ctx.block_w
+        need_db = ctx.has_bias and (ctx.needs_input_grad[2] or ctx.block_b)
         db_sink = _grad_sink(bp) if bp is not None else None
         db = None
         if need_db:
@@ -267,8 +275,8 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 13
-        db_in_wgrad = need_db and ctx.needs_input_grad[1]       # the weight-gradient kernel also emits the bias gradient
+            return (None,) * 14
+        db_in_wgrad = need_db and need_dw                        # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
                 call("danhip_relu_bwd_bias_grad", ptr(g), None, ptr(db), M, co8, stream())
@@ -288,7 +296,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, stream())
                 _prof_end(e0, d, 1)
         dw = None
-        if ctx.needs_input_grad[1]:
+        if need_dw:
             sink = _grad_sink(wp) if wp is not None else None
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
             e0 = _prof_begin()
@@ -300,21 +308,25 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same"):
     """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up."""
-    wp = w if isinstance(w, torch.nn.Parameter) else None
-    bp = b if isinstance(b, torch.nn.Parameter) else None
-    track = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
+    # a plain tensor carrying a gradient sink is a fused block of parameters (FlatParams): cached packing, gradients written in place
+    wp = w if (isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad")) else None
+    bp = b if (isinstance(b, torch.nn.Parameter) or hasattr(b, "_danhip_grad")) else None
+    track = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or _sink_trainable(w))
     if track and relu and residual is not None:
         raise NotImplementedError("relu + fused residual needs a separate ReLU mask in backward (y > 0 is not the mask)")
     yslot = GradSlot.__new__(GradSlot) if (track and not out_f32) else None
     pool_out = [] if (pool and relu and not out_f32 and residual is None and b is not None and w.shape[-1] % 8 == 0) else None
     if padding not in ("same", "valid"):
         raise ValueError("padding must be 'same' or 'valid'")
-    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out, padding == "valid")
+    blk = 0
+    if torch.is_grad_enabled():
+        blk = (1 if _sink_trainable(w) else 0) | (2 if (b is not None and _sink_trainable(b)) else 0)
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out, padding == "valid", blk)
     if yslot is not None:
         yslot.__init__(y, relu)
         y._dh_slot = yslot

@@ -114,6 +114,7 @@ class DetectorTrainer(object):
         self.flat = FlatParams(model.vs, weight_decay)
         self.buckets = GradBuckets(self.flat)
         self.param_name = {id(p): n for n, p in model.vs.named()}
+        self.param_name.update({id(t): key[0] for key, t in model.vs.fused.items()})
         self.step_no = 0
         self.last = None
         self._graph = None

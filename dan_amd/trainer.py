@@ -30,7 +30,23 @@ class FlatParams(object):
     def __init__(self, vs, weight_decay=5e-4):
         named = vs.named()
         dev = named[0][1].device
-        sizes = [p.numel() for _, p in named]
+        byname = dict(named)
+        # fused blocks (VariableStore.fuse): the members become strided views of ONE segment, placed where the first member stood
+        group_of, members_done = {}, set()
+        for key, axis in getattr(vs, "fuse_groups", []):
+            if all(k in byname for k in key):
+                group_of[key[0]] = (key, axis)
+                members_done.update(key[1:])
+        units = []                                   # (segment name, [member names], axis or None, numel)
+        for name, p in named:
+            if name in members_done:
+                continue
+            if name in group_of:
+                key, axis = group_of[name]
+                units.append((name, list(key), axis, sum(byname[k].numel() for k in key)))
+            else:
+                units.append((name, [name], None, p.numel()))
+        sizes = [u[3] for u in units]
         # every segment starts on a 64-element (256-byte) boundary so views stay 16-byte aligned
         starts, off = [], 0
         for n in sizes:
@@ -42,11 +58,33 @@ class FlatParams(object):
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         gm, wd = [], []
         self.names, self.starts, self.sizes = [], starts, sizes
-        for (name, p), s, n in zip(named, starts, sizes):
-            self.w[s:s + n].copy_(p.data.reshape(-1))
-            p.data = self.w[s:s + n].view(p.shape)
-            p.grad = self.g[s:s + n].view(p.shape)
-            p._danhip_grad = p.grad
+        self.start_of_member = {}
+        for (name, members, axis, n), s in zip(units, starts):
+            if axis is None:
+                p = byname[name]
+                self.w[s:s + n].copy_(p.data.reshape(-1))
+                p.data = self.w[s:s + n].view(p.shape)
+                p.grad = self.g[s:s + n].view(p.shape)
+                p._danhip_grad = p.grad
+            else:
+                ps = [byname[k] for k in members]
+                ax = axis % ps[0].dim()
+                shape = list(ps[0].shape)
+                shape[ax] = sum(q.shape[ax] for q in ps)
+                wblock, gblock = self.w[s:s + n].view(shape), self.g[s:s + n].view(shape)
+                lo = 0
+                for q in ps:
+                    hi = lo + q.shape[ax]
+                    wblock.narrow(ax, lo, hi - lo).copy_(q.data)
+                    q.data = wblock.narrow(ax, lo, hi - lo)
+                    q.grad = gblock.narrow(ax, lo, hi - lo)
+                    q._danhip_grad = q.grad
+                    lo = hi
+                wblock._danhip_grad = gblock
+                wblock._danhip_members = ps
+                vs.fused[tuple(members)] = wblock
+            for k in members:
+                self.start_of_member[k] = s
             # gradient multipliers (train_sfd.py:436-439) and the L2 term (train_sfd.py:419-427)
             gm.append(2.0 if "/bias" in name else 1.0)
             if "bn" in name:                           # train_sfd.py:421 ('bn' not in trainable_var.name)
@@ -100,7 +138,7 @@ class GradBuckets(object):
         self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.pending = []
         self.next_bucket = 0
-        self.start_of = {n: s for n, s in zip(flat.names, flat.starts)}
+        self.start_of = dict(getattr(flat, "start_of_member", None) or zip(flat.names, flat.starts))   # members of fused blocks map to their block
         self.done_upto = flat.total
 
     def begin_step(self):

@@ -61,9 +61,9 @@ def test_sfd_train_step_parity(dev):
     assert abs(g_l2 - l2_ref) <= 1e-4 * l2_ref
     # gradients: global relative error per tensor (bf16 network, fp32 oracle)
     bad = []
-    for i, name in enumerate(tr.flat.names):
-        s, n = tr.flat.starts[i], tr.flat.sizes[i]
-        got = tr.flat.g[s:s + n].cpu()
+    named = dict(model.vs.named())                    # loc_i | cls_i live as strided views of one fused block: go through the parameters
+    for name, prm in named.items():
+        got = prm.grad.detach().reshape(-1).cpu()
         want = params[name].grad.reshape(-1)
         denom = want.norm().item() + 1e-8
         rel = (got - want).norm().item() / denom
@@ -72,13 +72,12 @@ def test_sfd_train_step_parity(dev):
     assert not bad, bad[:8]
     # optimiser step: w' = w - lr * (g*mult + wd*w)  (first step: v = g)
     lr = 1e-4   # step 0 of the schedule: 1e-3 * 0.1
-    for i, name in enumerate(tr.flat.names[:6] + tr.flat.names[-4:]):
-        j = tr.flat.names.index(name)
-        s, n = tr.flat.starts[j], tr.flat.sizes[j]
-        g = tr.flat.g[s:s + n].cpu()
+    order = [n for n, _ in model.vs.named()]
+    for name in order[:6] + order[-4:]:
+        g = named[name].grad.detach().reshape(-1).cpu()
         w0 = w_before[name].reshape(-1)
         mult = 2.0 if "/bias" in name else 1.0
         wd = 0.0 if "/bias" in name else (0.2 * 5e-4 if "l2_norm_layer" in name else 5e-4)
         want = w0 - lr * (g + wd * w0) * mult
-        got = tr.flat.w[s:s + n].cpu()
+        got = named[name].detach().reshape(-1).cpu()
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), name

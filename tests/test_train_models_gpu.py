@@ -64,7 +64,7 @@ def test_dan_train_step(deform, dev):
     names = [n for n, _ in model.vs.named()]
     assert any("prediction_modules_stage2" in n for n in names)
     if deform:
-        gi = {n: tr.flat.g[s:s + k] for n, s, k in zip(tr.flat.names, tr.flat.starts, tr.flat.sizes)}
+        gi = {n: q.grad for n, q in model.vs.named()}
         assert gi["prediction_modules_stage1/predict_stage1_0/deform_conv/kernel"].abs().sum().item() > 0
         assert gi["prediction_modules_stage1/predict_stage1_0/deform_conv/conv2d/bias"].abs().sum().item() > 0
 

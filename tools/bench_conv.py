@@ -28,7 +28,8 @@ S3FD = [
 ]
 PB = [
     ("cpm160_a", 4, 160, 160, 256, 1024, 3, 1), ("cpm160_b", 4, 160, 160, 1024, 256, 3, 1), ("cpm80_a", 4, 80, 80, 512, 1024, 3, 1),
-    ("lat160", 16, 160, 160, 256, 256, 1, 1),
+    ("lat160", 16, 160, 160, 256, 256, 1, 1), ("dfm160", 16, 160, 160, 2304, 256, 1, 1), ("dfm80", 16, 80, 80, 2304, 256, 1, 1),
+    ("ctx160", 16, 160, 160, 256, 128, 3, 1), ("up1024", 16, 160, 160, 256, 1024, 1, 1),
 ]
 # 1024x1024 inputs (BASELINE.json configs[3..4]) and sizes that are multiples of nothing.  NB: --check uses torch's fp32 NCHW conv as the
 # yardstick, which itself breaks down on b1_2 (4.3 GB operand); tests/test_conv_gpu.py covers >= 2 GiB activations by self-consistency
