@@ -155,7 +155,7 @@ def _prof_end(e0, d, which):
         label = _lib.lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode()
     else:
         label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), which).decode()
-    cin = d.Cin if which == 0 else d.Cin   # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
+    cin = d.Cin                              # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
     flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
     PROFILE.setdefault(label, []).append((e0, e1, flops))
 
@@ -289,7 +289,7 @@ class _Conv2d(torch.autograd.Function):
                 buf, acc = xs.target()
                 e0 = _prof_begin()
                 call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, stream())
-                _prof_end(e0, d, 1)
+                _prof_end(e0, d, 5 if xs.is_relu else 1)
             else:
                 dx = torch.empty_like(x)
                 e0 = _prof_begin()

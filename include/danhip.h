@@ -80,6 +80,9 @@ int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_desc* d, cons
 int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_dev, int32_t n, int32_t total_blocks, void* stream);
 
 /* y = act(conv(x, w) + bias).  x bf16; y bf16 (out_dtype=DANHIP_BF16) or fp32; bias fp32[Cout] or NULL.
+ * Pointwise (1x1, stride 1) convolutions with >= 64 channels either side and 16-bit output are plain GEMMs and run on hipBLASLt
+ * (bias / ReLU as its epilogue; so does danhip_conv2d_bwd_data when relu_mask is NULL); DANHIP_NO_BLASLT=1 keeps them on the
+ * implicit-GEMM kernel.
  * relu: 0/1.  residual: optional bf16 tensor of y's shape added AFTER the activation (DAN context modules,
  * net/danet.py:912-918) or NULL. */
 int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias,
@@ -106,8 +109,8 @@ int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const
  * dy bf16 [M, C]; y bf16 [M, C] or NULL; db fp32 [C] or NULL. */
 int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_t M, int32_t C, void* stream);
 
-/* Kernel-instance label a forward (which=0) / data-gradient (which=1) / forward-with-fused-pool (which=4,
- * danhip_conv2d_fwd_pool) call of this descriptor launches (the demangled name rocprofv3 reports) — lets bench.py attribute
+/* Kernel-instance label a forward (which=0) / data-gradient (which=1; which=5 when relu_mask is passed) / forward-with-fused-pool
+ * (which=4, danhip_conv2d_fwd_pool) call of this descriptor launches (the demangled name rocprofv3 reports) — lets bench.py attribute
  * measured time to a kernel. */
 const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
 /* Same for the weight-gradient call of this descriptor. */

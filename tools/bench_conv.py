@@ -81,7 +81,7 @@ def run(shape, iters, which, check):
         ms = e0.elapsed_time(e1) / iters
         label = ""
         if wname != "wgrad":
-            label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else 1).decode()
+            label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else 5).decode()   # dgrad() passes a ReLU mask
         out.append((wname, ms, flops / ms / 1e9, label))
     errs = {}
     if check:
