@@ -26,6 +26,8 @@ SHAPES = [
     (2, 16, 64, 64, 64, 3, 3, 1), (1, 30, 62, 64, 64, 3, 3, 1), (9, 64, 128, 64, 64, 3, 3, 1),
     # first layer (3 channels padded to 8 -> 64): the store-bound direct kernel; ragged width, one-pixel-wide, many units
     (2, 17, 45, 8, 64, 3, 3, 1), (1, 5, 1, 8, 64, 3, 3, 1), (3, 64, 100, 8, 64, 3, 3, 1),
+    # pointwise convolutions with >= 4096 pixels: the hipBLASLt GEMM path (K = 64 .. 2304 as in the deformable conv, ragged Cout % 64)
+    (2, 48, 48, 256, 256, 1, 1, 1), (1, 64, 72, 2304, 256, 1, 1, 1), (1, 65, 67, 64, 72, 1, 1, 1), (4, 40, 40, 1024, 1024, 1, 1, 1),
 ]
 
 
@@ -196,3 +198,29 @@ def test_conv_relu_with_fused_max_pool(shape, dev):
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
     assert torch.equal(dx0, dx1)
     assert torch.allclose(dw0, dw1, rtol=1e-3, atol=1e-3 * dw0.abs().max().item())
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_pointwise_data_gradient_through_the_library_gemm(accumulate, dev):
+    """danhip_conv2d_bwd_data of a 1x1 conv without a fused ReLU mask is a hipBLASLt GEMM (beta = accumulate); with the mask it stays
+    on the implicit-GEMM kernel — both against the fp32 formula dx = dy . W^T."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, ptr, stream
+    N, H, W, Cin, Cout = 2, 48, 50, 320, 136
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn((1, 1, Cin, Cout), generator=g) / Cin ** 0.5).to(torch.bfloat16).float()
+    dy = torch.randn((N, H, W, Cout), generator=g).to(torch.bfloat16)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16)
+    dx0 = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16)
+    d = ops._desc(N, H, W, Cin, Cout, 1, 1, 1)
+    _, wb = ops.pack_conv_weight(d, w.to(dev), need_bwd=True)
+    ref = dy.float().reshape(-1, Cout) @ w.reshape(Cin, Cout).t()
+    ref = ref.reshape(N, H, W, Cin) + (dx0.float() if accumulate else 0.0)
+    for mask in (None, x.to(dev)):
+        dx = dx0.to(dev).clone()
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy.to(dev)), ptr(wb), ptr(mask), ptr(dx), accumulate, stream())
+        torch.cuda.synchronize()
+        want = ref if mask is None else torch.where(x.float() > 0, ref, dx0.float() if accumulate else torch.zeros_like(ref))
+        err = (dx.float().cpu() - want).abs().max().item()
+        assert err <= 2.0 ** -7 * want.abs().max().item() + 2e-2, (mask is not None, err)
