@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the training step in a hipGraph (single GPU; off by default)")
     ap.add_argument("--no-eval", action="store_true", help="skip the inference-FPS leg (the 'eval FPS' half of BASELINE.json's metric)")
+    ap.add_argument("--deform-offsets", type=float, default=0.0,
+                    help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
+                         "fractional, spread-out positions (SURVEY 8d asks for a second run at R = 2)")
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
@@ -112,6 +115,13 @@ def main():
         trainer = DANTrainer(model, anchors, world=world)
         step_args = (imgs,) + encode_batch_dan(anchors, gts)
         workload = "DAN-Deform (deformable context module)" if args.model == "dan_deform" else "DAN (two-stage heads, dynamic anchor routing)"
+    if args.deform_offsets > 0 and args.model == "dan_deform":
+        g = torch.Generator().manual_seed(synthetic.SEED + 7)
+        with torch.no_grad():
+            for n, p in model.vs.named():
+                if n.endswith("deform_conv/conv2d/bias"):
+                    p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * args.deform_offsets).to(p.device))
+        workload += ", offset biases U(-%g, %g) px" % (args.deform_offsets, args.deform_offsets)
     torch.cuda.synchronize()
 
     def barrier():

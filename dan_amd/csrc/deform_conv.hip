@@ -359,8 +359,19 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
     // position (one less under the high-edge clamp), so offsets in [-(R-1), R-1) cannot produce one: skip the whole search then
     const float lim = (float)(DEFORM_R - 1);
     if (!__any(lane < 9 && (off_h < -lim || off_h >= lim || off_w < -lim || off_w >= lim))) continue;
+    // ... otherwise the exact test, still tap t in lane t, and only the taps that own a far corner are replayed by the whole wave
+    bool mine = false;
+    {
+      const int nh = h_in + (tl / 3) * g.dil, nw = w_in + (tl % 3) * g.dil;
+      const CornerSet cs = corner_set(inv_h, inv_w, g.H, g.W);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mine = mine || (cs.ok[k] && (abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R));
+    }
+    unsigned long long todo = __ballot(mine && lane < 9);
     const int c = grp * 64 + lane;
-    for (int t = 0; t < 9; ++t) {
+    while (todo) {
+      const int t = __builtin_ctzll(todo);
+      todo &= todo - 1;
       const int nh = h_in + (t / 3) * g.dil, nw = w_in + (t % 3) * g.dil;
       const CornerSet cs = corner_set(lane_f(inv_h, t), lane_f(inv_w, t), g.H, g.W);
       const float cg = bf2f((ud + t * g.C)[lane]);
