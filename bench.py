@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong-scaling series (SURVEY 8d): fix the GLOBAL batch; each of the N ranks takes global/N images (default: weak, "
+                         "--batch-per-gpu images per rank)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the training step in a hipGraph (single GPU; off by default)")
@@ -90,6 +93,10 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local)
     B, S = args.batch_per_gpu, args.size
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must divide by the number of ranks (tf_replicate_model_fn.py:461-466)")
+        B = args.global_batch // world
 
     # synthetic shard of this rank (contiguous split of the global batch, tf_replicate_model_fn.py:458-498)
     imgs = synthetic.make_images(B, S, S, dev, seed=synthetic.SEED + rank)
@@ -227,7 +234,7 @@ def main():
         out = {
             "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": _lib.ACT_NAME, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": _lib.ACT_NAME, "data": "synthetic",
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
                        "step_launch": "hipGraph replay" if (args.graph and world == 1) else "eager"},
