@@ -574,10 +574,13 @@ extern "C" int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_pack
   return danhip_conv2d_fwd(&d, col, wf_packed, bias, y, DANHIP_BF16, relu, nullptr, stream);
 }
 
-extern "C" int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy, uint16_t* dx,
-                                      uint16_t* d_offsets, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
-                                      int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, int accumulate_dx,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+// `col_saved`: the im2col buffer danhip_deform_conv_fwd left in ITS workspace (same x / offsets), kept alive by the caller — the backward
+// then skips the reference's re-im2col (:744-748; 1.9 GB rewritten per call at 160x160x256, batch 16).  NULL: re-sample as the reference.
+extern "C" int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                               const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                               int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                               int32_t dilation, int32_t deformable_group, int accumulate_dx, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
   DH_REQUIRE(x && wb_packed && offsets && dy && dx && d_offsets && dw && workspace, DANHIP_EINVAL, "deform_conv_bwd: null pointer");
   const size_t need = danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1);
   DH_REQUIRE(workspace_bytes >= need && need > 0, DANHIP_EWORKSPACE, "deform_conv_bwd: workspace too small");
@@ -592,7 +595,17 @@ extern "C" int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_pack
   rc = danhip_deform_sample_bwd(x, offsets, dcol, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate_dx, scatter,
                                 stream);                                                              // col2im_coord + col2im (:716-741)
   if (rc) return rc;
-  rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);   // re-im2col (:744-748)
-  if (rc) return rc;
-  return danhip_conv2d_bwd_weight(&d, col, dy, dw, db, kh * kw * C, stream);                          // dW += dOut col^T (:750-768)
+  if (!col_saved) {
+    rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);   // re-im2col (:744-748)
+    if (rc) return rc;
+  }
+  return danhip_conv2d_bwd_weight(&d, col_saved ? col_saved : col, dy, dw, db, kh * kw * C, stream);  // dW += dOut col^T (:750-768)
+}
+
+extern "C" int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy, uint16_t* dx,
+                                      uint16_t* d_offsets, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
+                                      int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, int accumulate_dx,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return danhip_deform_conv_bwd_with_col(x, wb_packed, offsets, dy, nullptr, dx, d_offsets, dw, db, N, H, W, C, Cout, kh, kw, stride, dilation,
+                                         deformable_group, accumulate_dx, workspace, workspace_bytes, stream);
 }

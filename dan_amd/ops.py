@@ -673,10 +673,13 @@ class _DeformSample(torch.autograd.Function):
         return dx, doff, None, None, None, None, None
 
 
+KEEP_DEFORM_COL = True
+
+
 class _DeformConv(torch.autograd.Function):
     """DeformConvOp / DeformConvBackpropOp (cpp/Deform/deform_conv.cc:392-535, :635-771) through the single-call entry
-    points: the im2col buffer exists only inside each call (the backward re-samples it, as the reference does), so nothing
-    of size 9x the activation is kept between forward and backward.
+    points.  KEEP_DEFORM_COL (default on): the forward's im2col buffer (9x the activation, 1.9 GB at 160x160x256 batch 16) is kept for
+    the weight gradient instead of being re-sampled in backward as the reference does on its 11 GB cards (deform_conv.cc:744-748).
     x bf16 [N,H,W,C]; w fp32 [1,1,kh*kw*C,Cout] (the OIHW variable viewed as the GEMM operand); offsets bf16."""
 
     @staticmethod
@@ -699,6 +702,7 @@ class _DeformConv(torch.autograd.Function):
         ctx.b_param, ctx.yslot, ctx.has_bias = b_param, yslot, b is not None
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, offsets, wb, y if relu else None)
+        ctx.col = ws if (KEEP_DEFORM_COL and need_bwd) else None
         return y
 
     @staticmethod
@@ -706,6 +710,7 @@ class _DeformConv(torch.autograd.Function):
         x, offsets, wb, y = ctx.saved_tensors
         kh, kw, stride, dilation, dg, cout, relu = ctx.cfg
         N, H, W, C = x.shape
+        col, ctx.col = ctx.col, None
         g = ctx.yslot.take() if ctx.yslot is not None else None          # slot deliveries arrive ReLU-masked
         if dy is not None:
             assert dy.dtype == ACT and dy.shape[-1] == cout
@@ -726,8 +731,8 @@ class _DeformConv(torch.autograd.Function):
         dw = torch.zeros((1, 1, kh * kw * C, cout), dtype=torch.float32, device=x.device)
         nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
-        call("danhip_deform_conv_bwd", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout, kh, kw, stride,
-             dilation, dg, 0, ptr(ws), nws, stream())
+        call("danhip_deform_conv_bwd_with_col", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(col), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout,
+             kh, kw, stride, dilation, dg, 0, ptr(ws), nws, stream())
         if GRAD_READY_HOOK is not None and bp is not None:
             GRAD_READY_HOOK(bp)
         return dx, dw, (None if db_sink is not None else db), doff, None, None, None, None, None, None, None, None

@@ -270,6 +270,14 @@ int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const u
                            uint16_t* d_offsets, float* dw, float* db, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout,
                            int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, int accumulate_dx,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Same, with the im2col buffer that danhip_deform_conv_fwd left at the start of ITS workspace (kept alive by the caller; same x and
+ * offsets): skips the reference's re-im2col (deform_conv.cc:744-748) — on a 288 GB part the 9x-activation buffer is cheaper to keep
+ * than to regenerate.  col_saved = NULL behaves as danhip_deform_conv_bwd. */
+int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                    const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                    int32_t dilation, int32_t deformable_group, int accumulate_dx, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DynamicAnchorRouting custom op (cpp/ExtraLib/dynamic_anchor_routing.cc:32-65 op def, :188-518 kernel; Python name

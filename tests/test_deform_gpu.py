@@ -65,7 +65,8 @@ def test_single_call_entry_points_equal_the_two_halves(dev):
     b = torch.randn(64, generator=g)
     dy = torch.randn((2, 11, 13, 64), generator=g).to(torch.bfloat16).to(dev)
     res = []
-    for single in (True, False):
+    for single in (True, False, "resample"):            # "resample": the reference's re-im2col in backward instead of the kept buffer
+        ops.KEEP_DEFORM_COL = single != "resample"
         xd, od = x.to(dev).requires_grad_(True), off.to(dev).requires_grad_(True)
         w1 = w.permute(2, 3, 1, 0).reshape(1, 1, 9 * 128, 64).contiguous().to(dev).requires_grad_(True)
         bd = b.to(dev).requires_grad_(True)
@@ -75,11 +76,13 @@ def test_single_call_entry_points_equal_the_two_halves(dev):
             y = ops.conv2d(ops.deform_sample(xd, od, 3, 3, deformable_group=2), w1, bd, relu=True)
         y.backward(dy)
         res.append((y, xd.grad, od.grad, w1.grad, bd.grad))
-    for a, c, name in zip(res[0], res[1], ("y", "dx", "doffset", "dw", "db")):
-        if name in ("dw", "db", "dx"):        # fp32 atomics: order-dependent in the last bits
-            assert torch.allclose(a.float(), c.float(), rtol=1e-2, atol=1e-3 * c.float().abs().max().item()), name
-        else:
-            assert torch.equal(a, c), name
+    ops.KEEP_DEFORM_COL = True
+    for other in (res[1], res[2]):
+        for a, c, name in zip(res[0], other, ("y", "dx", "doffset", "dw", "db")):
+            if name in ("dw", "db", "dx"):        # fp32 atomics: order-dependent in the last bits
+                assert torch.allclose(a.float(), c.float(), rtol=1e-2, atol=1e-3 * c.float().abs().max().item()), name
+            else:
+                assert torch.equal(a, c), name
     need = lib().danhip_deform_conv_workspace_bytes(2, 11, 13, 128, 3, 3, 1, 0)
     assert need >= 2 * 11 * 13 * 9 * 128 * 2
     ws = torch.empty(16, dtype=torch.uint8, device=dev)
