@@ -399,7 +399,7 @@ __global__ __launch_bounds__(1024) void batch_phase3_kernel(BatchArgs p, int min
   }
 }
 __global__ void batch_encode_kernel(BatchArgs p, float ps0, float ps1, float ps2, float ps3, float scale) {
-  const int b = blockIdx.y, g0 = p.goff[b];
+  const int b = blockIdx.y, g0 = p.goff[b] < p.goff[b + 1] ? p.goff[b] : 0;   // an (unsupported) empty row range must not read past the buffer
   encode_anchors_body(p.ymin, p.xmin, p.ymax, p.xmax, p.gt + (long)g0 * 4, p.midx + (long)b * p.A, p.targets + (long)b * p.A * 4,
                       p.labels + (long)b * p.A, p.matched ? p.matched + (long)b * p.A * 4 : nullptr, p.A, ps0, ps1, ps2, ps3, scale);
 }
