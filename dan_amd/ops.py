@@ -138,19 +138,19 @@ def _sink_trainable(t):
 PROFILE = None
 
 
-def _prof_begin():
+def _prof_begin(st=None):
     if PROFILE is None:
         return None
     e = torch.cuda.Event(enable_timing=True)
-    e.record(torch.cuda.current_stream())
+    e.record(st if st is not None else torch.cuda.current_stream())
     return e
 
 
-def _prof_end(e0, d, which):
+def _prof_end(e0, d, which, st=None):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
-    e1.record(torch.cuda.current_stream())
+    e1.record(st if st is not None else torch.cuda.current_stream())
     if which == 2:
         label = _lib.lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode()
     else:
@@ -158,6 +158,39 @@ def _prof_end(e0, d, which):
     cin = d.Cin                              # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
     flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
     PROFILE.setdefault(label, []).append((e0, e1, flops))
+
+
+# ---- weight gradients on a second stream.  dgrad(L) and wgrad(L) both consume dY_L and are independent of each other; on one stream
+# each kernel's ramp-up and tail (and, on the 40x40 / 20x20 maps, its under-filled grid) leave CUs idle that the other kernel can use
+# (tools/probe_concurrent_bwd.py: conv4_2 0.95 -> 0.84 ms, conv5_1 0.37 -> 0.31, fc6 0.25 -> 0.18 for the pair).  The trainer switches
+# this on around its backward pass and joins before the gradients are consumed; tensors the side stream still reads are kept alive
+# until that join (no allocator reuse while in flight, also valid inside a hipGraph capture).
+_WGRAD = {"on": False, "side": None, "main": None, "keep": []}
+
+
+def wgrad_overlap_begin():
+    if not torch.cuda.is_available():
+        return
+    import os
+    if os.environ.get("DANHIP_WGRAD_STREAM", "1") != "1":
+        return
+    if _WGRAD["side"] is None:
+        _WGRAD["side"] = torch.cuda.Stream()
+    _WGRAD["main"] = torch.cuda.current_stream()
+    _WGRAD["on"] = True
+
+
+def wgrad_overlap_join():
+    """The launching stream waits for every weight gradient issued on the side stream; releases the kept tensors."""
+    if _WGRAD["on"]:
+        torch.cuda.current_stream().wait_stream(_WGRAD["side"])
+    _WGRAD["on"] = False
+    _WGRAD["keep"].clear()
+
+
+def wgrad_streams():
+    """Streams gradient producers may be running on (the data-parallel buckets wait for all of them)."""
+    return [_WGRAD["main"], _WGRAD["side"]] if _WGRAD["on"] else []
 
 
 # Optional callback(param) invoked right after a layer's weight/bias gradients have been produced in backward
@@ -296,17 +329,32 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, stream())
                 _prof_end(e0, d, 1)
         dw = None
+        hooked = False
         if need_dw:
             sink = _grad_sink(wp) if wp is not None else None
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
-            e0 = _prof_begin()
-            call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real, stream())
-            _prof_end(e0, d, 2)
+            if _WGRAD["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
+                side = _WGRAD["side"]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                side.wait_event(ev)
+                e0 = _prof_begin(side)                  # (explicit stream handle: no stream-context switch per layer on the host)
+                call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
+                     ctypes.c_void_p(side.cuda_stream))
+                _prof_end(e0, d, 2, side)
+                if GRAD_READY_HOOK is not None and wp is not None:
+                    GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
+                _WGRAD["keep"].append((g, x))
+                hooked = True
+            else:
+                e0 = _prof_begin()
+                call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real, stream())
+                _prof_end(e0, d, 2)
             if sink is not None:
                 dw = None
         if db_sink is not None:
             db = None
-        if GRAD_READY_HOOK is not None and wp is not None:
+        if GRAD_READY_HOOK is not None and wp is not None and not hooked:
             GRAD_READY_HOOK(wp)
         return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None
 

@@ -140,9 +140,13 @@ class DetectorTrainer(object):
         ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
         terms = self.loss_terms(images_u8, *targets)
         accs = [t[2] for t in terms]
-        torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
-        ops.GRAD_READY_HOOK = None
+        ops.wgrad_overlap_begin()                             # weight gradients on a second stream, next to the data gradients
+        try:
+            torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
+        finally:
+            ops.GRAD_READY_HOOK = None
         self.buckets.finish()
+        ops.wgrad_overlap_join()
         lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
         self.flat.sgd_step(lr, self.momentum, grad_scale=1.0 / self.loss_scale)

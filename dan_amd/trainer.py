@@ -157,10 +157,16 @@ class GradBuckets(object):
         while self.next_bucket < len(self.bounds) and self.bounds[self.next_bucket][0] >= self.done_upto:
             s, e = self.bounds[self.next_bucket]
             if self.on_gpu:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                from . import ops
+                producers = {st.cuda_stream: st for st in [torch.cuda.current_stream()] + ops.wgrad_streams()}
+                evs = []
+                for st in producers.values():          # gradients are produced on the backward stream AND the weight-gradient stream
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
                 with torch.cuda.stream(self.comm_stream):
-                    self.comm_stream.wait_event(ev)
+                    for ev in evs:
+                        self.comm_stream.wait_event(ev)
                     self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
             else:                                    # gloo / CPU tensors (unit tests)
                 self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
