@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--deform-offsets", type=float, default=0.0,
                     help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
                          "fractional, spread-out positions (SURVEY 8d asks for a second run at R = 2)")
+    ap.add_argument("--no-serialized-roofline", action="store_true",
+                    help="skip the two extra steps that time the dominant kernel with the weight-gradient stream off (use under rocprofv3 so "
+                         "its per-kernel averages cover the timed region's launches only)")
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
@@ -161,7 +164,7 @@ def main():
     # a backward kernel in the timed region includes the time it shares the chip.  For reference the same kernels are also timed
     # serialised (second stream off) in two extra steps AFTER the timed region; that figure is reported beside the in-region one.
     prof_serial = None
-    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and rank == 0:
+    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and rank == 0 and not args.no_serialized_roofline:
         os.environ["DANHIP_WGRAD_STREAM"] = "0"
         saved_graph, trainer._graph = trainer._graph, None
         ops.PROFILE = {}
