@@ -164,7 +164,7 @@ def main():
     # a backward kernel in the timed region includes the time it shares the chip.  For reference the same kernels are also timed
     # serialised (second stream off) in two extra steps AFTER the timed region; that figure is reported beside the in-region one.
     prof_serial = None
-    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and rank == 0 and not args.no_serialized_roofline:
+    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and world == 1 and not args.no_serialized_roofline:   # (world > 1 runs serialised anyway)
         os.environ["DANHIP_WGRAD_STREAM"] = "0"
         saved_graph, trainer._graph = trainer._graph, None
         ops.PROFILE = {}
@@ -263,7 +263,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": _lib.ACT_NAME, "data": "synthetic",
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
-                       "step_launch": "hipGraph replay" if (args.graph and world == 1) else "eager"},
+                       "step_launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
+                       "weight_gradient_stream": bool(world == 1 and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],

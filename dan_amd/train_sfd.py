@@ -140,7 +140,10 @@ class DetectorTrainer(object):
         ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
         terms = self.loss_terms(images_u8, *targets)
         accs = [t[2] for t in terms]
-        ops.wgrad_overlap_begin()                             # weight gradients on a second stream, next to the data gradients
+        # weight gradients on a second stream, next to the data gradients.  Single process only for now: with the bucketed all-reduce
+        # (a third stream) the combination stalled under the gloo stand-in (tools/debug_dp_overlap.py) and cannot be tried on RCCL here
+        if not self.buckets.enabled:
+            ops.wgrad_overlap_begin()
         try:
             torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
         finally:
