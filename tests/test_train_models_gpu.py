@@ -98,6 +98,32 @@ def test_graph_captured_step_equals_eager_steps(dev):
     assert l0[-1] < l0[0]                                  # and it trains
 
 
+def test_weight_gradient_stream_does_not_change_the_trajectory(dev, monkeypatch):
+    """ops.wgrad_overlap_begin/join: weight gradients issued on a second stream (default for single-process training) against the same
+    steps with everything on one stream — gradients after a step and weights after three, up to fp32-atomics order."""
+    from dan_amd import ops, synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    imgs = synthetic.make_images(3, 160, 128, dev, seed=31)
+    gts = synthetic.make_gt_boxes(3, 160, 128, seed=32, max_faces=6)
+    anchors = AnchorConfig(160, 128, dev)
+    loc_t, cls_t, _ = anchors.encode_batch(gts)
+    runs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("DANHIP_WGRAD_STREAM", on)
+        tr = SFDTrainer(SFDModel(device=dev, seed=6), world=1)
+        tr.train_step(imgs, loc_t, cls_t)
+        torch.cuda.synchronize()
+        assert not ops._WGRAD["on"] and not ops._WGRAD["keep"]          # joined, nothing kept alive
+        g1 = tr.flat.g.clone()
+        for _ in range(2):
+            tr.train_step(imgs, loc_t, cls_t)
+        runs.append((g1, tr.flat.w.clone()))
+    (ga, wa), (gb, wb) = runs
+    assert (ga - gb).abs().max().item() <= 1e-3 * ga.abs().max().item()
+    assert (wa - wb).abs().max().item() <= 1e-3 * wa.abs().max().item()
+    assert ga.abs().max().item() > 0
+
+
 def test_graph_captured_dan_step_advances_the_routing_stream(dev):
     from dan_amd import synthetic
     from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
