@@ -1,6 +1,8 @@
 """S3FD training / inference graph on libdanhip — the MI355X equivalent of the reference's train_sfd.py
 (input_pipeline anchor configuration :171-222 and sfd_model_fn :261-467) and eval_sfd.py's inference graph (:232-283).
 """
+import os
+
 import torch
 
 from . import ops
@@ -142,7 +144,7 @@ class DetectorTrainer(object):
         accs = [t[2] for t in terms]
         # weight gradients on a second stream, next to the data gradients.  Single process only for now: with the bucketed all-reduce
         # (a third stream) the combination stalled under the gloo stand-in (tools/debug_dp_overlap.py) and cannot be tried on RCCL here
-        if not self.buckets.enabled:
+        if not self.buckets.enabled or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
             ops.wgrad_overlap_begin()
         try:
             torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])

@@ -123,6 +123,9 @@ class GradBuckets(object):
     def __init__(self, flat, bucket_bytes=32 << 20):
         self.flat = flat
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # DANHIP_FAKE_ALLREDUCE=1 (diagnosis, single process): run the bucket machinery with a device-only stand-in for the collective
+        self.fake = (not self.enabled) and os.environ.get("DANHIP_FAKE_ALLREDUCE") == "1" and flat.g.is_cuda
+        self.enabled = self.enabled or self.fake
         per = max(1, bucket_bytes // 4)
         self.bounds = []
         end = flat.total
@@ -167,7 +170,10 @@ class GradBuckets(object):
                 with torch.cuda.stream(self.comm_stream):
                     for ev in evs:
                         self.comm_stream.wait_event(ev)
-                    self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                    if self.fake:
+                        self.flat.g[s:e].mul_(1.0)
+                    else:
+                        self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
             else:                                    # gloo / CPU tensors (unit tests)
                 self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
             self.next_bucket += 1
