@@ -102,3 +102,32 @@ def test_gradient_buckets_allreduce_gloo_world2(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_fused_head_blocks_in_the_flat_buffer():
+    """FlatParams lays loc_i | cls_i out as ONE block (VariableStore.fuse): the members are strided views of it (weights and
+    gradients), the block is one optimizer segment, and TF-named export / load still see the separate variables."""
+    import torch
+    from dan_amd.net.variables import VariableStore
+    from dan_amd.trainer import FlatParams, GradBuckets
+    vs = VariableStore(device="cpu")
+    a = vs.get("h/loc_0/kernel", (3, 3, 16, 4), "glorot")
+    b = vs.get("h/loc_0/bias", (4,), "zeros")
+    c = vs.get("h/cls_0/kernel", (3, 3, 16, 2), "glorot")
+    d = vs.get("h/cls_0/bias", (2,), 0.5)
+    vs.get("x/kernel", (1, 1, 8, 8), "glorot")
+    a0, c0 = a.detach().clone(), c.detach().clone()
+    kk, bb = ("h/loc_0/kernel", "h/cls_0/kernel"), ("h/loc_0/bias", "h/cls_0/bias")
+    assert vs.fuse(kk, 3) is None and vs.fuse(bb, 0) is None           # not laid out yet: the caller concatenates
+    flat = FlatParams(vs)
+    W, B = vs.fuse(kk, 3), vs.fuse(bb, 0)
+    assert W.shape == (3, 3, 16, 6) and W.is_contiguous() and torch.equal(B, torch.tensor([0, 0, 0, 0, .5, .5]))
+    assert torch.equal(W[..., :4], a0) and torch.equal(W[..., 4:], c0) and torch.equal(a, a0) and torch.equal(c, c0)
+    assert flat.names == ["h/loc_0/kernel", "h/loc_0/bias", "x/kernel"] and flat.sizes[:2] == [3 * 3 * 16 * 6, 6]
+    W._danhip_grad[..., 5] = 7.0                                         # a gradient written into the block shows up in the member
+    assert c.grad[..., 1].eq(7).all() and a.grad.eq(0).all()
+    assert GradBuckets(flat).start_of["h/cls_0/kernel"] == flat.starts[0]
+    assert set(n for n, _ in vs.named()) == {"h/loc_0/kernel", "h/loc_0/bias", "h/cls_0/kernel", "h/cls_0/bias", "x/kernel"}
+    vs.load_tf_named({"h/cls_0/kernel": torch.ones(3, 3, 16, 2)})        # loading by TF name writes through the view
+    assert W[..., 4:].eq(1).all() and torch.equal(W[..., :4], a0)
+    assert torch.equal(vs.export_tf_named()["h/loc_0/bias"], torch.zeros(4))
