@@ -148,6 +148,9 @@ class DetectorTrainer(object):
             ops.wgrad_overlap_begin()
         try:
             torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
+        except BaseException:
+            ops.wgrad_overlap_join()                          # never leave the second stream armed behind a failed step
+            raise
         finally:
             ops.GRAD_READY_HOOK = None
         self.buckets.finish()
