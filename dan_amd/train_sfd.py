@@ -101,7 +101,8 @@ class DetectorTrainer(object):
     def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64),
                  lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01), loss_scale=None):
         self.model = model
-        # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale and the
+        # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale (the factor enters
+        # through the loss terms' `scale`: their backward ignores the upstream seed) and the
         # fused optimizer divides the (fp32) weight gradients again; bf16 has fp32's exponent range and needs none
         from ._lib import ACT_NAME
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if ACT_NAME == "fp16" else 1.0)
@@ -147,7 +148,7 @@ class DetectorTrainer(object):
         if not self.buckets.enabled or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
             ops.wgrad_overlap_begin()
         try:
-            torch.autograd.backward(accs, [torch.full_like(a, self.loss_scale) for a in accs])
+            torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
         except BaseException:
             ops.wgrad_overlap_join()                          # never leave the second stream armed behind a failed step
             raise
@@ -215,7 +216,7 @@ class SFDTrainer(DetectorTrainer):
 
     def loss_terms(self, images_u8, loc_targets, cls_targets):
         loc, cls = self.model.forward(images_u8)
-        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=1.0 / self.world)
+        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=self.loss_scale / self.world)
         return [("face", 1.0, acc)]
 
     def losses(self):

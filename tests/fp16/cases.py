@@ -106,6 +106,15 @@ def main():
     assert torch.isfinite(tr.flat.w).all() and torch.isfinite(tr.flat.g).all()
     assert (tr.flat.w - w0).abs().max().item() > 0
     assert tr.flat.g.abs().max().item() > 1.0          # gradients are still in loss-scale units inside the flat buffer
+    # ... and they ARE the loss-scaled gradients: the same first step with loss_scale = 1 gives 1/1024 of them (fp16 rounding and the
+    # underflow the scale exists to avoid aside)
+    norms = []
+    for s in (1024.0, 1.0):
+        m2 = DANModel(device=dev, deform=True)
+        t2 = DANTrainer(m2, anchors, world=1, loss_scale=s)
+        t2.train_step(imgs, *targets)
+        norms.append(t2.flat.g.norm().item())
+    assert 0.8 < norms[0] / (1024.0 * norms[1]) < 1.25, norms
     n += 1
     print("FP16-OK", n, "groups; DAN-Deform losses", ["%.4f" % t for t in totals])
 

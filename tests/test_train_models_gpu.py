@@ -124,6 +124,28 @@ def test_weight_gradient_stream_does_not_change_the_trajectory(dev, monkeypatch)
     assert ga.abs().max().item() > 0
 
 
+def test_loss_scale_reaches_the_backward_and_cancels_in_the_optimizer(dev):
+    """DetectorTrainer(loss_scale=s): the backward pass runs on s * loss (fp16 build: s = 1024) and danhip_sgd_momentum_flat divides
+    the weight gradients by s again — the flat gradient buffer is s times the unscaled one and the trajectory is unchanged
+    (s a power of two: exact in bf16 up to atomics order)."""
+    from dan_amd import synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    imgs = synthetic.make_images(2, 128, 128, dev, seed=41)
+    gts = synthetic.make_gt_boxes(2, 128, 128, seed=42, max_faces=5)
+    anchors = AnchorConfig(128, 128, dev)
+    loc_t, cls_t, _ = anchors.encode_batch(gts)
+    runs = []
+    for s in (1.0, 1024.0):
+        tr = SFDTrainer(SFDModel(device=dev, seed=7), world=1, loss_scale=s)
+        tr.train_step(imgs, loc_t, cls_t)
+        g1 = tr.flat.g.clone()
+        tr.train_step(imgs, loc_t, cls_t)
+        runs.append((g1, tr.flat.w.clone()))
+    (g_a, w_a), (g_b, w_b) = runs
+    assert (g_b / 1024.0 - g_a).abs().max().item() <= 2e-3 * g_a.abs().max().item()
+    assert (w_a - w_b).abs().max().item() <= 1e-3 * w_a.abs().max().item()
+
+
 def test_graph_captured_dan_step_advances_the_routing_stream(dev):
     from dan_amd import synthetic
     from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
