@@ -80,6 +80,7 @@ SIGNATURES = {
     "danhip_detection_loss_fwd": [P, P, P, P, P, P, P, P, I32, I32, P],
     "danhip_detection_loss_bwd": [P, P, P, P, P, P, P, FL, FL, I32, I32, P],
     "danhip_sgd_momentum_flat": [P, P, P, P, P, P, I32, I64, FL, FL, FL, P, P],
+    "danhip_sgd_momentum_flat_dynamic": [P, P, P, P, P, P, I32, I64, FL, FL, P, P, P],
     "danhip_anchors_generate": [P, P, P, P, P, P, I32, I32, I32, FL, FL, FL, I32, P],
     "danhip_iou_matrix": [P, P, P, P, P, P, P, I32, I32, P],
     "danhip_dual_max_match": [P, I32, I32, FL, FL, ctypes.c_int, P, P, P, ctypes.c_size_t, P],

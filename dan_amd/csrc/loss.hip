@@ -205,11 +205,15 @@ __global__ void detection_loss_bwd_kernel(const float* __restrict__ cls, const f
 // Vector form: every segment starts on a 64-element boundary and total is padded to one (danhip_sgd_momentum_flat checks), so a
 // float4 never straddles two variables.  A thread walks float4s in ascending order: its segment index only moves forward
 // (one binary search at its first element, then a short scan), instead of a 7-step search per element.
+// `dyn` (optional): the device-resident dynamic loss-scale state {scale, good_steps, growth_interval, found_nonfinite}: the gradient is
+// divided by dyn[0] and a step whose gradients hold an inf / NaN (dyn[3] != 0, set by grad_nonfinite_kernel) leaves w and v untouched.
 __global__ void sgd_momentum_flat_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, const long* __restrict__ seg,
                                          const float* __restrict__ gmult, const float* __restrict__ wdc, int nseg, long total, float lr,
-                                         float momentum, float gscale, float* __restrict__ l2_out) {
+                                         float momentum, float gscale, float* __restrict__ l2_out, const float* __restrict__ dyn) {
   __shared__ float sh[8];
   float l2 = 0.f;
+  bool skip = false;
+  if (dyn) { gscale = 1.f / dyn[0]; skip = dyn[3] != 0.f; }
   const long n4 = total >> 2;
   long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int lo = 0;
@@ -229,13 +233,37 @@ __global__ void sgd_momentum_flat_kernel(float* __restrict__ w, const float* __r
     vi.z = momentum * vi.z + (gi.z * gscale + c * wi.z) * gm;
     vi.w = momentum * vi.w + (gi.w * gscale + c * wi.w) * gm;
     wi.x -= lr * vi.x; wi.y -= lr * vi.y; wi.z -= lr * vi.z; wi.w -= lr * vi.w;
-    reinterpret_cast<float4*>(v)[q] = vi;
-    reinterpret_cast<float4*>(w)[q] = wi;
+    if (!skip) {
+      reinterpret_cast<float4*>(v)[q] = vi;
+      reinterpret_cast<float4*>(w)[q] = wi;
+    }
   }
   if (l2_out) {
     l2 = block_sum(l2, sh);
     if (threadIdx.x == 0) atomicAdd(l2_out, l2);
   }
+}
+
+__global__ void grad_nonfinite_kernel(const float* __restrict__ g, long total, float* __restrict__ dyn) {
+  bool bad = false;
+  const long n4 = total >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+    const float4 gi = reinterpret_cast<const float4*>(g)[q];
+    const float t = gi.x + gi.y + gi.z + gi.w;            // inf - inf and NaN both end up non-finite
+    bad = bad || !(fabsf(t) <= 3.4028234663852886e+38f) || !(fabsf(gi.x) <= 3.4028234663852886e+38f) || !(fabsf(gi.y) <= 3.4028234663852886e+38f) ||
+          !(fabsf(gi.z) <= 3.4028234663852886e+38f) || !(fabsf(gi.w) <= 3.4028234663852886e+38f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) dyn[3] = 1.f;  // benign race: every writer stores the same value
+}
+// torch.cuda.amp.GradScaler's rule: halve after a non-finite step, double after `interval` clean ones
+__global__ void loss_scale_update_kernel(float* __restrict__ dyn) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (dyn[3] != 0.f) { dyn[0] = fmaxf(dyn[0] * 0.5f, 1.f); dyn[1] = 0.f; }
+  else {
+    dyn[1] += 1.f;
+    if (dyn[1] >= dyn[2]) { dyn[0] = fminf(dyn[0] * 2.f, 16777216.f); dyn[1] = 0.f; }
+  }
+  dyn[3] = 0.f;
 }
 
 inline int grid_for(long total, int block, int cap = 4096) {
@@ -309,7 +337,27 @@ extern "C" int danhip_sgd_momentum_flat(float* w, const float* g, float* v, cons
   DH_REQUIRE(total % 4 == 0 && (((uintptr_t)w | (uintptr_t)g | (uintptr_t)v) & 15) == 0, DANHIP_EINVAL,
              "sgd_momentum_flat: buffers must be 16-byte aligned, total a multiple of 4 (segments start on 64-element boundaries)");
   hipLaunchKernelGGL(sgd_momentum_flat_kernel, dim3(grid_for(total / 4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, w, g, v,
-                     reinterpret_cast<const long*>(seg_starts), gmult, wd_coef, nseg, (long)total, lr, momentum, grad_scale, l2_out);
+                     reinterpret_cast<const long*>(seg_starts), gmult, wd_coef, nseg, (long)total, lr, momentum, grad_scale, l2_out,
+                     (const float*)nullptr);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+// The same update under a dynamic loss scale kept on the device (no host round trip, capturable in the step's hipGraph):
+// loss_scale_state = {scale, clean steps so far, growth interval, scratch flag}.  One call = non-finite check of g, the update with
+// g / scale (skipped entirely when the check fired), then the scale rule (x0.5 after a skipped step, x2 after `interval` clean ones).
+extern "C" int danhip_sgd_momentum_flat_dynamic(float* w, const float* g, float* v, const int64_t* seg_starts, const float* gmult, const float* wd_coef,
+                                                int32_t nseg, int64_t total, float lr, float momentum, float* loss_scale_state, float* l2_out,
+                                                void* stream) {
+  DH_REQUIRE(w && g && v && seg_starts && gmult && wd_coef && loss_scale_state && nseg > 0 && total > 0, DANHIP_EINVAL,
+             "sgd_momentum_flat_dynamic: bad arguments");
+  DH_REQUIRE(total % 4 == 0 && (((uintptr_t)w | (uintptr_t)g | (uintptr_t)v) & 15) == 0, DANHIP_EINVAL,
+             "sgd_momentum_flat_dynamic: buffers must be 16-byte aligned, total a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(grid_for(total / 4, 256, 2048)), dim3(256), 0, s, g, (long)total, loss_scale_state);
+  hipLaunchKernelGGL(sgd_momentum_flat_kernel, dim3(grid_for(total / 4, 256, 4096)), dim3(256), 0, s, w, g, v, reinterpret_cast<const long*>(seg_starts),
+                     gmult, wd_coef, nseg, (long)total, lr, momentum, 1.f, l2_out, (const float*)loss_scale_state);
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, s, loss_scale_state);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

@@ -536,6 +536,10 @@ def head_split(h, loc, cls, nneg, npos, off):
     return _HeadSplit.apply(h, loc, cls, nneg, npos, off)
 
 
+# 1-element device tensor holding the current dynamic loss scale (set by the trainer around its backward pass), or None
+LOSS_SCALE_DEV = None
+
+
 class _DetectionLoss(torch.autograd.Function):
     """Hard-negative mining + CE*(ratio+1) + smooth-L1 (train_sfd.py:350-417 / train_dan.py:286-324,470-478).
     Returns a 4-vector acc = [ce_sum, n_selected, loc_sum, n_pos] (device, no sync); the loss is
@@ -568,6 +572,9 @@ class _DetectionLoss(torch.autograd.Function):
         dloc = torch.empty_like(loc)
         call("danhip_detection_loss_bwd", ptr(cls), ptr(loc), ptr(loc_t), ptr(sel), ptr(acc), ptr(dcls), ptr(dloc), float((ratio + 1.0) * scale),
              float(scale), B, A, stream())
+        if LOSS_SCALE_DEV is not None:                  # dynamic loss scale (fp16 build): a device scalar, so the step stays capturable
+            dcls.mul_(LOSS_SCALE_DEV)
+            dloc.mul_(LOSS_SCALE_DEV)
         return dcls, dloc, None, None, None, None, None
 
 

@@ -99,13 +99,23 @@ class DetectorTrainer(object):
     Subclasses implement loss_terms(images_u8, *targets) -> list of (name, acc4 tensor)."""
 
     def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64),
-                 lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01), loss_scale=None):
+                 lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01), loss_scale=None, dynamic_loss_scale=None,
+                 loss_scale_growth_interval=1000):
         self.model = model
         # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale (the factor enters
         # through the loss terms' `scale`: their backward ignores the upstream seed) and the
         # fused optimizer divides the (fp32) weight gradients again; bf16 has fp32's exponent range and needs none
         from ._lib import ACT_NAME
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if ACT_NAME == "fp16" else 1.0)
+        # dynamic_loss_scale: the scale lives on the device ({scale, clean steps, growth interval, flag}); the loss terms multiply their
+        # gradients by it, the optimizer entry checks the gradients for inf / NaN, skips such a step and applies GradScaler's rule
+        # (x0.5 after a skipped step, x2 after `interval` clean ones).  `loss_scale` is then the initial value.
+        self.ls_state = None
+        if dynamic_loss_scale is None:                        # default: on for the fp16 build unless a static scale was asked for
+            dynamic_loss_scale = ACT_NAME == "fp16" and loss_scale is None
+        if dynamic_loss_scale:
+            self.ls_state = torch.tensor([self.loss_scale, 0.0, float(loss_scale_growth_interval), 0.0], dtype=torch.float32, device=model.vs.device)
+            self.loss_scale = 1.0                             # host-side factor of the loss terms; the device scalar carries the scale
         self.world = world
         self.negative_ratio = negative_ratio
         self.momentum = momentum
@@ -147,6 +157,7 @@ class DetectorTrainer(object):
         # (a third stream) the combination stalled under the gloo stand-in (tools/debug_dp_overlap.py) and cannot be tried on RCCL here
         if not self.buckets.enabled or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
             ops.wgrad_overlap_begin()
+        ops.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
         try:
             torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
         except BaseException:
@@ -154,11 +165,12 @@ class DetectorTrainer(object):
             raise
         finally:
             ops.GRAD_READY_HOOK = None
+            ops.LOSS_SCALE_DEV = None
         self.buckets.finish()
         ops.wgrad_overlap_join()
         lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
-        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0 / self.loss_scale)
+        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0 / self.loss_scale, dynamic_state=self.ls_state)
         self.step_no += 1
         self.last = terms
         return terms

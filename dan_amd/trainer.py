@@ -104,10 +104,15 @@ class FlatParams(object):
     def zero_grad(self):
         self.g.zero_()
 
-    def sgd_step(self, lr, momentum=0.9, grad_scale=1.0):
+    def sgd_step(self, lr, momentum=0.9, grad_scale=1.0, dynamic_state=None):
+        """dynamic_state: fp32[4] device tensor {loss scale, clean steps, growth interval, flag} (danhip_sgd_momentum_flat_dynamic)."""
         self.l2.zero_()
-        call("danhip_sgd_momentum_flat", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc), len(self.names),
-             self.total, float(lr), float(momentum), float(grad_scale), ptr(self.l2), stream())
+        if dynamic_state is not None:
+            call("danhip_sgd_momentum_flat_dynamic", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc),
+                 len(self.names), self.total, float(lr), float(momentum), ptr(dynamic_state), ptr(self.l2), stream())
+        else:
+            call("danhip_sgd_momentum_flat", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc), len(self.names),
+                 self.total, float(lr), float(momentum), float(grad_scale), ptr(self.l2), stream())
         from . import ops
         ops.WEIGHT_EPOCH += 1          # the kernel wrote the parameters through raw pointers: cached bf16 packings are stale
         ops.repack_all()               # ... and are refreshed by one launch for all conv weights

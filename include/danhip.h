@@ -192,6 +192,13 @@ int danhip_detection_loss_bwd(const float* cls, const float* loc, const float* l
 int danhip_sgd_momentum_flat(float* w, const float* g, float* v, const int64_t* seg_starts, const float* gmult,
                              const float* wd_coef, int32_t nseg, int64_t total, float lr, float momentum, float grad_scale,
                              float* l2_out, void* stream);
+/* The same update under a DYNAMIC loss scale kept on the device (fp16 build; no host round trip, capturable in a hipGraph).
+ * loss_scale_state: 4 floats {scale, clean steps so far, growth interval, scratch flag}.  One call = non-finite check of g; the
+ * update with g / scale, skipped entirely (w, v untouched) when the check fired; then torch.cuda.amp.GradScaler's rule: scale x0.5
+ * after a skipped step, x2 after `interval` clean ones.  The loss terms multiply their gradients by state[0] on the device. */
+int danhip_sgd_momentum_flat_dynamic(float* w, const float* g, float* v, const int64_t* seg_starts, const float* gmult,
+                                     const float* wd_coef, int32_t nseg, int64_t total, float lr, float momentum,
+                                     float* loss_scale_state, float* l2_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Anchor / box index-compare kernels (fp32 + int32, bit-exact vs the oracle; utility/anchor_manipulator.py).

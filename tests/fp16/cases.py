@@ -87,12 +87,12 @@ def main():
         assert err <= 0.01 * want.abs().max().item(), (name, err, want.abs().max().item())
     n += 1
 
-    # DAN-Deform (configs[4]) trains: static loss scale 1024 in the backward pass, finite losses, parameters move
+    # DAN-Deform (configs[4]) trains: dynamic loss scale (starts at 1024) in the backward pass, finite losses, parameters move
     from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
     model = DANModel(device=dev, deform=True)
     anchors = dan_anchor_config(128, 128, dev)
     tr = DANTrainer(model, anchors, world=1)
-    assert tr.loss_scale == 1024.0
+    assert tr.loss_scale == 1.0 and tr.ls_state.tolist() == [1024.0, 0.0, 1000.0, 0.0]      # the scale lives on the device
     imgs = synthetic.make_images(2, 128, 128, dev, seed=3)
     gts = synthetic.make_gt_boxes(2, 128, 128, seed=4, max_faces=5)
     targets = encode_batch_dan(anchors, gts)
@@ -106,12 +106,13 @@ def main():
     assert torch.isfinite(tr.flat.w).all() and torch.isfinite(tr.flat.g).all()
     assert (tr.flat.w - w0).abs().max().item() > 0
     assert tr.flat.g.abs().max().item() > 1.0          # gradients are still in loss-scale units inside the flat buffer
+    assert tr.ls_state.tolist() == [1024.0, 3.0, 1000.0, 0.0]                               # three clean steps, none skipped
     # ... and they ARE the loss-scaled gradients: the same first step with loss_scale = 1 gives 1/1024 of them (fp16 rounding and the
     # underflow the scale exists to avoid aside)
     norms = []
     for s in (1024.0, 1.0):
         m2 = DANModel(device=dev, deform=True)
-        t2 = DANTrainer(m2, anchors, world=1, loss_scale=s)
+        t2 = DANTrainer(m2, anchors, world=1, loss_scale=s, dynamic_loss_scale=False)
         t2.train_step(imgs, *targets)
         norms.append(t2.flat.g.norm().item())
     assert 0.8 < norms[0] / (1024.0 * norms[1]) < 1.25, norms

@@ -146,6 +146,69 @@ def test_loss_scale_reaches_the_backward_and_cancels_in_the_optimizer(dev):
     assert (w_a - w_b).abs().max().item() <= 1e-3 * w_a.abs().max().item()
 
 
+def test_dynamic_loss_scale_entry_skips_nonfinite_steps_and_follows_the_growth_rule(dev):
+    """danhip_sgd_momentum_flat_dynamic against the plain entry: same update with g / scale; a gradient holding inf or NaN leaves w and v
+    untouched and halves the scale; `interval` clean steps double it."""
+    from dan_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(3)
+    n = 64 * 40
+    w0 = torch.randn(n, generator=g).to(dev)
+    gr = torch.randn(n, generator=g).to(dev)
+    seg = torch.tensor([0, 64 * 10, n], dtype=torch.int64, device=dev)
+    gm = torch.tensor([1.0, 2.0], device=dev)
+    wd = torch.tensor([5e-4, 0.0], device=dev)
+
+    def plain(w, v, grad, scale):
+        call("danhip_sgd_momentum_flat", ptr(w), ptr(grad), ptr(v), ptr(seg), ptr(gm), ptr(wd), 2, n, 0.1, 0.9, 1.0 / scale, None, stream())
+
+    def dyn(w, v, grad, state):
+        call("danhip_sgd_momentum_flat_dynamic", ptr(w), ptr(grad), ptr(v), ptr(seg), ptr(gm), ptr(wd), 2, n, 0.1, 0.9, ptr(state), None, stream())
+
+    state = torch.tensor([256.0, 0.0, 2.0, 0.0], device=dev)
+    wa, va, wb, vb = w0.clone(), torch.zeros_like(w0), w0.clone(), torch.zeros_like(w0)
+    plain(wa, va, gr * 256.0, 256.0)
+    dyn(wb, vb, gr * 256.0, state)
+    torch.cuda.synchronize()
+    assert torch.equal(wa, wb) and torch.equal(va, vb)
+    assert state.tolist() == [256.0, 1.0, 2.0, 0.0]
+    dyn(wb, vb, gr * 256.0, state)                       # second clean step: interval reached -> scale doubles
+    assert state.tolist() == [512.0, 0.0, 2.0, 0.0]
+    for bad in (float("inf"), float("nan"), float("-inf")):
+        wk, vk = wb.clone(), vb.clone()
+        gbad = (gr * 512.0).clone()
+        gbad[n - 3] = bad
+        before = state[0].item()
+        dyn(wb, vb, gbad, state)
+        torch.cuda.synchronize()
+        assert torch.equal(wb, wk) and torch.equal(vb, vk), bad      # skipped
+        assert state.tolist() == [before * 0.5, 0.0, 2.0, 0.0], (bad, state.tolist())
+
+
+def test_trainer_with_dynamic_loss_scale(dev):
+    """DetectorTrainer(dynamic_loss_scale=True): the device scale multiplies the loss gradients and cancels in the optimizer (same
+    trajectory as the static run), grows after the interval, and an overflowing scale costs one skipped step, not the run."""
+    from dan_amd import synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    imgs = synthetic.make_images(2, 128, 128, dev, seed=51)
+    gts = synthetic.make_gt_boxes(2, 128, 128, seed=52, max_faces=5)
+    anchors = AnchorConfig(128, 128, dev)
+    loc_t, cls_t, _ = anchors.encode_batch(gts)
+    ref = SFDTrainer(SFDModel(device=dev, seed=8), world=1, loss_scale=1.0)
+    tr = SFDTrainer(SFDModel(device=dev, seed=8), world=1, loss_scale=256.0, dynamic_loss_scale=True, loss_scale_growth_interval=2)
+    for _ in range(2):
+        ref.train_step(imgs, loc_t, cls_t)
+        tr.train_step(imgs, loc_t, cls_t)
+    assert (ref.flat.w - tr.flat.w).abs().max().item() <= 1e-3 * ref.flat.w.abs().max().item()
+    assert tr.ls_state.tolist() == [512.0, 0.0, 2.0, 0.0]
+    tr.ls_state[0] = float(2.0 ** 126)                   # the scaled head gradients overflow fp32 -> inf in the weight gradients
+    w_before = tr.flat.w.clone()
+    tr.train_step(imgs, loc_t, cls_t)
+    assert torch.equal(tr.flat.w, w_before) and tr.ls_state[0].item() == float(2.0 ** 125)
+    tr.ls_state[0] = 512.0
+    tr.train_step(imgs, loc_t, cls_t)
+    assert not torch.equal(tr.flat.w, w_before) and torch.isfinite(tr.flat.w).all()
+
+
 def test_graph_captured_dan_step_advances_the_routing_stream(dev):
     from dan_amd import synthetic
     from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
