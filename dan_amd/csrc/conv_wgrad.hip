@@ -18,6 +18,7 @@ struct WgradArgs {
   int N, H, W, C, Ho, Wo, Co8, Cout, cin_real;
   int kh, kw, stride, pad_t, pad_l;
   int M, ktiles, kt_per_split;
+  int linear;
   int ci_tiles;        // number of input-channel tiles (blockIdx.x = co_tile * ci_tiles + ci_tile)
   int tapcols;         // 1: tile columns are the taps (C == 8 first layer): column chunk t = tap t, channels 0..7
   FastDiv div_wo, div_howo;
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         const int m = mb + prow;
         const int cs = xc ^ swz<RBX>(prow);                           // source chunk for this LDS position
         const bf16_t* src = zero;
-        if (m < a.M) {
+        if (a.linear) {                                               // pointwise, stride 1: pixel m of x IS pixel m of dy, no decomposition
+          const int cc = ci0 + cs * 8;
+          if (m < a.M && cc < a.C) src = a.x + ((size_t)m * a.C + cc);
+        } else if (m < a.M) {
           const unsigned n = fdiv((unsigned)m, a.div_howo);
           const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
           const unsigned ho = fdiv(rem, a.div_wo);
@@ -261,6 +265,7 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
     return a.Co8 > 64 ? launch_wgrad<128, 128, 2>(a, s) : launch_wgrad<128, 64, 2>(a, s);
   }
   a.tapcols = 0;
+  a.linear = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W;
   const bool ci_small = d->Cin <= 64, co_small = a.Co8 <= 64;
   if (ci_small && co_small) return launch_wgrad<64, 64, 2>(a, s);
   if (ci_small) return launch_wgrad<64, 128, 2>(a, s);
