@@ -93,6 +93,7 @@ def main():
     from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
 
     rank, world, local = init_distributed()
+    multi = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())   # DANHIP_FORCE_DIST: 1-rank group
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local)
     B, S = args.batch_per_gpu, args.size
@@ -135,7 +136,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +165,7 @@ def main():
     # a backward kernel in the timed region includes the time it shares the chip.  For reference the same kernels are also timed
     # serialised (second stream off) in two extra steps AFTER the timed region; that figure is reported beside the in-region one.
     prof_serial = None
-    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and world == 1 and not args.no_serialized_roofline:   # (world > 1 runs serialised anyway)
+    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and not args.no_serialized_roofline:   # every rank: the steps carry collectives
         os.environ["DANHIP_WGRAD_STREAM"] = "0"
         saved_graph, trainer._graph = trainer._graph, None
         ops.PROFILE = {}
@@ -174,7 +175,7 @@ def main():
         prof_serial, ops.PROFILE = ops.PROFILE, None
         trainer._graph = saved_graph
         os.environ["DANHIP_WGRAD_STREAM"] = "1"
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -190,7 +191,7 @@ def main():
                 fn()
             barrier()
             et = time.perf_counter() - e0
-            if world > 1:
+            if multi:
                 t = torch.tensor([et], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 et = float(t.item())
@@ -264,7 +265,7 @@ def main():
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
                        "step_launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
-                       "weight_gradient_stream": bool(world == 1 and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
+                       "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],
@@ -276,7 +277,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

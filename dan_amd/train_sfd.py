@@ -153,9 +153,10 @@ class DetectorTrainer(object):
         ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
         terms = self.loss_terms(images_u8, *targets)
         accs = [t[2] for t in terms]
-        # weight gradients on a second stream, next to the data gradients.  Single process only for now: with the bucketed all-reduce
-        # (a third stream) the combination stalled under the gloo stand-in (tools/debug_dp_overlap.py) and cannot be tried on RCCL here
-        if not self.buckets.enabled or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
+        # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
+        # collectives are device-side (RCCL; checked on hardware with a one-rank group, tests/test_ddp_gpu.py).  gloo's host-staged
+        # all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
+        if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
             ops.wgrad_overlap_begin()
         ops.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
         try:

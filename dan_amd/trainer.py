@@ -127,7 +127,7 @@ class GradBuckets(object):
 
     def __init__(self, flat, bucket_bytes=32 << 20):
         self.flat = flat
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("DANHIP_FORCE_DIST") == "1")
         # DANHIP_FAKE_ALLREDUCE=1 (diagnosis, single process): run the bucket machinery with a device-only stand-in for the collective
         self.fake = (not self.enabled) and os.environ.get("DANHIP_FAKE_ALLREDUCE") == "1" and flat.g.is_cuda
         self.enabled = self.enabled or self.fake
@@ -143,6 +143,8 @@ class GradBuckets(object):
         if cur_end > 0:
             self.bounds.append((0, cur_end))
         self.on_gpu = flat.g.is_cuda
+        # device-side collectives (RCCL) coexist with the weight-gradient stream; gloo's host-staged ones stalled with it
+        self.device_collectives = self.enabled and (getattr(self, "fake", False) or dist.get_backend() == "nccl")
         self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.pending = []
         self.next_bucket = 0
@@ -199,7 +201,10 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # DANHIP_FORCE_DIST=1: initialise the process group (and run the bucketed all-reduce) even for ONE rank — the only way to put the
+    # RCCL code path on a single-GPU box (tests/test_ddp_gpu.py)
+    force = os.environ.get("DANHIP_FORCE_DIST") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # DANHIP_DIST_BACKEND=gloo: the test hook that runs several ranks on ONE GPU (RCCL refuses duplicate devices; gloo stages

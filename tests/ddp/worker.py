@@ -22,12 +22,15 @@ loc_t, cls_t, _ = anchors.encode_batch(gts)
 per = GB // world
 sl = slice(rank * per, (rank + 1) * per)                 # contiguous split (tf_replicate_model_fn.py:458-498)
 tr = SFDTrainer(SFDModel(device=dev, seed=9), world=world)
-assert tr.buckets.enabled == (world > 1)
+forced = os.environ.get("DANHIP_FORCE_DIST") == "1"
+assert tr.buckets.enabled == (world > 1 or forced)
+if forced:
+    assert tr.buckets.device_collectives                 # RCCL group: the weight-gradient stream stays on beside the buckets
 for _ in range(2):
     tr.train_step(imgs[sl].contiguous(), loc_t[sl].contiguous(), cls_t[sl].contiguous())
 torch.cuda.synchronize()
 if rank == 0:
     torch.save({"w": tr.flat.w.cpu(), "g": tr.flat.g.cpu()}, out)
-if world > 1:
+if torch.distributed.is_initialized():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -38,3 +38,18 @@ def test_two_ranks_follow_the_same_trajectory_twice_and_differ_from_one_rank_onl
     rel = (a["w"] - one["w"]).abs().max().item() / scale
     assert rel < 5e-3, rel
     assert a["g"].abs().max().item() > 0
+
+
+def test_rccl_code_path_with_a_one_rank_group(dev, tmp_path):
+    """The only RCCL coverage a one-GPU box allows: DANHIP_FORCE_DIST=1 makes rank 0 of a 1-rank NCCL (= RCCL) group run the bucketed
+    all-reduce on its communication stream, with the weight-gradient stream beside it — same parameters as the plain process."""
+    env = dict(os.environ, DANHIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.pop("DANHIP_DIST_BACKEND", None)
+    out = str(tmp_path / "rccl1.pt")
+    r = subprocess.run([sys.executable, WORKER, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    a = torch.load(out)
+    one = _run(1, str(tmp_path / "plain.pt"), 0)
+    scale = one["w"].abs().max().item()
+    assert (a["w"] - one["w"]).abs().max().item() <= 1e-4 * scale
+    assert torch.isfinite(a["g"]).all() and a["g"].abs().max().item() > 0
