@@ -256,6 +256,10 @@ def main():
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": n // prof_steps,
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
                 "share_of_step_time": round(ms / prof_steps / (dt / args.steps * 1e3), 4), "calibrated": calib,
+                "whole_step": {"what": "all convolution launches of the timed region (forward, data and weight gradients): algorithmic FLOP / wall time",
+                               "tflop_per_step": round(sum(f for _, _, _, f in stats) / prof_steps / 1e12, 3),
+                               "achieved": round(sum(f for _, _, _, f in stats) / prof_steps / (dt / args.steps) / 1e12, 1),
+                               "frac": round(sum(f for _, _, _, f in stats) / prof_steps / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)},
                 "concurrency": ("weight-gradient kernels share the chip with the data-gradient kernels (second stream): in-region durations "
                                 "include the shared time" if serial else None), "serialized": serial}
         out = {
