@@ -209,6 +209,24 @@ def test_trainer_with_dynamic_loss_scale(dev):
     assert not torch.equal(tr.flat.w, w_before) and torch.isfinite(tr.flat.w).all()
 
 
+def test_batch_without_any_face_trains_on_the_negatives_only(dev):
+    """Edge case of the input pipeline (anchor_manipulator.py:286 substitutes a dummy box for an empty list; train_sfd.py:350-417 divides
+    by max(n_pos, 1)): a batch whose images hold no face still gives finite losses and gradients, zero localisation loss, and a step."""
+    from dan_amd import synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    imgs = synthetic.make_images(2, 128, 128, dev, seed=61)
+    anchors = AnchorConfig(128, 128, dev)
+    empty = [torch.zeros((0, 4), device=dev), torch.zeros((0, 4), device=dev)]
+    loc_t, cls_t, _ = anchors.encode_batch(empty)
+    assert (cls_t == 1).sum().item() <= 2 * 6            # at most the dummy [0,0,1,1] box's compensation matches
+    tr = SFDTrainer(SFDModel(device=dev, seed=9), world=1)
+    w0 = tr.flat.w.clone()
+    tr.train_step(imgs, loc_t, cls_t)
+    lv = tr.loss_values()
+    assert all(v == v and abs(v) < 1e4 for v in (lv["total"], lv["face"][0], lv["face"][1])), lv
+    assert torch.isfinite(tr.flat.g).all() and torch.isfinite(tr.flat.w).all() and not torch.equal(tr.flat.w, w0)
+
+
 def test_graph_captured_dan_step_advances_the_routing_stream(dev):
     from dan_amd import synthetic
     from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
