@@ -210,6 +210,17 @@ class DetectorTrainer(object):
         self.last = self._graph_terms
         return self._graph_terms
 
+    # ---- checkpoint / resume (the Estimator's save_checkpoints_steps + resume-from-model_dir behaviour, train_dan.py:549-556)
+    def save(self, prefix, model_scope, checksums=False):
+        """Variables, batch-norm moving statistics, Momentum slots and global_step under the reference's names."""
+        from .utility import checkpoint
+        torch.cuda.synchronize() if self.flat.w.is_cuda else None
+        checkpoint.save_checkpoint(self.model.vs, prefix, model_scope, checksums=checksums, trainer=self)
+
+    def restore(self, checkpoint_path, model_scope, strict=True):
+        from .utility import checkpoint
+        return checkpoint.restore_checkpoint(self.model.vs, checkpoint_path, model_scope, trainer=self, strict=strict)
+
     def loss_values(self):
         """{name: (cross_entropy, loc_loss)} per term + 'l2' + 'total' as python floats (synchronises)."""
         out, total = {}, 0.0

@@ -150,17 +150,35 @@ class GradBuckets(object):
         self.next_bucket = 0
         self.start_of = dict(getattr(flat, "start_of_member", None) or zip(flat.names, flat.starts))   # members of fused blocks map to their block
         self.done_upto = flat.total
+        self.fired = set()
+        # DANHIP_DP_CHECK=1 (tests): every bucket's reduced values are snapshotted on the communication stream and compared in finish()
+        # with what the gradient buffer holds then — any difference is a gradient written AFTER its bucket had been reduced
+        self.check = os.environ.get("DANHIP_DP_CHECK") == "1"
+        self.snapshots = []
 
     def begin_step(self):
         self.next_bucket = 0
         self.pending = []
         self.done_upto = self.flat.total
+        self.fired = set()
+        self.snapshots = []
 
     def ready(self, name):
         """Gradient of `name` (and of everything created after it) is final."""
         if not self.enabled:
             return
-        self.done_upto = min(self.done_upto, self.start_of[name])
+        # The overlap rests on two properties of the step: a variable's gradient is produced by exactly ONE backward call, and the calls
+        # arrive in reverse creation order (autograd runs nodes by decreasing sequence number; variables are created in forward order).
+        # A variable consumed twice, or a hook arriving out of order, would be reduced before it is complete: refuse loudly.
+        if name in self.fired:
+            raise RuntimeError("GradBuckets.ready(%r) fired twice in one step: the variable is consumed by two ops, its first gradient "
+                               "may already have been all-reduced" % name)
+        self.fired.add(name)
+        start = self.start_of[name]
+        if start > self.done_upto:
+            raise RuntimeError("GradBuckets.ready(%r): offset %d arrives after offsets >= %d were declared final (backward order is not "
+                               "reverse creation order)" % (name, start, self.done_upto))
+        self.done_upto = start
         self._launch_ready()
 
     def _launch_ready(self):
@@ -180,9 +198,18 @@ class GradBuckets(object):
                     if self.fake:
                         self.flat.g[s:e].mul_(1.0)
                     else:
-                        self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                        wk = dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+                        self.pending.append(wk)
+                        if self.check:
+                            wk.wait()                # (orders the snapshot behind the collective on this stream; host-blocking for gloo)
+                    if self.check:
+                        self.snapshots.append((s, e, self.flat.g[s:e].clone()))
             else:                                    # gloo / CPU tensors (unit tests)
-                self.pending.append(dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                wk = dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True)
+                self.pending.append(wk)
+                if self.check:
+                    wk.wait()
+                    self.snapshots.append((s, e, self.flat.g[s:e].clone()))
             self.next_bucket += 1
 
     def finish(self):
@@ -194,6 +221,18 @@ class GradBuckets(object):
             w.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.check:
+            from . import ops
+            for st in ops.wgrad_streams():
+                if st is not None:
+                    torch.cuda.current_stream().wait_stream(st)
+            for s, e, snap in self.snapshots:
+                if not torch.equal(self.flat.g[s:e], snap):
+                    bad = (self.flat.g[s:e] != snap).nonzero()[0].item() + s
+                    names = [n for n, st0 in sorted(self.start_of.items(), key=lambda kv: kv[1]) if st0 <= bad]
+                    raise RuntimeError("GradBuckets: the gradient at flat offset %d (variable %r) changed after its bucket [%d, %d) had been "
+                                       "all-reduced" % (bad, names[-1] if names else "?", s, e))
+            self.snapshots = []
 
 
 def init_distributed():

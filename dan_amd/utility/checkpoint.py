@@ -437,9 +437,81 @@ def init_from_checkpoint(variables, checkpoint_path, model_scope, checkpoint_mod
         with torch.no_grad():
             p.copy_(torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(p.device))
         restored.append(full[var_name])
+    _bump_weight_epoch()
     return restored
 
 
-def save_checkpoint(variables, prefix, model_scope, checksums=False):
-    """Writes the VariableStore under the reference's graph names ('<model_scope>/<name>')."""
-    write_checkpoint(prefix, {model_scope + "/" + n: p.detach().cpu().numpy() for n, p in variables.named()}, checksums=checksums)
+def _bump_weight_epoch():
+    """Parameters were written through views (members of fused blocks keep their own version counters): the cached 16-bit packings of
+    ops.packed_weights key on (WEIGHT_EPOCH, block version, pointer) and must be refreshed."""
+    from .. import ops
+    ops.WEIGHT_EPOCH += 1
+
+
+def _momentum_views(trainer):
+    """{variable name: view of the flat momentum buffer} — tf.train.MomentumOptimizer keeps one 'Momentum' slot per variable."""
+    flat = trainer.flat
+    out = {}
+    for n, p in trainer.model.vs.named():
+        off = p.data.data_ptr() - flat.w.data_ptr()
+        assert off >= 0 and off % 4 == 0
+        out[n] = flat.v.as_strided(p.data.shape, p.data.stride(), off // 4)
+    return out
+
+
+def save_checkpoint(variables, prefix, model_scope, checksums=False, trainer=None):
+    """Writes the VariableStore under the reference's graph names ('<model_scope>/<name>'): trainable variables AND the non-trainable
+    state the Estimator's Saver writes — batch-norm moving_mean / moving_variance (VariableStore.bufs) — and, given the trainer, the
+    optimizer slots ('<var>/Momentum', tf.train.MomentumOptimizer train_dan.py:521) and 'global_step' (int64), so that a run resumed
+    from its own checkpoint continues the learning-rate schedule and the momenta (train_dan.py:549-556 keeps 5 such checkpoints)."""
+    tensors = {model_scope + "/" + n: p.detach().cpu().numpy() for n, p in variables.named()}
+    for n, b in getattr(variables, "bufs", {}).items():
+        tensors[model_scope + "/" + n] = b.detach().cpu().numpy()
+    if trainer is not None:
+        for n, v in _momentum_views(trainer).items():
+            tensors[model_scope + "/" + n + "/Momentum"] = v.detach().cpu().contiguous().numpy()
+        tensors["global_step"] = np.asarray(int(trainer.step_no), dtype=np.int64)
+    write_checkpoint(prefix, tensors, checksums=checksums)
+
+
+def restore_checkpoint(variables, checkpoint_path, model_scope, trainer=None, strict=True):
+    """tf.train.Saver().restore of a checkpoint written by save_checkpoint (the Estimator's resume path; eval_dan.py:406-411): every
+    variable, the batch-norm moving statistics and — given the trainer — the Momentum slots and global_step.  Returns the restored
+    names.  strict: a variable / slot missing in the checkpoint is an error (Saver semantics); global_step and slots are optional when
+    strict is False (e.g. an inference-only checkpoint)."""
+    import torch
+    if os.path.isdir(checkpoint_path):
+        found = latest_checkpoint(checkpoint_path)
+        if found is None:
+            raise CheckpointError("no checkpoint in %s" % checkpoint_path)
+        checkpoint_path = found
+    reader = CheckpointReader(checkpoint_path)
+    restored = []
+
+    def load(ck_name, dst):
+        if not reader.has_tensor(ck_name):
+            if strict:
+                raise CheckpointError("variable %s missing in checkpoint %s" % (ck_name, checkpoint_path))
+            return
+        t = reader.get_tensor(ck_name)
+        if tuple(t.shape) != tuple(dst.shape):
+            raise CheckpointError("%s: checkpoint shape %s != variable shape %s" % (ck_name, tuple(t.shape), tuple(dst.shape)))
+        with torch.no_grad():
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(dst.device))
+        restored.append(ck_name)
+
+    for n, p in variables.named():
+        load(model_scope + "/" + n, p.data)
+    for n, b in getattr(variables, "bufs", {}).items():
+        load(model_scope + "/" + n, b)
+    if trainer is not None:
+        for n, v in _momentum_views(trainer).items():
+            load(model_scope + "/" + n + "/Momentum", v)
+        if reader.has_tensor("global_step"):
+            trainer.step_no = int(reader.get_tensor("global_step"))
+            restored.append("global_step")
+        elif strict:
+            raise CheckpointError("global_step missing in checkpoint %s" % checkpoint_path)
+        trainer._graph = None                    # a captured step holds the old learning rate: re-capture on demand
+    _bump_weight_epoch()
+    return restored

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import tf_ops as T
-from .deform import deform_conv_forward
+from .deform import deform_conv_forward, deform_im2col
 
 
 class Params:
@@ -191,23 +191,37 @@ def se_inception_block_v1(P, x, name):
     return T.round_bf16(out, True, True) if P.emulate_bf16 else out
 
 
-def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False):
+def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False, relu=False):
     """custom_op.deform_conv_2d — utility/custom_op.py:128-146 (channels_last: transposes around the op).
-    Offset conv: tf.layers.conv2d default name 'conv2d', zero-init kernel+bias; kernel var OIHW."""
+    Offset conv: tf.layers.conv2d default name 'conv2d', zero-init kernel+bias; kernel var OIHW.
+    relu: the activation the graphs apply right after (net/danet_deform.py:281), folded in here so that the bf16-storage
+    emulation can round where the MI355X build stores (sampled columns, the activated output, their gradients)."""
     off = conv(P, x, 2 * dg * 9, (3, 3), 1, name + "/conv2d", relu=False, init="zeros")
     w = P.get(name + "/kernel", (num_outputs, x.shape[-1], 3, 3), "glorot_oihw")
-    y = deform_conv_forward(x.permute(0, 3, 1, 2), w, off.permute(0, 3, 1, 2), 1, 1, dg).permute(0, 2, 3, 1)
-    if not no_bias:
-        y = y + P.get(name + "/bias", (num_outputs,), "zeros")
-    return y
+    b = None if no_bias else P.get(name + "/bias", (num_outputs,), "zeros")
+    xn, on = x.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2)
+    if not P.emulate_bf16:
+        y = deform_conv_forward(xn, w, on, 1, 1, dg).permute(0, 2, 3, 1)
+        y = y if b is None else y + b
+        return torch.relu(y) if relu else y
+    w = T.round_bf16(w, True, False)
+    col = T.round_bf16(deform_im2col(xn, on, 3, 3, 1, 1, dg), True, True)       # the sampled operand is a 16-bit MFMA input
+    B, C, K, Ho, Wo = col.shape
+    y = torch.einsum("ok,bkn->bon", w.reshape(num_outputs, C * K), col.reshape(B, C * K, Ho * Wo)).reshape(B, num_outputs, Ho, Wo)
+    y = y.permute(0, 2, 3, 1)
+    y = y if b is None else y + b
+    y = T.round_bf16(y, False, True) if relu else y
+    y = torch.relu(y) if relu else y
+    return T.round_bf16(y, True, not relu)
 
 
 def se_inception_block_v2(P, x, name):
     """DAN-Deform context module V2 — net/danet_deform.py:267-290."""
     c = x.shape[-1]
     d = conv(P, x, 256, (1, 1), 1, name + "/conv_1x1_down", relu=True)
-    y = deform_conv_2d(P, d, 256, name + "/deform_conv", dg=4, no_bias=False)
-    return conv(P, torch.relu(y), c, (1, 1), 1, name + "/conv_1x1_up", relu=True) + x
+    y = deform_conv_2d(P, d, 256, name + "/deform_conv", dg=4, no_bias=False, relu=True)
+    out = conv(P, y, c, (1, 1), 1, name + "/conv_1x1_up", relu=True) + x
+    return T.round_bf16(out, True, True) if P.emulate_bf16 else out
 
 
 def features_conv_only(P, feats, stage1=None, name=None):
@@ -223,7 +237,7 @@ def features_conv_only(P, feats, stage1=None, name=None):
             rs = conv(P, f, c - c // 3, (1, 1), 1, "{}/residual_conv_1x1_{}".format(n2, i), relu=True)
             f = torch.cat([s1, rs], dim=-1)
             nm = "{}/predict_stage2_conv{}".format(n2, i)
-        outs.append(torch.relu(deform_conv_2d(P, f, c, nm, dg=4, no_bias=False)))
+        outs.append(deform_conv_2d(P, f, c, nm, dg=4, no_bias=False, relu=True))
     return outs
 
 

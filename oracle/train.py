@@ -73,3 +73,58 @@ def momentum_sgd_step(params, grads, momenta, lr, momentum=0.9):
             g = g * 2.0
         momenta[name].mul_(momentum).add_(g)
         params[name].sub_(lr * momenta[name])
+
+
+# ------------------------------------------------------------------ data-parallel semantics (tf_replicate_model_fn.py)
+def split_batch(tensors, number_of_shards):
+    """_split_batch — tf_replicate_model_fn.py:458-498: every tensor is split on dim 0 into `number_of_shards` equal CONTIGUOUS
+    pieces (array_ops.split); a batch that does not divide raises (ensure_divisible_by_shards :461-466).
+    tensors: one tensor, or a dict / list / tuple of tensors.  Returns a list of `number_of_shards` objects of the same structure."""
+    def split_one(t):
+        if t.shape[0] % number_of_shards != 0:
+            raise ValueError("Batch size {} needs to be divisible by the number of GPUs, which is {}.".format(t.shape[0], number_of_shards))
+        return list(torch.chunk(t, number_of_shards, dim=0))
+
+    if torch.is_tensor(tensors):
+        return split_one(tensors)
+    if isinstance(tensors, dict):
+        shards = [{} for _ in range(number_of_shards)]
+        for name, t in tensors.items():
+            for i, piece in enumerate(split_one(t)):
+                shards[i][name] = piece
+        return shards
+    cols = [split_one(t) for t in tensors]
+    return [type(tensors)(c[i] for c in cols) for i in range(number_of_shards)]
+
+
+def scale_loss(loss, number_of_towers):
+    """_scale_loss — tf_replicate_model_fn.py:615-625 with loss_reduction = MEAN (train_dan.py:558): one tower -> unchanged, else
+    loss / number_of_towers."""
+    return loss if number_of_towers == 1 else loss / (1.0 * number_of_towers)
+
+
+def dp_step(tower_fn, shards):
+    """One data-parallel step's gradient aggregation as replicate_model_fn builds it:
+      * every tower i runs the model_fn on its shard and `TowerOptimizer.compute_gradients` differentiates
+        `_scale_loss(loss_i)` = loss_i / N (tf_replicate_model_fn.py:297-302) — loss_i is that tower's TOTAL loss, its own
+        L2 term and its own per-shard normalisers (positives / mined negatives of the shard) included;
+      * `_apply_gathered_gradients` sums the towers' gradients per variable with add_n (:328-343, `_compute_sum_on_device` :633-645)
+        and applies them once;
+      * the reported loss is the add_n of the scaled tower losses (`_train_spec`, :661-663).
+    tower_fn(shard, loss_scale) -> (loss_i [python float or 0-d tensor, UNSCALED], {var name: gradient of loss_i * loss_scale}).
+    Returns ({var name: aggregated gradient}, reported loss)."""
+    n = len(shards)
+    grad_lists, reported = {}, 0.0
+    for shard in shards:
+        loss_i, grads_i = tower_fn(shard, 1.0 if n == 1 else 1.0 / (1.0 * n))
+        reported = reported + scale_loss(loss_i, n)
+        for var, g in grads_i.items():
+            if g is not None:
+                grad_lists.setdefault(var, []).append(g)
+    aggregated = {}
+    for var, gs in grad_lists.items():                 # math_ops.add_n(values): summed in tower order
+        s = gs[0].clone()
+        for g in gs[1:]:
+            s = s + g
+        aggregated[var] = s
+    return aggregated, reported

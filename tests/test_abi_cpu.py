@@ -90,6 +90,37 @@ for n in reversed(f.names):      # backward order
     b.ready(n)
 b.finish()
 assert torch.all(f.g == float(sum(range(1, world + 1)))), f.g[:4]
+# invariants of the overlap (trainer.GradBuckets.ready): one firing per variable and step, reverse creation order
+b.begin_step()
+b.ready("v5")
+for bad, what in (("v5", "fired twice"), ):
+    try:
+        b.ready(bad); raise SystemExit("no error: " + what)
+    except RuntimeError as e:
+        assert what in str(e), e
+b.begin_step()
+b.ready("v2")
+try:
+    b.ready("v4"); raise SystemExit("no error: out of order")
+except RuntimeError as e:
+    assert "reverse creation order" in str(e), e
+# DANHIP_DP_CHECK: a gradient written after its bucket was reduced is caught in finish()
+os.environ["DANHIP_DP_CHECK"] = "1"
+f.g = torch.full((f.total,), float(rank + 1))
+b = GradBuckets(f, bucket_bytes=16 << 10)
+b.begin_step()
+for n in reversed(f.names):
+    b.ready(n)
+b.finish()                                  # clean step passes
+f.g = torch.full((f.total,), float(rank + 1)); b.flat = f
+b.begin_step()
+b.ready("v5"); b.ready("v4")
+f.g[f.starts[4] + 3] += 1.0                 # late contribution to v4
+b.ready("v3"); b.ready("v2"); b.ready("v1"); b.ready("v0")
+try:
+    b.finish(); raise SystemExit("late write not detected")
+except RuntimeError as e:
+    assert "changed after its bucket" in str(e) and "'v4'" in str(e), e
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 '''

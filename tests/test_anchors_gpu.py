@@ -157,3 +157,40 @@ def test_batched_pa_encode_equals_the_per_image_calls(dev):
     for b, g in enumerate(gts):
         t, l, s, m = cfg.enc.encode_pa_anchors(g, *sub, 0.35, 0.35, match_mining=False, scale=2.)
         assert torch.equal(L[b], l) and torch.equal(S[b], s) and torch.equal(M[b], m) and torch.equal(T[b], t), b
+
+
+@pytest.mark.parametrize("scale", [2.0, 4.0])
+@pytest.mark.parametrize("mining", [False, True])
+@pytest.mark.parametrize("hw", [(320, 320), (640, 640)])
+def test_encode_pa_anchors_vs_oracle(scale, mining, hw, dev):
+    """AnchorEncoder.encode_pa_anchors (anchor_manipulator.py:328-387; PyramidBox head / body targets, train_pb.py:218,223): anchors of
+    levels 1.. / 2.. shrunk by `scale` around their centre for matching, targets log(gt * scale / anchor).  HIP path (per-image entry
+    AND the batched one, kernel branch anchors_exact.hip `scale != 1`) against oracle.anchors.encode_pa_anchors: labels, scores,
+    matched boxes and centre offsets bit-exact; the two log() targets within 2 ulp of logf scaled by 1 / 0.2.  Cases: ragged lists,
+    an empty list (the [[0,0,1,1]] substitute, :347), many tiny faces, one face, 100 faces."""
+    from dan_amd.train_sfd import AnchorConfig
+    h, w = hw
+    ref = _cfg(h, w, 1.0)
+    cfg = AnchorConfig(h, w, dev)
+    first = sum(cfg.num_anchors_per_layer[:1 if scale == 2.0 else 2])           # head anchors: levels 1.., body: levels 2.. (train_pb.py:205-247)
+    sub = tuple(t[first:].contiguous() for t in cfg.anchors)
+    rsub = tuple(a[first:] for a in ref[:4])
+    rinside = ref[4][first:]
+    rs = np.random.RandomState(17)
+    tiny = np.stack([np.array([y, x, y + s, x + s], np.float32) for y, x, s in zip(rs.randint(0, h - 20, 30), rs.randint(0, w - 20, 30), rs.randint(3, 14, 30))])
+    gts = [_gt(12, h, w, 5), np.zeros((0, 4), np.float32), tiny, _gt(1, h, w, 6), _gt(100, h, w, 7)]
+    mf = (lambda ov: OE.small_mining_match(ov, 0., 0.35, 0.35, 6, 0.3)) if mining else (lambda ov: OA.do_dual_max_match(ov, 0.35, 0.35))
+    T, L, S, M = cfg.enc.encode_pa_anchors_batch([torch.from_numpy(g).to(dev) for g in gts], *sub, 0.35, 0.35, match_mining=mining, scale=scale)
+    n_pos = 0
+    for b, gt in enumerate(gts):
+        t_ref, l_ref, s_ref, m_ref = OA.encode_pa_anchors(gt, rsub, rinside, [0.1, 0.1, 0.2, 0.2], mf, scale)
+        t, l, s, m = cfg.enc.encode_pa_anchors(torch.from_numpy(gt).to(dev), *sub, 0.35, 0.35, match_mining=mining, scale=scale)
+        for (tt, ll, ss, mm), what in (((t, l, s, m), "per-image"), ((T[b], L[b], S[b], M[b]), "batched")):
+            assert np.array_equal(ll.cpu().numpy().astype(np.int64), l_ref), (b, what)
+            assert np.array_equal(ss.cpu().numpy(), s_ref), (b, what)
+            assert np.array_equal(mm.cpu().numpy(), m_ref), (b, what)
+            tg = tt.cpu().numpy()
+            assert np.array_equal(tg[:, :2], t_ref[:, :2]), (b, what)
+            assert np.allclose(tg[:, 2:], t_ref[:, 2:], rtol=0, atol=4 * np.finfo(np.float32).eps * 5 * 4), (b, what)
+        n_pos += int((l_ref == 1).sum())
+    assert n_pos > 0

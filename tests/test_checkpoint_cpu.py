@@ -106,3 +106,66 @@ def test_warm_start_into_a_variable_store(tmp_path):
     assert len(C.init_from_checkpoint(again, own, "sfd", None)) == 3
     for (n, p), (_, q) in zip(dst.named(), again.named()):
         assert torch.equal(p, q), n
+
+
+def test_full_state_round_trip_with_momenta_moving_statistics_and_global_step(tmp_path):
+    """save_checkpoint(trainer=...) / restore_checkpoint: what the Estimator's Saver writes besides the trainable variables — batch-norm
+    moving statistics, '<var>/Momentum' slots, 'global_step' (int64) — survives a round trip into a fresh store whose head variables live
+    as strided views of a fused block; the cached weight packings are invalidated (ops.WEIGHT_EPOCH)."""
+    from dan_amd import ops
+    from dan_amd.net.variables import VariableStore
+    from dan_amd.trainer import FlatParams
+
+    class FakeModel(object):
+        pass
+
+    class FakeTrainer(object):
+        _graph = None
+
+    def make(seed):
+        vs = VariableStore(device="cpu", seed=seed)
+        vs.get("conv1/conv1_1/conv2d/kernel", (3, 3, 8, 8), "glorot")
+        vs.get("conv1/conv1_1/conv2d/bias", (8,), 0.1 * seed)
+        vs.get("h/loc_0/kernel", (3, 3, 8, 4), "glorot")
+        vs.get("h/loc_0/bias", (4,), "zeros")
+        vs.get("h/cls_0/kernel", (3, 3, 8, 2), "glorot")
+        vs.get("h/cls_0/bias", (2,), 0.5)
+        vs.buffer("block_0/conv_1/bn/moving_mean", (8,), 0.0).add_(float(seed))
+        vs.buffer("block_0/conv_1/bn/moving_variance", (8,), 1.0).mul_(float(seed))
+        vs.fuse(("h/loc_0/kernel", "h/cls_0/kernel"), 3)
+        vs.fuse(("h/loc_0/bias", "h/cls_0/bias"), 0)
+        t = FakeTrainer()
+        t.model = FakeModel()
+        t.model.vs = vs
+        t.flat = FlatParams(vs)
+        t.step_no = 0
+        return t
+
+    a = make(3)
+    a.flat.v.copy_(torch.arange(a.flat.total, dtype=torch.float32) * 1e-3)
+    a.step_no = 81234
+    prefix = str(tmp_path / "run" / "model.ckpt-81234")
+    C.save_checkpoint(a.model.vs, prefix, "dan", trainer=a)
+    names = C.CheckpointReader(prefix).get_variable_to_shape_map()
+    assert "global_step" in names and "dan/h/cls_0/kernel/Momentum" in names and "dan/block_0/conv_1/bn/moving_variance" in names
+    assert names["dan/h/cls_0/kernel/Momentum"] == [3, 3, 8, 2] and names["global_step"] == []
+    b = make(5)
+    epoch = ops.WEIGHT_EPOCH
+    got = C.restore_checkpoint(b.model.vs, str(tmp_path / "run"), "dan", trainer=b)
+    assert ops.WEIGHT_EPOCH > epoch and "global_step" in got and b.step_no == 81234
+    for (n, p), (_, q) in zip(a.model.vs.named(), b.model.vs.named()):
+        assert torch.equal(p, q), n
+    for n in a.model.vs.bufs:
+        assert torch.equal(a.model.vs.bufs[n], b.model.vs.bufs[n]), n
+    # momenta: compare per variable through the trainer's own views (the flat buffers' padding is not saved)
+    va, vb = C._momentum_views(a), C._momentum_views(b)
+    assert all(torch.equal(va[n], vb[n]) for n in va) and vb["h/cls_0/kernel"].abs().sum() > 0
+    # an inference checkpoint (no slots, no step) restores strictly into a plain store, and non-strictly into a trainer
+    inf = str(tmp_path / "inf" / "model.ckpt")
+    C.save_checkpoint(a.model.vs, inf, "dan")
+    with pytest.raises(C.CheckpointError):
+        C.restore_checkpoint(b.model.vs, inf, "dan", trainer=b)
+    assert "global_step" not in C.restore_checkpoint(b.model.vs, inf, "dan", trainer=b, strict=False)
+    epoch = ops.WEIGHT_EPOCH
+    C.init_from_checkpoint(b.model.vs, inf, "dan", None)
+    assert ops.WEIGHT_EPOCH > epoch                                   # warm start also invalidates the cached packings

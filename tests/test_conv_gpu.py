@@ -224,3 +224,47 @@ def test_pointwise_data_gradient_through_the_library_gemm(accumulate, dev):
         want = ref if mask is None else torch.where(x.float() > 0, ref, dx0.float() if accumulate else torch.zeros_like(ref))
         err = (dx.float().cpu() - want).abs().max().item()
         assert err <= 2.0 ** -7 * want.abs().max().item() + 2e-2, (mask is not None, err)
+
+
+# The 12 distinct 3x3 shapes of the VGG-16 backbone at BASELINE.json's 640x640 (SURVEY §7 "minimum slice", Appendix B) plus conv1_1 and
+# the two heavy pointwise shapes, at N = 1 and FULL spatial size, against the CPU oracle convolution (oneDNN fp32 on bf16-rounded
+# operands): forward with bias + ReLU, data gradient, weight gradient, bias gradient.
+FULL_SHAPES = [
+    ("conv1_1", 640, 8, 64, 3, 1), ("conv1_2", 640, 64, 64, 3, 1), ("conv2_1", 320, 64, 128, 3, 1), ("conv2_2", 320, 128, 128, 3, 1),
+    ("conv3_1", 160, 128, 256, 3, 1), ("conv3_2", 160, 256, 256, 3, 1), ("conv4_1", 80, 256, 512, 3, 1), ("conv4_2", 80, 512, 512, 3, 1),
+    ("conv5_x", 40, 512, 512, 3, 1), ("fc6", 20, 512, 1024, 3, 1), ("conv6_2", 20, 256, 512, 3, 2), ("conv7_2", 10, 128, 256, 3, 2),
+    ("fc7", 20, 1024, 1024, 1, 1), ("lfpn_lateral", 160, 256, 256, 1, 1),
+]
+
+
+@pytest.mark.parametrize("name,hw,cin,cout,k,stride", FULL_SHAPES)
+def test_backbone_layer_at_full_size_vs_oracle(name, hw, cin, cout, k, stride, dev):
+    from dan_amd import ops
+    x, w, b, s = _mk((1, hw, hw, cin, cout, k, k, stride), 100 + hw + cin)
+    if name == "conv1_1":                                         # 3 real channels padded to 8 (prepare_input): the pad lanes are zero
+        x[..., 3:] = 0
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    pre = T.conv2d_same(xr, wr, br, stride=s, relu=False)
+    ref = torch.relu(pre)
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride=s, relu=True)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    err = (y.detach().float().cpu() - ref.detach()).abs().max().item()
+    assert err <= _tol(ref.detach()), (name, "fwd", err, _tol(ref.detach()))
+    # the HIP path masks by its own stored bf16 output; use the same mask so that sign ties at the ReLU boundary do not enter
+    mask = (y.detach().float().cpu() > 0).float()
+    pre.backward(dy.float() * mask)
+    checks = [("dw", wd.grad.cpu(), wr.grad), ("db", bd.grad.cpu(), br.grad)]
+    if name != "conv1_1":                                         # the image needs no gradient (and the pad channels have none)
+        checks.append(("dx", xd.grad.float().cpu(), xr.grad))
+    for what, got, want in checks:
+        scale = want.abs().max().item() + 1e-6
+        e = (got - want).abs().max().item()
+        assert e <= 2.0 ** -6 * scale + 2e-3, (name, what, e, scale)

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "ddp", "worker.py")
 
 
-def _run(world, out, port):
-    env = dict(os.environ, DANHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+def _run(world, out, port, **extra):
+    env = dict(os.environ, DANHIP_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", **extra)
     if world == 1:
         cmd = [sys.executable, WORKER, out]
     else:
@@ -53,3 +53,39 @@ def test_rccl_code_path_with_a_one_rank_group(dev, tmp_path):
     scale = one["w"].abs().max().item()
     assert (a["w"] - one["w"]).abs().max().item() <= 1e-4 * scale
     assert torch.isfinite(a["g"]).all() and a["g"].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("model", ["sfd", "pb", "dan", "dan_deform"])
+def test_two_rank_step_equals_the_oracle_dp_step_over_shard_gradients(model, dev, tmp_path):
+    """SURVEY a35 against oracle.train.dp_step (tf_replicate_model_fn.py:297-343, 458-498, 615-645): the gradient buffer a 2-rank
+    run holds after its bucketed, overlapped all-reduce equals add_n over the towers of grad(loss_shard / N), each tower computed by
+    ONE plain process from the same parameters — for all four graphs, with DANHIP_DP_CHECK=1 (no gradient may be written after its
+    bucket was reduced).  Tolerance 1e-4 of the gradient's max-norm (fp32 atomics order in the weight-gradient kernels); the weights
+    after the step equal the Momentum update of the aggregated gradient (oracle.train.momentum_sgd_step semantics: x2 on biases,
+    L2 term once) at 1e-5."""
+    from oracle import train as OT
+    dp = _run(2, str(tmp_path / "dp.pt"), 29641 + ["sfd", "pb", "dan", "dan_deform"].index(model), DDP_MODEL=model, DANHIP_DP_CHECK="1")
+    sh = _run(1, str(tmp_path / "sh.pt"), 0, DDP_MODEL=model, DDP_MODE="shards", DDP_SHARDS="2")
+    assert torch.equal(dp["w0"], sh["w0"])
+
+    def tower(i, loss_scale):
+        assert loss_scale == 0.5                       # the shard gradients were produced with world = 2
+        return sh["loss"][i], {"flat": sh["g"][i]}
+
+    agg, reported = OT.dp_step(tower, [0, 1])
+    g = agg["flat"]
+    scale = g.abs().max().item()
+    assert scale > 0 and torch.isfinite(dp["g1"]).all()
+    err = (dp["g1"] - g).abs().max().item()
+    assert err <= 1e-4 * scale, (model, err, scale)
+    assert abs(dp["loss1"] - sh["loss"][0]) <= 1e-3 * abs(sh["loss"][0]) + 1e-4          # rank 0 reports its own tower's loss
+    assert dp["buckets"] >= 2
+    # Momentum step 0 (v = 0): w1 = w0 - lr * mult * (g + wd * w0), lr = 1e-3 * 0.1 (train_sfd.py:429-447)
+    seg = sh["seg"].tolist()
+    mult = torch.ones_like(g)
+    wd = torch.zeros_like(g)
+    for k in range(len(seg) - 1):
+        mult[seg[k]:seg[k + 1]] = sh["gmult"][k]
+        wd[seg[k]:seg[k + 1]] = sh["wdc"][k]
+    want = sh["w0"] - 1e-4 * mult * (dp["g1"] + wd * sh["w0"])
+    assert torch.allclose(dp["w1"], want, rtol=1e-5, atol=1e-7), (dp["w1"] - want).abs().max().item()

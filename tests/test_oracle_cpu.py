@@ -287,3 +287,46 @@ def test_psroi_pool_oracle_kat():
     assert top.flatten().tolist() == [2.0]
     dd, dt = OD.deform_psroi_pool_backward(data, rois, trans, cnt, np.ones_like(top), sample_per_part=2, **at2)
     assert np.allclose(dd[0, 0], [[0.375, 0.375], [0.125, 0.125]]) and np.isclose(dd.sum(), 1.0)
+
+
+def test_dp_step_restates_replicate_model_fn():
+    """oracle.train.split_batch / scale_loss / dp_step against tf_replicate_model_fn.py:458-498, 615-625, 297-343 on a toy model_fn whose loss
+    is normalised by a per-shard count (as the detectors' losses are by their positives): aggregated gradient = gradient of the MEAN of the
+    tower losses (each with its own normaliser and its own L2 term, so L2 counts once), which differs from the whole-batch gradient; the
+    reported loss is the sum of the scaled tower losses; a batch that does not divide raises."""
+    import pytest
+    import torch
+    from oracle import train as OT
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(5, 3, generator=g)
+    x = torch.randn(8, 5, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    m = torch.tensor([1., 1., 1., 0., 1., 0., 0., 1.])             # shard counts differ (2,1,1,1 at n = 4; 3,2 at n = 2)
+
+    def loss_fn(wv, xs, ys, ms):
+        per = ((xs @ wv - ys) ** 2).sum(-1)
+        return (per * ms).sum() / ms.sum() + 5e-4 * 0.5 * (wv * wv).sum()
+
+    def tower(shard, loss_scale):
+        wv = w.clone().requires_grad_(True)
+        loss = loss_fn(wv, *shard)
+        (loss * loss_scale).backward()
+        return loss.item(), {"w": wv.grad}
+
+    for n in (1, 2, 4):
+        shards = OT.split_batch((x, y, m), n)
+        assert len(shards) == n and torch.equal(shards[-1][0], x[8 - 8 // n:])          # contiguous, in order
+        agg, rep = OT.dp_step(tower, shards)
+        wv = w.clone().requires_grad_(True)
+        mean_loss = sum(loss_fn(wv, *s) for s in shards) / n
+        mean_loss.backward()
+        assert torch.allclose(agg["w"], wv.grad, rtol=1e-6, atol=1e-7)
+        assert abs(rep - mean_loss.item()) < 1e-5 * abs(rep)
+    whole = w.clone().requires_grad_(True)
+    loss_fn(whole, x, y, m).backward()
+    assert not torch.allclose(agg["w"], whole.grad, rtol=1e-3, atol=1e-5)               # per-shard normalisers: not the whole-batch gradient
+    assert OT.scale_loss(3.0, 1) == 3.0 and OT.scale_loss(3.0, 4) == 0.75
+    d = OT.split_batch({"a": x, "b": m}, 2)
+    assert set(d[0]) == {"a", "b"} and torch.equal(d[1]["b"], m[4:])
+    with pytest.raises(ValueError):
+        OT.split_batch(x, 3)

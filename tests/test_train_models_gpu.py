@@ -245,3 +245,34 @@ def test_graph_captured_dan_step_advances_the_routing_stream(dev):
         lv = tr.loss_values()
         assert lv["total"] == lv["total"] and lv["total"] < 1e4
     assert int(tr._routing_ctr.item()) == 4 * per_step      # the device-resident counter moved with every replay
+
+
+def test_resume_from_own_checkpoint_continues_the_trajectory(dev, tmp_path):
+    """DetectorTrainer.save / restore (the Estimator's checkpoint + resume, train_dan.py:549-556): a fresh trainer restored from a
+    checkpoint taken after 2 steps predicts identically at once (cached packings of the fused head blocks refreshed) and after one more
+    step holds the same weights, momenta and step counter as the run that never stopped (fp32-atomics noise only)."""
+    from dan_amd import synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    imgs = synthetic.make_images(2, 128, 128, dev, seed=71)
+    gts = synthetic.make_gt_boxes(2, 128, 128, seed=72, max_faces=5)
+    anchors = AnchorConfig(128, 128, dev)
+    loc_t, cls_t, _ = anchors.encode_batch(gts)
+    a = SFDTrainer(SFDModel(device=dev, seed=10), world=1, lr_boundaries=(1, 80000, 100000))       # the schedule moves at step 2
+    for _ in range(2):
+        a.train_step(imgs, loc_t, cls_t)
+    prefix = str(tmp_path / "model.ckpt-2")
+    a.save(prefix, "sfd")
+    b = SFDTrainer(SFDModel(device=dev, seed=11), world=1, lr_boundaries=(1, 80000, 100000))
+    with torch.no_grad():
+        before = b.model.forward(imgs)[1].clone()                      # populates b's packed-weight cache with the OLD weights
+    got = b.restore(str(tmp_path), "sfd")
+    assert "global_step" in got and b.step_no == 2
+    with torch.no_grad():
+        pa, pb_ = a.model.forward(imgs), b.model.forward(imgs)
+    assert torch.equal(pa[0], pb_[0]) and torch.equal(pa[1], pb_[1]) and not torch.equal(before, pb_[1])
+    a.train_step(imgs, loc_t, cls_t)
+    b.train_step(imgs, loc_t, cls_t)
+    scale = a.flat.w.abs().max().item()
+    assert (a.flat.w - b.flat.w).abs().max().item() <= 1e-5 * scale
+    assert (a.flat.v - b.flat.v).abs().max().item() <= 1e-4 * a.flat.v.abs().max().item()
+    assert a.step_no == b.step_no == 3
