@@ -229,8 +229,17 @@ class GradSlot(object):
         return b if n > 0 else None
 
 
+# USE_SLOTS = False (tests): every activation gradient travels through autograd's own edges instead of the direct hand-off, which gives
+# the parity tests a second, independent route through the same kernels (tests/test_grad_parity_gpu.py)
+USE_SLOTS = True
+
+
 def _slot_of(t):
-    return getattr(t, "_dh_slot", None)
+    return getattr(t, "_dh_slot", None) if USE_SLOTS else None
+
+
+def _new_slot(track):
+    return GradSlot.__new__(GradSlot) if (track and USE_SLOTS) else None
 
 
 def _attach_slot(t, is_relu):
@@ -367,7 +376,7 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     track = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or _sink_trainable(w))
     if track and relu and residual is not None:
         raise NotImplementedError("relu + fused residual needs a separate ReLU mask in backward (y > 0 is not the mask)")
-    yslot = GradSlot.__new__(GradSlot) if (track and not out_f32) else None
+    yslot = _new_slot(track and not out_f32)
     pool_out = [] if (pool and relu and not out_f32 and residual is None and b is not None and w.shape[-1] % 8 == 0) else None
     if padding not in ("same", "valid"):
         raise ValueError("padding must be 'same' or 'valid'")
@@ -428,7 +437,7 @@ def _pool_deliver_ok(ctx, dy):
 def max_pool_2x2(x):
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
-    yslot = GradSlot.__new__(GradSlot) if track else None
+    yslot = _new_slot(track)
     y = _MaxPool.apply(x, xs, yslot, getattr(x, "_dh_pooled", None))
     if yslot is not None:
         # consumers may mask by (pooled > 0) when the source is a ReLU output
@@ -499,7 +508,7 @@ class _L2Norm(torch.autograd.Function):
 
 def l2_normalize(x, gamma):
     track = torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad)
-    yslot = GradSlot.__new__(GradSlot) if track else None
+    yslot = _new_slot(track)
     y = _L2Norm.apply(x, gamma, gamma if isinstance(gamma, torch.nn.Parameter) else None, _slot_of(x) if track else None, yslot)
     if yslot is not None:
         yslot.__init__(y, False)
@@ -797,7 +806,7 @@ def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_gr
     """y = act(DeformConvOp(x, filter, offsets) + b); w1x1 = the filter viewed [1,1,kh*kw*C,Cout]."""
     bp = b if isinstance(b, torch.nn.Parameter) else None
     track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad)
-    yslot = GradSlot.__new__(GradSlot) if track else None
+    yslot = _new_slot(track)
     y = _DeformConv.apply(x, w1x1, b, offsets, kh, kw, stride, dilation, deformable_group, relu, bp, yslot)
     if yslot is not None:
         yslot.__init__(y, relu)
