@@ -6,7 +6,7 @@ get_features_stage2 (net/danet.py:934) would show.  Three angles:
 1. fixed random upstream gradient on every head output (tests/gradcheck.py), HIP vs oracle, per variable.  Tolerance: relative L2
    error <= 0.25.  That is the noise floor of 16-bit storage on these 40-60-layer graphs at 64 x 96 (ReLU / max-pool decisions of
    pre-activations within rounding of zero differ): the oracle's OWN fp32 and bf16-emulated gradients differ by 0.10 median / 0.25 max
-   per variable.  The fp16 build runs the same check at 0.08 (tests/fp16/cases.py) and
+   per variable.  The fp16 build runs the same check at 0.12 (tests/fp16/cases.py) and
 2. the same gradients through the HIP kernels with the direct hand-off switched off (ops.USE_SLOTS = False: every activation gradient
    travels through autograd's own edges) must agree with the shipped hand-off path to 0.03 — a dropped / doubled contribution is >= 0.1;
 3. the real training step (hard-negative mining, routing targets, flat gradient buffer): loss terms within 3 % of the oracle's, the
