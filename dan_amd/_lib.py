@@ -14,6 +14,8 @@ if ACT_NAME not in ("bf16", "fp16"):
     raise ValueError("DANHIP_DTYPE must be bf16 or fp16, got %r" % ACT_NAME)
 ACT_DTYPE = torch.float16 if ACT_NAME == "fp16" else torch.bfloat16
 SO_PATH = os.path.join(_HERE, "libdanhip_f16.so" if ACT_NAME == "fp16" else "libdanhip.so")
+if os.environ.get("DANHIP_LIB_PATH"):          # diagnosis: A/B another in-tree build of the same library (tools/build_one.sh variants)
+    SO_PATH = os.path.abspath(os.environ["DANHIP_LIB_PATH"])
 
 F32, BF16 = 0, 1      # BF16 = "the build's 16-bit activation type" in out_dtype arguments
 

@@ -44,9 +44,10 @@ const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad);   // kernel-in
 int danhip_launch_conv_c8(const ConvArgs& a, hipStream_t s);
 const char* danhip_conv_c8_label(const ConvArgs& a);
 
-// Halo-reuse 3x3/stride-1 weight gradient (conv_wgrad_halo.hip): DANHIP_OK when launched, 1 when not eligible.
-const char* danhip_wgrad_halo_label(const danhip_conv_desc* d);
-int danhip_launch_wgrad_halo(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
+// Row-streaming 3x3/stride-1 weight gradient with a register window of X fragments (conv_wgrad_rows.hip): DANHIP_OK when launched,
+// 1 when the shape is not eligible.
+const char* danhip_wgrad_rows_label(const danhip_conv_desc* d);
+int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
 __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {

@@ -6,6 +6,8 @@
 // (a 4-pixel x 16-channel block per 16-lane group), so nothing is ever transposed in registers or through HBM.
 // The reduction over pixels is split across workgroups (grid.z); partial tiles are combined with fp32 atomics
 // straight into the HWIO gradient (zeroed by the caller once per step).
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace {
@@ -224,8 +226,8 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
 
 extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d) {
   if (!d) return "";
-  const char* hl = danhip_wgrad_halo_label(d);
-  if (hl) return hl;
+  const char* rl = danhip_wgrad_rows_label(d);
+  if (rl) return rl;
   const int co8 = (d->Cout + 7) / 8 * 8;
   if (d->Cin == 8 && d->kh * d->kw <= 16) return co8 > 64 ? "conv_wgrad_kernel<128, 128, 2>" : "conv_wgrad_kernel<128, 64, 2>";
   const bool ci_small = d->Cin <= 64, co_small = co8 <= 64;
@@ -246,7 +248,7 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
     DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
   }
   {
-    const int hr = danhip_launch_wgrad_halo(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
+    const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
     if (hr <= 0) return hr;
   }
   WgradArgs a{};
