@@ -44,6 +44,10 @@ const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad);   // kernel-in
 int danhip_launch_conv_c8(const ConvArgs& a, hipStream_t s);
 const char* danhip_conv_c8_label(const ConvArgs& a);
 
+// Pointwise (1x1 / stride 1) streaming GEMM (conv_pointwise.hip): forward (bias, ReLU) and data gradient (mask, accumulate); same return convention.
+int danhip_launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
+const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad);
+
 // Row-streaming 3x3/stride-1 weight gradient with a register window of X fragments (conv_wgrad_rows.hip): DANHIP_OK when launched,
 // 1 when the shape is not eligible.
 const char* danhip_wgrad_rows_label(const danhip_conv_desc* d);

@@ -309,6 +309,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (cr <= 0) return cr;
   const int hr = danhip_launch_conv_halo(a, s);        // 3x3 / stride-1 on large maps: halo-reuse kernel
   if (hr <= 0) return hr;
+  const int pr = danhip_launch_conv_pointwise(a, s);   // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
+  if (pr <= 0) return pr;
   const bool fast = (a.C % 64 == 0);
   switch (pick_bn(a.Co)) {
     case 128: return launch_cfg<128, 128, 2>(a, fast, s);
@@ -346,15 +348,6 @@ int check_desc(const danhip_conv_desc* d) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
-
-// gemm_lt.hip
-int danhip_gemm_lt(int m, long n, int k, const void* wp, int lda, const void* act, int ldb, void* out, int ldd, const float* bias, int relu,
-                   int accumulate, hipStream_t stream);
-// pointwise convolutions large enough to be worth a library GEMM (see gemm_lt.hip)
-static bool pointwise_gemm_shape(const danhip_conv_desc* d) {
-  return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->Cin >= 64 &&
-         d->Cout >= 64 && (long)d->N * d->H * d->W >= 4096;
-}
 
 extern "C" int danhip_conv_packed_dims(const danhip_conv_desc* d, int which, int64_t* rows, int64_t* cols) {
   int rc = check_desc(d);
@@ -442,14 +435,13 @@ ConvArgs bwd_args(const danhip_conv_desc* d) {
 // Label of the kernel instance a forward (which=0) / data-gradient (which=1) call of this descriptor launches
 // (matches the demangled name rocprofv3 reports) — used by bench.py to attribute measured time.
 extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which) {
+  static bf16_t dummy_mask = 0;
   if (!d) return "";
   const bool masked = which == 5;                      // which = 5: data gradient with the producer's ReLU mask fused (never the library GEMM)
   if (which == 5) which = 1;
   const int cin = (which == 0 || which == 4) ? d->Cin : round_up(d->Cout, 8);
   const int cout = (which == 0 || which == 4) ? d->Cout : d->Cin;
   if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return "conv_bwd_data_strided_kernel";
-  if ((which == 0 || (which == 1 && !masked)) && pointwise_gemm_shape(d) && !(getenv("DANHIP_NO_BLASLT") && getenv("DANHIP_NO_BLASLT")[0] == '1'))
-    return "hipblaslt gemm (pointwise conv)";          // forward, and the data gradient when no ReLU mask is fused
   {
     ConvArgs a = (which == 0 || which == 4) ? fwd_args(d) : bwd_args(d);
     if (which == 4) {                                  // forward conv_relu with the fused 2x2 max-pool (danhip_conv2d_fwd_pool)
@@ -463,6 +455,10 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     if (cl) return cl;
     const char* hl = danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
+    if (which == 1) { if (masked) a.mask = &dummy_mask; }
+    else { static const float one = 1.f; a.bias = &one; }
+    const char* pl = danhip_conv_pointwise_label(a, which == 1);
+    if (pl) return pl;
   }
   const bool fast = cin % 64 == 0;
   switch (pick_bn(cout)) {
@@ -568,11 +564,6 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   if (out_dtype == DANHIP_F16 && danhip_act_dtype() == DANHIP_F16) out_dtype = DANHIP_BF16;      // alias for "the build's 16-bit type"
   DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
   DH_REQUIRE(!(residual && out_dtype == DANHIP_F32), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
-  if (pointwise_gemm_shape(d) && out_dtype == DANHIP_BF16 && !residual) {
-    rc = danhip_gemm_lt(d->Cout, (long)d->N * d->H * d->W, d->Cin, wf_packed, round_up(d->Cin, 64), x, d->Cin, y, d->Cout, bias, relu, 0,
-                        (hipStream_t)stream);
-    if (rc <= 0) return rc;                             // 1: no library path for this shape -> own kernel
-  }
   ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
   a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
@@ -665,11 +656,6 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
                        d->H, d->W, d->Cin, d->Ho, d->Wo, co8, d->kh, d->kw, d->stride, pad_t, pad_l, round_up(taps * co8, 64), accumulate);
     DH_LAUNCH_CHECK();
     return DANHIP_OK;
-  }
-  if (pointwise_gemm_shape(d) && !relu_mask) {          // the fused ReLU mask of the producer has no library epilogue: own kernel then
-    rc = danhip_gemm_lt(d->Cin, (long)d->N * d->H * d->W, co8, wb_packed, round_up(co8, 64), dy, co8, dx, d->Cin, nullptr, 0, accumulate,
-                        (hipStream_t)stream);
-    if (rc <= 0) return rc;
   }
   ConvArgs a = bwd_args(d);
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = relu_mask; a.resid = nullptr; a.y = dx;

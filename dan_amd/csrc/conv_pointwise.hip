@@ -1,0 +1,386 @@
+// Pointwise (1x1, stride 1) convolution = streaming GEMM on MFMA for gfx950:  Y[M, Co] = X[M, C] . Wp[Co, C]^T  (+ bias, ReLU), and
+// run on dY with the transposed packing its data gradient  dX[M, Cin] (+)= dY[M, Co8] . Wb[Cin, Co8]^T  (* (x > 0), + old).
+//
+// Reference call sites: the LFPN lateral / upsample convs (net/pb_net.py:198-218, net/danet.py:352-372), every 1x1 of the DAN context
+// modules (net/danet.py:842-918, net/danet_deform.py:267-290), the stage-2 mixing convs (net/danet.py:944-947), fc7 / conv6_1 / conv7_1
+// (net/sfd_net.py:146-154), and the GEMM half of DeformConvOp over its sampled columns (cpp/Deform/deform_conv.cc:509-518: K = 9 C).
+// Round 1 sent these shapes to hipBLASLt; this kernel replaces the library on the default path.
+//
+// These products are HBM-bound (read X once, write Y once; the weights are L2-resident): the design is a streaming one.
+//  * persistent 512-thread workgroup per CU, tile = 128 pixels x BN output channels (BN = 256 / 128 / 64 = the whole Co for the
+//    common layers, so X is read exactly once), K walked in 64-channel steps through an NST-deep LDS ring;
+//  * both operands are K-contiguous in HBM ([pixel][C] NHWC rows, packed [Co][Kpad] weights): 16-byte LDS-DMA pieces of 8 rows x 128 B,
+//    XOR-swizzled on the source side, ds_read_b128 fragments, v_mfma_f32_16x16x32 with the weight fragment as the A operand (a lane
+//    owns 8 consecutive output channels of one pixel -> 16-byte NHWC stores, channel tiles interleaved in pairs as in conv_halo.hip);
+//  * the step sequence is flattened across items: the next item's first K-steps are already landing while the epilogue stores run;
+//    the DMA is inline asm with a counted vmcnt (never drained in the loop: hipcc would wait vmcnt(0) before each ds_read), the
+//    epilogue's mask / old-value reads are asm loads issued BEFORE the item's last DMA so that waiting for them retires nothing else;
+//  * XCD-grouped item order: the Co / BN column blocks of one pixel tile run on one XCD (second .. last read X from that L2).
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+struct PwGeom {
+  int m_tiles, NB, items, ksteps, grouped;
+  FastDiv div_nb;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned pw_u32x4;
+
+template <int N>
+__device__ __forceinline__ void pw_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pw_dma16(pw_u32x4 rsrc, unsigned voff, unsigned lds_addr) {      // voff out of range: zeros land in LDS
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ pw_u32x4 pw_make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  return pw_u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ pw_u32x4 pw_load16(const void* p) {        // asm load: counted by hand (pw_wait_vmcnt + pw_land)
+  pw_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void pw_land(pw_u32x4& v) { asm volatile("" : "+v"(v)); }
+
+// Dynamic wait: at most `n` vector-memory operations of this wave may stay outstanding (n wave-uniform, clamped to the hardware's 63)
+__device__ __forceinline__ void pw_wait_vmcnt_dyn(int n) {
+  if (n <= 0) pw_wait_vmcnt<0>();
+  else if (n <= 2) pw_wait_vmcnt<2>();
+  else if (n <= 4) pw_wait_vmcnt<4>();
+  else if (n <= 6) pw_wait_vmcnt<6>();
+  else if (n <= 8) pw_wait_vmcnt<8>();
+  else if (n <= 12) pw_wait_vmcnt<12>();
+  else if (n <= 16) pw_wait_vmcnt<16>();
+  else if (n <= 24) pw_wait_vmcnt<24>();
+  else pw_wait_vmcnt<32>();
+}
+// ... rounded DOWN to the nearest encodable step (waiting for more than necessary is always safe)
+__device__ __forceinline__ int pw_floor_count(int n) {
+  return n >= 32 ? 32 : n >= 24 ? 24 : n >= 16 ? 16 : n >= 12 ? 12 : n >= 8 ? 8 : n >= 6 ? 6 : n >= 4 ? 4 : n >= 2 ? 2 : 0;
+}
+
+// LD: the epilogue has inputs to read (forward: bias; data gradient: ReLU mask and / or the old value to accumulate onto)
+template <int BN, int NST, bool DGRAD, bool LD>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_pointwise_kernel(const ConvArgs a, const PwGeom g) {
+  constexpr int BM = 128;
+  constexpr int WN = BN / 64, WM = 8 / WN;            // waves along Co / along pixels
+  constexpr int TP = BM / WM;                         // pixels per wave (64 / 32 / 16)
+  constexpr int NPT = TP / 16, NCT = 4, NPAIR = 2;    // wave tile: TP pixels x 64 channels
+  constexpr int ABYTES = BM * 128, WBYTES = BN * 128, SB = ABYTES + WBYTES;
+  constexpr int APW = 2, WPW = BN / 64;               // DMA pieces per wave and K-step (A: 16 pieces, W: BN / 8 pieces)
+  constexpr int DPW = APW + WPW;
+  static_assert(NST * SB <= 160 * 1024, "LDS budget");
+  static_assert((NST - 1) * DPW + 2 * NPT * NPAIR <= 63, "vmcnt range");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int srow = lane >> 3;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
+  const int G = gridDim.x;
+
+  auto decode = [&](int v, int& mt, int& nb) __attribute__((always_inline)) -> bool {     // v = round * G + block
+    int it;
+    if (g.grouped) {
+      const int r = v / G, b = v - r * G;
+      it = r * G + (b & 7) * (G >> 3) + (b >> 3);      // an XCD (blocks b, b + 8, ...) takes a contiguous run of items
+    } else {
+      it = v;
+    }
+    mt = (int)fdiv((unsigned)it, g.div_nb);
+    nb = it - mt * g.NB;
+    return it < g.items;
+  };
+
+  // ---- DMA geometry.  LDS rows are 128 bytes (64 channels); chunk c of row r sits at position c ^ key(r).
+  // A rows (pixels): key = r & 7.  W rows: pairs of channel tiles are interleaved (lane row frow of tile c is output channel
+  // (c>>1)*32 + (frow>>2)*8 + (c&1)*4 + (frow&3)), a ds_read_b128 group touches rows {0-3, 8-11 | 16-19, 24-27}: key = (r&3) | ((r>>3)&1)<<2.
+  auto wkey = [](int r) __attribute__((always_inline)) -> int { return (r & 3) | (((r >> 3) & 1) << 2); };
+  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, (unsigned)a.M * (unsigned)a.C * 2u);             // rows >= M are out of range: zero fill
+  const pw_u32x4 rsrc_w = pw_make_rsrc(a.w, (unsigned)(g.NB * BN) * (unsigned)a.Kpad * 2u);
+  unsigned avoff[APW], wvoff[WPW];
+#pragma unroll
+  for (int k = 0; k < APW; ++k) {
+    const int row = (wave * APW + k) * 8 + srow;
+    avoff[k] = (unsigned)row * (unsigned)(a.C * 2) + (unsigned)(((lane & 7) ^ (row & 7)) << 4);
+  }
+#pragma unroll
+  for (int k = 0; k < WPW; ++k) {
+    const int row = (wave * WPW + k) * 8 + srow;
+    wvoff[k] = (unsigned)row * (unsigned)(a.Kpad * 2) + (unsigned)(((lane & 7) ^ wkey(row)) << 4);
+  }
+  int d_v = blockIdx.x, d_k = 0, d_idx = 0, d_mt, d_nb;
+  bool d_ok = decode(d_v, d_mt, d_nb);
+  auto issue = [&]() __attribute__((always_inline)) {      // K-step (d_v, d_k) into ring slot d_idx % NST; always DPW instructions
+    const unsigned base = lds0 + (unsigned)(d_idx % NST) * SB;
+    // (the whole offset goes through the per-lane operand: that one is range-checked, so pixel rows >= M and the steps beyond the
+    // stream read zeros)
+    const unsigned inv = d_ok ? 0u : 0xFFFFFFFFu;
+    const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.C * 2) + (unsigned)(d_k * 128);
+    const unsigned sw = (unsigned)(d_nb * BN) * (unsigned)(a.Kpad * 2) + (unsigned)(d_k * 128);
+#pragma unroll
+    for (int k = 0; k < APW; ++k) pw_dma16(rsrc_x, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) pw_dma16(rsrc_w, (wvoff[k] + sw) | inv, base + ABYTES + (wave * WPW + k) * 1024);
+    ++d_idx;
+    if (d_ok && ++d_k == g.ksteps) {
+      d_k = 0;
+      d_v += G;
+      d_ok = decode(d_v, d_mt, d_nb);
+    }
+  };
+
+  // ---- fragment addresses (ring slot 0; ks = 1 is ^ 64)
+  const int frow = lane & 15, fq = lane >> 4;
+  const int wrow0 = (frow >> 2) * 8 + (frow & 3);
+  const int offW = ABYTES + (wn * 64 + wrow0) * 128 + ((fq ^ wkey(wrow0)) << 4);      // + (c>>1)*4096 + (c&1)*512
+  int offA[NPT];
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int r = wm * TP + p * 16 + frow;
+    offA[p] = r * 128 + ((fq ^ (r & 7)) << 4);
+  }
+
+  f32x4 acc[NCT][NPT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int c_v = blockIdx.x, c_idx = 0, c_mt, c_nb;
+  if (!decode(c_v, c_mt, c_nb)) return;                // (uniform) nothing for this block
+
+  // ---- prologue: NST - 1 K-steps in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue();
+  int st_age = NST;                                    // K-steps since this wave's last epilogue stores (>= NST - 1: none pending)
+  int st_cnt = 0;                                      // number of those stores
+
+  // One K-step.  LAST = the item's last step: its epilogue inputs (forward: bias; data gradient: ReLU mask, old value) are asm loads
+  // issued AHEAD of the step's DMA, waited for with vmcnt(DPW) after the MFMAs (only this step's DMA is younger) and handed to the
+  // compiler by ONE statement naming every destination — straight-line code, so no register of a load in flight is ever copied.
+  // Waves 0-3 issue the step's DMA BEFORE their fragment reads / MFMAs, waves 4-7 AFTER (one wave of each group per SIMD): a group's DMA
+  // issue (~80 cycles per instruction) runs under the other group's MFMAs instead of all eight waves moving in lockstep.
+  auto step = [&](auto lastc, auto latec) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(lastc)::value, LATE = decltype(latec)::value;
+    constexpr int LDWAIT = LATE ? 0 : DPW;            // vector-memory operations younger than the epilogue loads at their wait
+    // pieces of K-step c_idx have landed when at most the (NST - 2) younger steps + the stores of a recent epilogue are outstanding
+    const int pend = st_age <= NST - 2 ? st_cnt : 0;
+    pw_wait_vmcnt_dyn(pw_floor_count((NST - 2) * DPW + pend));
+    __builtin_amdgcn_s_barrier();                      // ... for every wave; and every wave is done reading slot (c_idx - 1) % NST
+    [[maybe_unused]] pw_u32x4 ld_m[NPT][NPAIR], ld_o[NPT][NPAIR], ld_b[NPAIR][2];
+    const int cb = c_nb * BN + wn * 64 + fq * 8;       // this lane's 8 consecutive channels of pair 0 (+32 per pair)
+    if constexpr (LAST && LD) {
+      if constexpr (DGRAD) {
+        // (a mode that is off reads the other mode's tensor: same lines, no extra traffic, value unused)
+        const bf16_t* mbase = a.mask ? a.mask : reinterpret_cast<const bf16_t*>(a.y);
+        const bf16_t* obase = a.accumulate ? reinterpret_cast<const bf16_t*>(a.y) : a.mask;
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const long m = (long)c_mt * BM + wm * TP + p * 16 + frow;
+          const long mm = m < a.M ? m : (long)a.M - 1;
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q) {
+            const size_t o = (size_t)mm * a.Co + cb + q * 32;
+            ld_m[p][q] = pw_load16(mbase + o);
+            ld_o[p][q] = pw_load16(obase + o);
+          }
+        }
+      } else {
+        const float* bbase = a.bias ? a.bias + cb : reinterpret_cast<const float*>(a.w);
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+          ld_b[q][0] = pw_load16(bbase + q * 32);
+          ld_b[q][1] = pw_load16(bbase + q * 32 + 4);
+        }
+      }
+    }
+    if constexpr (!LATE) issue();                      // K-step c_idx + NST - 1 into the slot just freed
+    const int base = (c_idx % NST) * SB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[NCT], xf[NPT];
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(smem + base + ((offW + (c >> 1) * 4096 + (c & 1) * 512) ^ (ks * 64)));
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(smem + base + (offA[p] ^ (ks * 64)));
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(wf[c], xf[p], acc[c][p]);
+    }
+    ++c_idx;
+    ++st_age;
+    if constexpr (LAST) {
+      // ---- epilogue: lane owns channels cb + q*32 .. +7 of pixel m
+      if constexpr (!LD) {
+      } else if constexpr (DGRAD) {
+        if constexpr (NPT == 2)
+          asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ld_m[0][0]), "+v"(ld_m[0][1]), "+v"(ld_m[1][0]), "+v"(ld_m[1][1]), "+v"(ld_o[0][0]), "+v"(ld_o[0][1]),
+                       "+v"(ld_o[1][0]), "+v"(ld_o[1][1]) : "n"(LDWAIT) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ld_m[0][0]), "+v"(ld_m[0][1]), "+v"(ld_o[0][0]), "+v"(ld_o[0][1]) : "n"(LDWAIT) : "memory");
+        static_assert(NPT <= 2, "data-gradient tiles with epilogue inputs are at most 128 wide");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ld_b[0][0]), "+v"(ld_b[0][1]), "+v"(ld_b[1][0]), "+v"(ld_b[1][1]) : "n"(LDWAIT) : "memory");
+      }
+      float bv[NPAIR][8];
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bv[q][r] = 0.f;
+      if constexpr (!DGRAD && LD) {
+        if (a.bias) {
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bv[q][r] = __uint_as_float(ld_b[q][0][r]);
+              bv[q][4 + r] = __uint_as_float(ld_b[q][1][r]);
+            }
+        }
+      }
+      int ns = 0;
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        const long m = (long)c_mt * BM + wm * TP + p * 16 + frow;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][p][r]; v[4 + r] = acc[2 * q + 1][p][r]; }
+          if constexpr (!DGRAD) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bv[q][r];
+            if (a.relu) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+          } else {
+            if (LD && a.mask) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float lo, hi;
+                unpack2bf(ld_m[p][q][r], lo, hi);
+                if (!(lo > 0.f)) v[2 * r] = 0.f;
+                if (!(hi > 0.f)) v[2 * r + 1] = 0.f;
+              }
+            }
+            if (LD && a.accumulate) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float lo, hi;
+                unpack2bf(ld_o[p][q][r], lo, hi);
+                v[2 * r] += lo;
+                v[2 * r + 1] += hi;
+              }
+            }
+          }
+          if (m < a.M) {
+            const pw_u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            *reinterpret_cast<pw_u32x4*>(reinterpret_cast<bf16_t*>(a.y) + (size_t)m * a.Co + cb + q * 32) = t;
+          }
+          ++ns;
+          acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      st_age = 0;
+      st_cnt = ((long)c_mt * BM + BM <= (long)a.M) ? ns : 0;      // a ragged last tile may skip stores: never over-count what is pending
+    }
+    if constexpr (LATE) issue();
+  };
+  if (wave < 4) {
+    for (;;) {
+      for (int k = 0; k + 1 < g.ksteps; ++k) step(std::false_type{}, std::false_type{});
+      step(std::true_type{}, std::false_type{});
+      c_v += G;
+      if (!decode(c_v, c_mt, c_nb)) break;
+    }
+  } else {
+    for (;;) {
+      for (int k = 0; k + 1 < g.ksteps; ++k) step(std::false_type{}, std::true_type{});
+      step(std::true_type{}, std::true_type{});
+      c_v += G;
+      if (!decode(c_v, c_mt, c_nb)) break;
+    }
+  }
+  pw_wait_vmcnt<0>();                                  // zero-fill pieces of the steps beyond the stream may still be landing
+}
+
+int pw_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+template <int BN, int NST, bool DGRAD, bool LD>
+int launch_pw(const ConvArgs& a, hipStream_t s) {
+  constexpr int LDS = NST * (128 * 128 + BN * 128);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pointwise_kernel<BN, NST, DGRAD, LD>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)attr_ok;
+  PwGeom g{};
+  g.m_tiles = (a.M + 127) / 128;
+  g.NB = a.Co / BN;
+  g.items = g.m_tiles * g.NB;
+  g.ksteps = a.C / 64;
+  g.div_nb = make_fastdiv(g.NB);
+  int G = pw_cu_count();
+  if (g.items < G) G = g.items;
+  g.grouped = (G % 8 == 0 && ((G >> 3) % g.NB) == 0 && g.items >= G) ? 1 : 0;
+  hipLaunchKernelGGL((conv_pointwise_kernel<BN, NST, DGRAD, LD>), dim3(G), dim3(512), LDS, s, a, g);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+bool pw_eligible(const ConvArgs& a) {
+  if (!(a.kh == 1 && a.kw == 1 && a.stride == 1 && a.dstride == 1 && a.H == a.Ho && a.W == a.Wo)) return false;
+  if (a.C % 64 != 0 || a.Co % 64 != 0 || a.C < 64 || a.Kpad != a.C) return false;
+  if (a.out_f32 || a.resid || a.pool_y) return false;
+  if ((long)a.M < 2048) return false;                      // tiny maps: the flat-M kernel's smaller tiles fill the chip better
+  if ((long)a.M * a.C >= (1l << 31) || (long)a.Co * a.Kpad >= (1l << 31)) return false;
+  return true;
+}
+
+}  // namespace
+
+// tile width: the whole Co where it fits (X read once); a data gradient WITH epilogue inputs keeps them in registers: 128 at most
+static int pw_bn(const ConvArgs& a, bool dgrad_ld) { return (a.Co % 256 == 0 && !dgrad_ld) ? 256 : (a.Co % 128 == 0 ? 128 : 64); }
+
+const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad) {
+  if (!pw_eligible(a)) return nullptr;
+  const bool ld = dgrad ? (a.mask || a.accumulate) : true;
+  const int bn = pw_bn(a, dgrad && ld);
+  if (dgrad) {
+    if (ld) return bn == 128 ? "conv_pointwise_kernel<128, 4, true, true>" : "conv_pointwise_kernel<64, 4, true, true>";
+    return bn == 256 ? "conv_pointwise_kernel<256, 3, true, false>" : bn == 128 ? "conv_pointwise_kernel<128, 4, true, false>" : "conv_pointwise_kernel<64, 4, true, false>";
+  }
+  return bn == 256 ? "conv_pointwise_kernel<256, 3, false, true>" : bn == 128 ? "conv_pointwise_kernel<128, 4, false, true>" : "conv_pointwise_kernel<64, 4, false, true>";
+}
+
+// DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to the flat-M kernel).
+int danhip_launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
+  if (!pw_eligible(a)) return 1;
+  const bool dgrad = !a.bias && !a.relu;
+  if (!dgrad && (a.mask || a.accumulate)) return 1;
+  const bool ld = dgrad ? (a.mask || a.accumulate) : true;
+  const int bn = pw_bn(a, dgrad && ld);
+  if (dgrad) {
+    if (ld) return bn == 128 ? launch_pw<128, 4, true, true>(a, s) : launch_pw<64, 4, true, true>(a, s);
+    return bn == 256 ? launch_pw<256, 3, true, false>(a, s) : bn == 128 ? launch_pw<128, 4, true, false>(a, s) : launch_pw<64, 4, true, false>(a, s);
+  }
+  return bn == 256 ? launch_pw<256, 3, false, true>(a, s) : bn == 128 ? launch_pw<128, 4, false, true>(a, s) : launch_pw<64, 4, false, true>(a, s);
+}

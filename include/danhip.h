@@ -80,9 +80,9 @@ int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_desc* d, cons
 int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_dev, int32_t n, int32_t total_blocks, void* stream);
 
 /* y = act(conv(x, w) + bias).  x bf16; y bf16 (out_dtype=DANHIP_BF16) or fp32; bias fp32[Cout] or NULL.
- * Pointwise (1x1, stride 1) convolutions with >= 64 channels either side and 16-bit output are plain GEMMs and run on hipBLASLt
- * (bias / ReLU as its epilogue; so does danhip_conv2d_bwd_data when relu_mask is NULL); DANHIP_NO_BLASLT=1 keeps them on the
- * implicit-GEMM kernel.
+ * Pointwise (1x1, stride 1) convolutions with channel counts that are multiples of 64 run on the streaming GEMM kernel
+ * (csrc/conv_pointwise.hip; bias / ReLU, or mask / accumulate for danhip_conv2d_bwd_data, in its epilogue).  No vendor GEMM or
+ * convolution library is linked.
  * relu: 0/1.  residual: optional bf16 tensor of y's shape added AFTER the activation (DAN context modules,
  * net/danet.py:912-918) or NULL. */
 int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias,

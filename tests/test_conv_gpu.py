@@ -26,7 +26,7 @@ SHAPES = [
     (2, 16, 64, 64, 64, 3, 3, 1), (1, 30, 62, 64, 64, 3, 3, 1), (9, 64, 128, 64, 64, 3, 3, 1),
     # first layer (3 channels padded to 8 -> 64): the store-bound direct kernel; ragged width, one-pixel-wide, many units
     (2, 17, 45, 8, 64, 3, 3, 1), (1, 5, 1, 8, 64, 3, 3, 1), (3, 64, 100, 8, 64, 3, 3, 1),
-    # pointwise convolutions with >= 4096 pixels: the hipBLASLt GEMM path (K = 64 .. 2304 as in the deformable conv, ragged Cout % 64)
+    # pointwise convolutions: conv_pointwise.hip (K = 64 .. 2304 as in the deformable conv) and, for ragged Cout % 64, the flat-M kernel
     (2, 48, 48, 256, 256, 1, 1, 1), (1, 64, 72, 2304, 256, 1, 1, 1), (1, 65, 67, 64, 72, 1, 1, 1), (4, 40, 40, 1024, 1024, 1, 1, 1),
 ]
 
@@ -201,9 +201,9 @@ def test_conv_relu_with_fused_max_pool(shape, dev):
 
 
 @pytest.mark.parametrize("accumulate", [0, 1])
-def test_pointwise_data_gradient_through_the_library_gemm(accumulate, dev):
-    """danhip_conv2d_bwd_data of a 1x1 conv without a fused ReLU mask is a hipBLASLt GEMM (beta = accumulate); with the mask it stays
-    on the implicit-GEMM kernel — both against the fp32 formula dx = dy . W^T."""
+def test_pointwise_data_gradient_ragged_channels(accumulate, dev):
+    """danhip_conv2d_bwd_data of a 1x1 conv whose channel counts are not multiples of 64 (flat-M kernel), with / without the fused ReLU
+    mask and accumulation — against the fp32 formula dx = dy . W^T."""
     import ctypes
     from dan_amd import ops
     from dan_amd._lib import call, ptr, stream
@@ -268,3 +268,46 @@ def test_backbone_layer_at_full_size_vs_oracle(name, hw, cin, cout, k, stride, d
         scale = want.abs().max().item() + 1e-6
         e = (got - want).abs().max().item()
         assert e <= 2.0 ** -6 * scale + 2e-3, (name, what, e, scale)
+
+
+# conv_pointwise.hip (1x1 / stride 1, channels multiples of 64): tiles 256 / 128 / 64 wide, K = 64 .. 2304 (the deformable conv's GEMM),
+# ragged pixel counts (last 128-pixel tile partial), one K-step per item (C = 64), several column blocks (Co = 512, 1024)
+PW_SHAPES = [(2, 48, 48, 256, 256), (1, 64, 72, 2304, 256), (4, 40, 40, 1024, 1024), (1, 45, 47, 64, 64), (3, 33, 35, 64, 256), (1, 50, 50, 128, 512),
+             (2, 40, 56, 512, 128), (1, 61, 67, 192, 64), (5, 32, 32, 256, 64), (1, 160, 160, 256, 256)]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
+    """Forward (bias, ReLU on / off) against the oracle convolution; data gradient through the C ABI in all four epilogue modes
+    (plain, ReLU mask of the producer, accumulate into an existing gradient, both) against dx = dy . W^T in fp32."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, lib, ptr, stream
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(N * H + Cin + Cout)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16)
+    w = (torch.randn((1, 1, Cin, Cout), generator=g) / Cin ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn((Cout,), generator=g)
+    d = ops._desc(N, H, W, Cin, Cout, 1, 1, 1)
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv_pointwise_kernel")
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 5).decode().startswith("conv_pointwise_kernel")
+    for relu in (False, True):
+        ref = T.conv2d_same(x.float(), w, b, stride=1, relu=relu)
+        y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=1, relu=relu)
+        torch.cuda.synchronize()
+        err = (y.float().cpu() - ref).abs().max().item()
+        assert err <= _tol(ref), (shape, relu, err, _tol(ref))
+    _, wb = ops.pack_conv_weight(d, w.to(dev), need_bwd=True)
+    dy = torch.randn((N, H, W, Cout), generator=g).to(torch.bfloat16)
+    dx0 = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16)
+    ref = (dy.float().reshape(-1, Cout) @ w.reshape(Cin, Cout).t()).reshape(N, H, W, Cin)
+    xd, dyd, dx0d = x.to(dev), dy.to(dev), dx0.to(dev)       # (held: a temporary passed through ptr() would be freed before the launch)
+    for masked in (False, True):
+        for acc in (0, 1):
+            dx = dx0d.clone()
+            call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dyd), ptr(wb), ptr(xd) if masked else None, ptr(dx), acc, stream())
+            torch.cuda.synchronize()
+            want = torch.where(x.float() > 0, ref, torch.zeros_like(ref)) if masked else ref
+            want = want + (dx0.float() if acc else 0.0)
+            err = (dx.float().cpu() - want).abs().max().item()
+            assert err <= 2.0 ** -7 * want.abs().max().item() + 2e-2, (shape, masked, acc, err)

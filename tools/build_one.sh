@@ -7,5 +7,5 @@ SRC=$1; shift
 EXTRA=""
 case "$SRC" in *_exact.hip) EXTRA="-ffp-contract=off";; esac
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -fno-gpu-rdc -Wall -Wno-unused-function $EXTRA "$@" -c "$ROOT/dan_amd/csrc/$SRC" -o "$ROOT/dan_amd/csrc/_obj/$SRC.o"
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/dan_amd/libdanhip.so" "$ROOT"/dan_amd/csrc/_obj/*.o -L/opt/rocm/lib -lhipblaslt
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/dan_amd/libdanhip.so" "$ROOT"/dan_amd/csrc/_obj/*.o
 echo "relinked $ROOT/dan_amd/libdanhip.so"
