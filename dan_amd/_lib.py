@@ -43,6 +43,12 @@ SIGNATURES = {
     "danhip_pack_entry_init": [ctypes.POINTER(PackEntry), DESC, P, I32, P, P, I32, ctypes.POINTER(ctypes.c_int32)],
     "danhip_pack_conv_weights_batched": [P, I32, I32, P],
     "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],
+    "danhip_conv2d_fwd_f32": [DESC, P, P, P, P, ctypes.c_int, P, P],
+    "danhip_maxpool2x2_fwd_f32": [P, P, I32, I32, I32, I32, P],
+    "danhip_l2norm_fwd_f32": [P, P, P, I64, I32, P],
+    "danhip_resize_bilinear_add_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, P],
+    "danhip_avgpool2x2s1_same_fwd_f32": [P, P, I32, I32, I32, I32, P],
+    "danhip_deform_sample_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],

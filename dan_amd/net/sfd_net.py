@@ -141,8 +141,11 @@ class VGG16Backbone(object):
         return self.predict_heads(feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, "multibox_head")
 
 
-def prepare_input(img_u8_rgb):
-    """uint8 RGB [B,H,W,3] (device) -> network input."""
+def prepare_input(img_u8_rgb, precision="act"):
+    """uint8 RGB [B,H,W,3] (device) -> network input.  precision "act": the build's 16-bit activation type (training and fast inference);
+    "fp32": the fp32 inference path (ops._f32_infer: every layer then runs the fp32 kernels)."""
+    if precision == "fp32":
+        return ops.preprocess_f32(img_u8_rgb)
     x = ops.preprocess_u8(img_u8_rgb)
     x._real_channels = 3
     return x

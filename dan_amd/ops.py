@@ -136,6 +136,7 @@ def _sink_trainable(t):
 # Optional per-kernel timing (bench.py): when PROFILE is a dict, every conv forward / stride-1 data-gradient launch is
 # bracketed by events on the launch stream and recorded under its kernel-instance label with its algorithmic FLOPs.
 PROFILE = None
+PROFILE_BYTES = None        # {label: [algorithmic bytes per launch]} beside PROFILE (bench.py: GB/s of the HBM-bound convolutions)
 
 
 def _prof_begin(st=None):
@@ -158,6 +159,10 @@ def _prof_end(e0, d, which, st=None):
     cin = d.Cin                              # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
     flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
     PROFILE.setdefault(label, []).append((e0, e1, flops))
+    if PROFILE_BYTES is not None:            # algorithmic HBM bytes: activations in + out (16-bit; the heads write fp32), weights once
+        co8 = (d.Cout + 7) // 8 * 8
+        nbytes = 2.0 * d.N * (d.H * d.W * cin + d.Ho * d.Wo * co8) + 2.0 * d.kh * d.kw * cin * d.Cout
+        PROFILE_BYTES.setdefault(label, []).append(nbytes)
 
 
 # ---- weight gradients on a second stream.  dgrad(L) and wgrad(L) both consume dY_L and are independent of each other; on one stream
@@ -368,8 +373,31 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None
 
 
+# ---- fp32 inference path (csrc/f32_infer.hip): every op below accepts fp32 NHWC activations and then runs the fp32 kernels — forward
+# only (the evaluation graphs; "eval box outputs within 1e-4 of the reference").  The TF variables are used as they are (no packing).
+def _f32_infer(x):
+    if x.dtype != torch.float32:
+        return False
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise RuntimeError("the fp32 path is inference only (run it under torch.no_grad())")
+    return True
+
+
+def _conv2d_f32(x, w, b, stride, relu, residual, padding):
+    N, H, W, C = x.shape
+    kh, kw, cin, cout = w.shape
+    assert cin == C and x.is_contiguous(), "fp32 conv: input channels must match the kernel (no channel padding on this path)"
+    d = _desc(N, H, W, C, cout, kh, kw, stride, padding == "valid")
+    y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32, device=x.device)
+    call("danhip_conv2d_fwd_f32", ctypes.byref(d), ptr(x), ptr(w.detach().contiguous()), ptr(b.detach()) if b is not None else None, ptr(y), int(relu),
+         ptr(residual.contiguous()) if residual is not None else None, stream())
+    return y
+
+
 def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same"):
     """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up."""
+    if _f32_infer(x):
+        return _conv2d_f32(x, w, b, stride, relu, residual, padding)
     # a plain tensor carrying a gradient sink is a fused block of parameters (FlatParams): cached packing, gradients written in place
     wp = w if (isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad")) else None
     bp = b if (isinstance(b, torch.nn.Parameter) or hasattr(b, "_danhip_grad")) else None
@@ -435,6 +463,11 @@ def _pool_deliver_ok(ctx, dy):
 
 
 def max_pool_2x2(x):
+    if _f32_infer(x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
+        call("danhip_maxpool2x2_fwd_f32", ptr(x.contiguous()), ptr(y), N, H, W, C, stream())
+        return y
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
     yslot = _new_slot(track)
@@ -507,6 +540,10 @@ class _L2Norm(torch.autograd.Function):
 
 
 def l2_normalize(x, gamma):
+    if _f32_infer(x):
+        y = torch.empty_like(x)
+        call("danhip_l2norm_fwd_f32", ptr(x.contiguous()), ptr(gamma.detach()), ptr(y), x.numel() // x.shape[-1], x.shape[-1], stream())
+        return y
     track = torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad)
     yslot = _new_slot(track)
     y = _L2Norm.apply(x, gamma, gamma if isinstance(gamma, torch.nn.Parameter) else None, _slot_of(x) if track else None, yslot)
@@ -636,6 +673,13 @@ class _ResizeAdd(torch.autograd.Function):
 
 
 def resize_bilinear_add(up, lateral=None, size=None):
+    if _f32_infer(up):
+        N, Hi, Wi, C = up.shape
+        Ho, Wo = (lateral.shape[1], lateral.shape[2]) if lateral is not None else size
+        out = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=up.device)
+        call("danhip_resize_bilinear_add_fwd_f32", ptr(up.contiguous()), ptr(lateral.contiguous()) if lateral is not None else None, ptr(out), N, Hi, Wi,
+             Ho, Wo, C, stream())
+        return out
     return _ResizeAdd.apply(up, lateral, size)
 
 
@@ -659,6 +703,11 @@ class _AvgPool2x2S1(torch.autograd.Function):
 
 
 def avg_pool_2x2_s1(x):
+    if _f32_infer(x):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        call("danhip_avgpool2x2s1_same_fwd_f32", ptr(x.contiguous()), ptr(y), N, H, W, C, stream())
+        return y
     assert x.dtype == ACT and x.is_contiguous() and x.shape[-1] % 8 == 0
     return _AvgPool2x2S1.apply(x)
 
@@ -804,6 +853,13 @@ class _DeformConv(torch.autograd.Function):
 
 def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_group=1, relu=False):
     """y = act(DeformConvOp(x, filter, offsets) + b); w1x1 = the filter viewed [1,1,kh*kw*C,Cout]."""
+    if _f32_infer(x):
+        N, H, W, C = x.shape
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        S = torch.empty((N, Ho, Wo, kh * kw * C), dtype=torch.float32, device=x.device)
+        call("danhip_deform_sample_fwd_f32", ptr(x.contiguous()), ptr(offsets.contiguous()), ptr(S), N, H, W, C, kh, kw, stride, dilation, deformable_group,
+             stream())
+        return _conv2d_f32(S, w1x1, b, 1, relu, None, "same")
     bp = b if isinstance(b, torch.nn.Parameter) else None
     track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad)
     yslot = _new_slot(track)
@@ -812,6 +868,13 @@ def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_gr
         yslot.__init__(y, relu)
         y._dh_slot = yslot
     return y
+
+
+def preprocess_f32(img_rgb_u8):
+    """uint8 RGB [N,H,W,3] -> fp32 [N,H,W,3] BGR - mean (dan_preprocessing.py:55-57,755-758): exact fp32 subtraction, 3 real channels."""
+    assert img_rgb_u8.dtype == torch.uint8 and img_rgb_u8.shape[-1] == 3
+    means = torch.tensor([123.68, 116.78, 103.94], dtype=torch.float32, device=img_rgb_u8.device)
+    return (img_rgb_u8.to(torch.float32) - means).flip(-1).contiguous()
 
 
 def deform_sample(x, offsets, kh, kw, stride=1, dilation=1, deformable_group=1):

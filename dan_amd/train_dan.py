@@ -28,7 +28,7 @@ class DANModel(object):
     def forward(self, images_u8):
         """train_dan.py:410-428 -> ((loc1 [B,A,4], cls1 [B,A,2]), (loc2, cls2), feature map sizes)."""
         b = self.backbone
-        x = sfd_net.prepare_input(images_u8)
+        x = sfd_net.prepare_input(images_u8, getattr(self, "precision", "act"))
         feats = b.get_featmaps(x, training=True)
         feats = b.build_lfpn(feats, skip_last=3)
         s1 = b.get_features_stage1(feats, name="prediction_modules_stage1")

@@ -17,7 +17,7 @@ class PBModel(object):
         """train_pb.py:396-420: {'face','head','body'} -> (location_pred [B,A_k,4], cls_pred [B,A_k,2]); the head / body
         heads predict on levels 1.. / 2.. (A_head = 8 525, A_body = 2 125 at 640x640)."""
         b = self.backbone
-        x = sfd_net.prepare_input(images_u8)
+        x = sfd_net.prepare_input(images_u8, getattr(self, "precision", "act"))
         feats = b.get_featmaps(x, training=True)
         feats = b.build_lfpn(feats, skip_last=3)
         feats = b.context_pred_module(feats)

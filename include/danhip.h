@@ -360,6 +360,22 @@ int danhip_augment_preprocess(const uint8_t* src, int32_t H, int32_t W, int32_t 
                               int32_t win_y, int32_t win_x, int32_t win_h, int32_t win_w, int32_t flip, uint16_t* dst, int32_t out_h,
                               int32_t out_w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fp32 inference path (csrc/f32_infer.hip): the evaluation graphs of eval_sfd.py:232-283 / eval_pb.py / eval_dan.py:299-404 with fp32
+ * storage and arithmetic end to end, for the north-star tolerance "eval box outputs within 1e-4 of the reference".  NHWC fp32
+ * activations, the TF variables as they are (HWIO fp32 kernel, no packing; Cin need not be padded), forward only.  Same semantics as
+ * the 16-bit entry points above: TF 'same' / 'valid' sizes through the descriptor, optional bias / ReLU / residual-after-activation. */
+int danhip_conv2d_fwd_f32(const danhip_conv_desc* d, const float* x, const float* w_hwio, const float* bias, float* y, int relu,
+                          const float* residual, void* stream);
+int danhip_maxpool2x2_fwd_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int danhip_l2norm_fwd_f32(const float* x, const float* gamma, float* y, int64_t M, int32_t C, void* stream);
+int danhip_resize_bilinear_add_fwd_f32(const float* up, const float* lateral, float* out, int32_t N, int32_t Hi, int32_t Wi, int32_t Ho,
+                                       int32_t Wo, int32_t C, void* stream);
+int danhip_avgpool2x2s1_same_fwd_f32(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* deformable im2col of DeformConvOp (cpp/Deform/deform_conv.cu:229-275) in fp32: S[N,Ho,Wo,kh*kw*C]; the GEMM is a 1x1
+ * danhip_conv2d_fwd_f32 over S */
+int danhip_deform_sample_fwd_f32(const float* x, const float* offsets, float* S, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh,
+                                 int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
