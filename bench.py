@@ -89,7 +89,7 @@ def main():
                          "--batch-per-gpu images per rank)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="capture the training step in a hipGraph (single GPU; off by default)")
+    ap.add_argument("--graph", action="store_true", help="capture the training step (incl. the bucketed RCCL all-reduce when N > 1) in a hipGraph; off by default")
     ap.add_argument("--no-eval", action="store_true", help="skip the inference-FPS leg (the 'eval FPS' half of BASELINE.json's metric)")
     ap.add_argument("--deform-offsets", type=float, default=0.0,
                     help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
@@ -153,12 +153,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.graph and world == 1:
+    if args.graph:                                    # (data-parallel steps are captured too: RCCL collectives are device-side)
         trainer.enable_graph(*step_args)
     for _ in range(args.warmup):
         trainer.train_step(*step_args)
     barrier()
-    ops.PROFILE = {} if not (args.graph and world == 1) else None      # per-kernel events cannot be recorded inside a replayed graph
+    ops.PROFILE = {} if not args.graph else None      # per-kernel events cannot be recorded inside a replayed graph
     ops.PROFILE_BYTES = {} if ops.PROFILE is not None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -303,7 +303,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": _lib.ACT_NAME, "data": "synthetic",
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
-                       "step_launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
+                       "step_launch": "hipGraph replay" if args.graph else "eager",
                        "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,

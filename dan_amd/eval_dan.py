@@ -19,8 +19,13 @@ class Detector(object):
     image uint8 [H,W,3] -> (bboxes [A,4] as (ymin,xmin,ymax,xmax), scores [A]).  Anchors are cached per image size
     (the reference rebuilds them inside the graph from tf.shape, eval_dan.py:320-342)."""
 
-    def __init__(self, model, anchor_config_fn):
+    def __init__(self, model, anchor_config_fn, precision="act"):
+        """precision: "act" = the library build's 16-bit activations (fast path, 3 k img/s); "fp32" = the fp32 inference kernels end to end,
+        the path whose box outputs agree with an fp32 reference to 1e-4 (tests/test_eval_f32_gpu.py)."""
+        if precision not in ("act", "fp32"):
+            raise ValueError("precision must be 'act' or 'fp32'")
         self.model = model
+        self.model.precision = precision
         self.anchor_config_fn = anchor_config_fn
         self._anchors = {}
 

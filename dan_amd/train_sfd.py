@@ -176,12 +176,17 @@ class DetectorTrainer(object):
         self.last = terms
         return terms
 
-    # ---- hipGraph capture of the whole step (forward, backward, optimizer, weight repack): one launch per step instead of
-    # ~600 (S3FD) ... ~3000 (DAN) kernel launches from Python.  Single-process only: the bucketed all-reduce runs on a side stream
-    # with host-side bookkeeping.  The learning rate is a kernel argument, so the graph is re-captured when the schedule moves.
+    # ---- hipGraph capture of the whole step (forward, backward, bucketed all-reduce, optimizer, weight repack): one launch per step
+    # instead of ~600 (S3FD) ... ~3000 (DAN) kernel launches from Python.  The data-parallel step is captured too when the collectives
+    # are device-side (RCCL): the buckets' side stream forks from the capturing stream through the gradient-ready events and joins it
+    # again in GradBuckets.finish(), so every rank replays [backward kernels || all-reduce of finished buckets] -> optimizer as one graph;
+    # the host-side bucket bookkeeping runs once, at capture.  gloo (host-staged) collectives cannot be captured.
+    # The learning rate is a kernel argument, so the graph is re-captured when the schedule moves.
     def enable_graph(self, images_u8, *targets, warmup=2):
-        if self.world != 1 or self.buckets.enabled:
-            raise RuntimeError("graph capture of the training step is single-process only")
+        if self.buckets.enabled and not self.buckets.device_collectives:
+            raise RuntimeError("graph capture of the data-parallel step needs device-side collectives (backend nccl = RCCL), not gloo")
+        if self.buckets.enabled and self.buckets.check:
+            raise RuntimeError("DANHIP_DP_CHECK compares on the host: not capturable")
         self._graph = None
         self._static = _tree_clone((images_u8,) + tuple(targets))
         side = torch.cuda.Stream()
@@ -196,7 +201,9 @@ class DetectorTrainer(object):
         self._graph_lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         g = torch.cuda.CUDAGraph()
         step_no = self.step_no
-        with torch.cuda.graph(g):
+        # a process group's watchdog thread polls its events while this thread captures: restrict the capture-safety check to this thread
+        mode = "thread_local" if self.buckets.enabled else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             terms = self._eager_step(*self._static)
         self.step_no = step_no                               # recording does not execute: nothing was stepped
         self._graph, self._graph_terms = g, terms

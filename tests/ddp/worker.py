@@ -2,6 +2,7 @@
 
 mode "dp" (default): WORLD_SIZE ranks (all on cuda:0, gloo backend; or one forced RCCL rank) train data-parallel on contiguous shards
 of one global batch; rank 0 saves the all-reduced gradient and the parameters after step 1 and after step 2.
+mode "graph": as "dp", with the step captured as one hipGraph (bucketed all-reduce included; RCCL groups only) after one eager warm-up step.
 mode "shards" (DDP_MODE=shards, one plain process): the same global batch cut into DDP_SHARDS contiguous shards; for each shard the
 gradient of loss_shard / N is computed from the SAME initial parameters (what one tower of tf_replicate_model_fn.py:297-302 computes) and
 saved, for the oracle's dp_step to aggregate.
@@ -78,15 +79,27 @@ assert tr.buckets.enabled == (world > 1 or forced)
 if forced:
     assert tr.buckets.device_collectives                 # RCCL group: the weight-gradient stream stays on beside the buckets
 w0 = tr.flat.w.clone()
+if mode == "graph":                                      # the data-parallel step (bucketed all-reduce included) replayed as ONE hipGraph
+    tr.enable_graph(*args_of(sl), warmup=1)
+    for _ in range(2):
+        tr.train_step(*args_of(sl))
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"w": tr.flat.w.cpu(), "g": tr.flat.g.cpu(), "step": tr.step_no, "buckets": len(tr.buckets.bounds)}, out)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    sys.exit(0)
 tr.train_step(*args_of(sl))
 torch.cuda.synchronize()
 g1, w1 = tr.flat.g.clone(), tr.flat.w.clone()
 loss1 = tr.loss_values()["total"] - tr.loss_values()["l2"]
 tr.train_step(*args_of(sl))
+tr.train_step(*args_of(sl))                           # (a third step: the graph mode's warm-up + 2 replays = 3 steps)
 torch.cuda.synchronize()
 if rank == 0:
     torch.save({"w": tr.flat.w.cpu(), "g": tr.flat.g.cpu(), "w0": w0.cpu(), "g1": g1.cpu(), "w1": w1.cpu(), "loss1": loss1,
-                "buckets": len(tr.buckets.bounds)}, out)
+                "buckets": len(tr.buckets.bounds), "step": tr.step_no}, out)
 if torch.distributed.is_initialized():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

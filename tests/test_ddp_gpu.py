@@ -89,3 +89,23 @@ def test_two_rank_step_equals_the_oracle_dp_step_over_shard_gradients(model, dev
         wd[seg[k]:seg[k + 1]] = sh["wdc"][k]
     want = sh["w0"] - 1e-4 * mult * (dp["g1"] + wd * sh["w0"])
     assert torch.allclose(dp["w1"], want, rtol=1e-5, atol=1e-7), (dp["w1"] - want).abs().max().item()
+
+
+def test_data_parallel_step_replayed_as_one_hipgraph(dev, tmp_path):
+    """DetectorTrainer.enable_graph on a data-parallel trainer: forward, backward, the bucketed RCCL all-reduce on its side stream and the
+    fused optimizer captured as ONE hipGraph (the buckets' stream forks from / joins the capturing stream through events).  The only RCCL
+    group a one-GPU box allows is a forced one-rank group; its captured run must land on the eager forced-rank run's parameters after the
+    same three steps (fp32-atomics noise), with more than one bucket in flight."""
+    base = dict(os.environ, DANHIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    base.pop("DANHIP_DIST_BACKEND", None)
+    outs = {}
+    for mode, port in (("dp", "29651"), ("graph", "29652")):
+        out = str(tmp_path / (mode + ".pt"))
+        r = subprocess.run([sys.executable, WORKER, out], env=dict(base, DDP_MODE=mode, MASTER_PORT=port), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (mode, r.stdout[-1500:], r.stderr[-3000:])
+        outs[mode] = torch.load(out)
+    a, b = outs["dp"], outs["graph"]
+    assert a["step"] == b["step"] == 3 and b["buckets"] >= 2
+    scale = a["w"].abs().max().item()
+    assert (a["w"] - b["w"]).abs().max().item() <= 1e-4 * scale
+    assert torch.isfinite(b["g"]).all() and b["g"].abs().max().item() > 0
