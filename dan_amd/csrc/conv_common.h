@@ -51,6 +51,9 @@ const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad);
 // Row-streaming 3x3/stride-1 weight gradient with a register window of X fragments (conv_wgrad_rows.hip): DANHIP_OK when launched,
 // 1 when the shape is not eligible.
 const char* danhip_wgrad_rows_label(const danhip_conv_desc* d);
+// Pointwise (1x1 / stride 1) weight gradient, 256 x 256 gradient tile per workgroup (conv_wgrad_pw.hip); same return convention.
+const char* danhip_wgrad_pw_label(const danhip_conv_desc* d);
+int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).

@@ -228,6 +228,8 @@ extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d)
   if (!d) return "";
   const char* rl = danhip_wgrad_rows_label(d);
   if (rl) return rl;
+  const char* pl = danhip_wgrad_pw_label(d);
+  if (pl) return pl;
   const int co8 = (d->Cout + 7) / 8 * 8;
   if (d->Cin == 8 && d->kh * d->kw <= 16) return co8 > 64 ? "conv_wgrad_kernel<128, 128, 2>" : "conv_wgrad_kernel<128, 64, 2>";
   const bool ci_small = d->Cin <= 64, co_small = co8 <= 64;
@@ -250,6 +252,8 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
   {
     const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
     if (hr <= 0) return hr;
+    const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
+    if (pr <= 0) return pr;
   }
   WgradArgs a{};
   a.x = x; a.dy = dy; a.dw = dw_hwio; a.db = db;

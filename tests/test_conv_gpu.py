@@ -273,7 +273,7 @@ def test_backbone_layer_at_full_size_vs_oracle(name, hw, cin, cout, k, stride, d
 # conv_pointwise.hip (1x1 / stride 1, channels multiples of 64): tiles 256 / 128 / 64 wide, K = 64 .. 2304 (the deformable conv's GEMM),
 # ragged pixel counts (last 128-pixel tile partial), one K-step per item (C = 64), several column blocks (Co = 512, 1024)
 PW_SHAPES = [(2, 48, 48, 256, 256), (1, 64, 72, 2304, 256), (4, 40, 40, 1024, 1024), (1, 45, 47, 64, 64), (3, 33, 35, 64, 256), (1, 50, 50, 128, 512),
-             (2, 40, 56, 512, 128), (1, 61, 67, 192, 64), (5, 32, 32, 256, 64), (1, 160, 160, 256, 256)]
+             (2, 40, 56, 512, 128), (1, 61, 67, 192, 64), (5, 32, 32, 256, 64), (1, 160, 160, 256, 256), (2, 47, 49, 320, 192), (1, 70, 70, 128, 72)]
 
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
@@ -289,8 +289,11 @@ def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
     w = (torch.randn((1, 1, Cin, Cout), generator=g) / Cin ** 0.5).to(torch.bfloat16).float()
     b = torch.randn((Cout,), generator=g)
     d = ops._desc(N, H, W, Cin, Cout, 1, 1, 1)
-    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv_pointwise_kernel")
-    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 5).decode().startswith("conv_pointwise_kernel")
+    if Cin % 64 == 0 and Cout % 64 == 0:
+        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv_pointwise_kernel")
+        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 5).decode().startswith("conv_pointwise_kernel")
+    if Cin % 64 == 0 and Cin >= 128 and N * H * W >= 4096:
+        assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_pw_kernel"
     for relu in (False, True):
         ref = T.conv2d_same(x.float(), w, b, stride=1, relu=relu)
         y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=1, relu=relu)
@@ -311,3 +314,12 @@ def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
             want = want + (dx0.float() if acc else 0.0)
             err = (dx.float().cpu() - want).abs().max().item()
             assert err <= 2.0 ** -7 * want.abs().max().item() + 2e-2, (shape, masked, acc, err)
+    # weight / bias gradient (conv_wgrad_pw.hip where eligible): dW = X^T dY, db = column sums of dY, accumulated onto what is there
+    dw = torch.ones((1, 1, Cin, Cout), dtype=torch.float32, device=dev)
+    db = torch.ones((Cout,), dtype=torch.float32, device=dev)
+    call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(xd), ptr(dyd), ptr(dw), ptr(db), Cin, stream())
+    torch.cuda.synchronize()
+    want_w = x.float().reshape(-1, Cin).t() @ dy.float().reshape(-1, Cout) + 1.0
+    want_b = dy.float().reshape(-1, Cout).sum(0) + 1.0
+    assert (dw.cpu().reshape(Cin, Cout) - want_w).abs().max().item() <= 2e-3 * want_w.abs().max().item(), shape
+    assert (db.cpu() - want_b).abs().max().item() <= 2e-3 * want_b.abs().max().item() + 1e-2, shape
