@@ -4,7 +4,9 @@
 // Reference call sites: the LFPN lateral / upsample convs (net/pb_net.py:198-218, net/danet.py:352-372), every 1x1 of the DAN context
 // modules (net/danet.py:842-918, net/danet_deform.py:267-290), the stage-2 mixing convs (net/danet.py:944-947), fc7 / conv6_1 / conv7_1
 // (net/sfd_net.py:146-154), and the GEMM half of DeformConvOp over its sampled columns (cpp/Deform/deform_conv.cc:509-518: K = 9 C).
-// Round 1 sent these shapes to hipBLASLt; this kernel replaces the library on the default path.
+// Round 1 sent these shapes to hipBLASLt; this kernel replaces the library on the default path.  With TAPS it is also the implicit-GEMM
+// kernel of every window convolution the halo kernels do not take (maps <= 40 px wide, stride 2, 3x1 / 1x3), in place of the two-stage
+// flat-M kernel (conv_igemm.hip keeps the ragged-channel shapes and the tiny maps).
 //
 // These products are HBM-bound (read X once, write Y once; the weights are L2-resident): the design is a streaming one.
 //  * persistent 512-thread workgroup per CU, tile = 128 pixels x BN output channels (BN = 256 / 128 / 64 = the whole Co for the
@@ -67,7 +69,11 @@ __device__ __forceinline__ int pw_floor_count(int n) {
 }
 
 // LD: the epilogue has inputs to read (forward: bias; data gradient: ReLU mask and / or the old value to accumulate onto)
-template <int BN, int NST, bool DGRAD, bool LD>
+// TAPS: a kh x kw window (any stride for the forward pass, stride 1 for the data gradient) instead of 1x1 — the implicit-GEMM form:
+// K-step (tap, 64-channel chunk) gathers the tap's shifted pixel rows; padding pixels are out-of-range lanes (zero fill).  This is what
+// carries the 3x3 convolutions on maps too small for the halo tiles (40x40, 20x20: conv5_x, fc6, the CPM / context levels 2..5), the
+// stride-2 extra layers and DAN's 3x1 / 1x3 branches.
+template <int BN, int NST, bool DGRAD, bool LD, bool TAPS>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_pointwise_kernel(const ConvArgs a, const PwGeom g) {
   constexpr int BM = 128;
   constexpr int WN = BN / 64, WM = 8 / WN;            // waves along Co / along pixels
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // A rows (pixels): key = r & 7.  W rows: pairs of channel tiles are interleaved (lane row frow of tile c is output channel
   // (c>>1)*32 + (frow>>2)*8 + (c&1)*4 + (frow&3)), a ds_read_b128 group touches rows {0-3, 8-11 | 16-19, 24-27}: key = (r&3) | ((r>>3)&1)<<2.
   auto wkey = [](int r) __attribute__((always_inline)) -> int { return (r & 3) | (((r >> 3) & 1) << 2); };
-  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, (unsigned)a.M * (unsigned)a.C * 2u);             // rows >= M are out of range: zero fill
+  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, (unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u);      // rows >= M are out of range: zero fill
   const pw_u32x4 rsrc_w = pw_make_rsrc(a.w, (unsigned)(g.NB * BN) * (unsigned)a.Kpad * 2u);
   unsigned avoff[APW], wvoff[WPW];
 #pragma unroll
@@ -119,22 +125,64 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   int d_v = blockIdx.x, d_k = 0, d_idx = 0, d_mt, d_nb;
   bool d_ok = decode(d_v, d_mt, d_nb);
+  // TAPS: per staged pixel row the byte offset of its tap-(0,0) source pixel (+ swizzled chunk) and a bit mask of the taps that fall
+  // inside the image, rebuilt when the DMA cursor enters a new item; a K-step adds the wave-uniform (tap, chunk) offset
+  [[maybe_unused]] unsigned pbase[APW], tmask[APW];
+  [[maybe_unused]] int d_ti = 0, d_tj = 0, d_cc = 0, d_tap = 0;
+  auto item_rows = [&]() __attribute__((always_inline)) {
+    if constexpr (TAPS) {
+#pragma unroll
+      for (int k = 0; k < APW; ++k) {
+        const int row = (wave * APW + k) * 8 + srow;
+        const int m = d_mt * BM + row;
+        unsigned mk = 0;
+        unsigned pb = 0;
+        if (d_ok && m < a.M) {
+          const unsigned n = fdiv((unsigned)m, a.div_howo);
+          const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
+          const unsigned ho = fdiv(rem, a.div_wo);
+          const int rh = (int)ho * a.stride - a.pad_t, rw = (int)(rem - ho * (unsigned)a.Wo) * a.stride - a.pad_l;
+          pb = (unsigned)((((int)n * a.H + rh) * a.W + rw) * a.C) * 2u + (unsigned)(((lane & 7) ^ (row & 7)) << 4);   // may wrap; exact for valid taps
+          for (int t = 0; t < a.taps; ++t) {
+            const int i = (int)fdiv((unsigned)t, a.div_kw), jj = t - i * a.kw;
+            if ((unsigned)(rh + i) < (unsigned)a.H && (unsigned)(rw + jj) < (unsigned)a.W) mk |= 1u << t;
+          }
+        }
+        pbase[k] = pb;
+        tmask[k] = mk;
+      }
+    }
+  };
+  item_rows();
   auto issue = [&]() __attribute__((always_inline)) {      // K-step (d_v, d_k) into ring slot d_idx % NST; always DPW instructions
     const unsigned base = lds0 + (unsigned)(d_idx % NST) * SB;
     // (the whole offset goes through the per-lane operand: that one is range-checked, so pixel rows >= M and the steps beyond the
     // stream read zeros)
     const unsigned inv = d_ok ? 0u : 0xFFFFFFFFu;
-    const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.C * 2) + (unsigned)(d_k * 128);
     const unsigned sw = (unsigned)(d_nb * BN) * (unsigned)(a.Kpad * 2) + (unsigned)(d_k * 128);
+    if constexpr (TAPS) {
+      const unsigned toff = (unsigned)((d_ti * a.W + d_tj) * a.C + d_cc * 64) * 2u;       // wave-uniform
 #pragma unroll
-    for (int k = 0; k < APW; ++k) pw_dma16(rsrc_x, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
+      for (int k = 0; k < APW; ++k) {
+        const unsigned voff = ((tmask[k] >> d_tap) & 1u) ? pbase[k] + toff : 0xFFFFFFFFu;
+        pw_dma16(rsrc_x, voff | inv, base + (wave * APW + k) * 1024);
+      }
+    } else {
+      const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.C * 2) + (unsigned)(d_k * 128);
+#pragma unroll
+      for (int k = 0; k < APW; ++k) pw_dma16(rsrc_x, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
+    }
 #pragma unroll
     for (int k = 0; k < WPW; ++k) pw_dma16(rsrc_w, (wvoff[k] + sw) | inv, base + ABYTES + (wave * WPW + k) * 1024);
     ++d_idx;
+    if constexpr (TAPS) {
+      if (++d_cc == a.cpt) { d_cc = 0; ++d_tap; if (++d_tj == a.kw) { d_tj = 0; ++d_ti; } }
+    }
     if (d_ok && ++d_k == g.ksteps) {
       d_k = 0;
       d_v += G;
       d_ok = decode(d_v, d_mt, d_nb);
+      if constexpr (TAPS) { d_ti = d_tj = d_cc = d_tap = 0; item_rows(); }
     }
   };
 
@@ -326,32 +374,38 @@ int pw_cu_count() {
   return n;
 }
 
-template <int BN, int NST, bool DGRAD, bool LD>
-int launch_pw(const ConvArgs& a, hipStream_t s) {
+template <int BN, int NST, bool DGRAD, bool LD, bool TAPS>
+int launch_pw_t(const ConvArgs& a, hipStream_t s) {
   constexpr int LDS = NST * (128 * 128 + BN * 128);
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pointwise_kernel<BN, NST, DGRAD, LD>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pointwise_kernel<BN, NST, DGRAD, LD, TAPS>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   PwGeom g{};
   g.m_tiles = (a.M + 127) / 128;
   g.NB = a.Co / BN;
   g.items = g.m_tiles * g.NB;
-  g.ksteps = a.C / 64;
+  g.ksteps = a.Kpad / 64;
   g.div_nb = make_fastdiv(g.NB);
   int G = pw_cu_count();
   if (g.items < G) G = g.items;
   g.grouped = (G % 8 == 0 && ((G >> 3) % g.NB) == 0 && g.items >= G) ? 1 : 0;
-  hipLaunchKernelGGL((conv_pointwise_kernel<BN, NST, DGRAD, LD>), dim3(G), dim3(512), LDS, s, a, g);
+  hipLaunchKernelGGL((conv_pointwise_kernel<BN, NST, DGRAD, LD, TAPS>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
 
+template <int BN, int NST, bool DGRAD, bool LD>
+int launch_pw(const ConvArgs& a, hipStream_t s) {
+  const bool plain = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
+  return plain ? launch_pw_t<BN, NST, DGRAD, LD, false>(a, s) : launch_pw_t<BN, NST, DGRAD, LD, true>(a, s);
+}
+
 bool pw_eligible(const ConvArgs& a) {
-  if (!(a.kh == 1 && a.kw == 1 && a.stride == 1 && a.dstride == 1 && a.H == a.Ho && a.W == a.Wo)) return false;
-  if (a.C % 64 != 0 || a.Co % 64 != 0 || a.C < 64 || a.Kpad != a.C) return false;
+  if (a.dstride != 1 || a.taps > 32) return false;
+  if (a.C % 64 != 0 || a.Co % 64 != 0 || a.C < 64 || a.Kpad != a.taps * a.C) return false;
   if (a.out_f32 || a.resid || a.pool_y) return false;
   if ((long)a.M < 2048) return false;                      // tiny maps: the flat-M kernel's smaller tiles fill the chip better
-  if ((long)a.M * a.C >= (1l << 31) || (long)a.Co * a.Kpad >= (1l << 31)) return false;
+  if ((long)a.N * a.H * a.W * a.C >= (1l << 31) || (long)a.Co * a.Kpad >= (1l << 31)) return false;
   return true;
 }
 
@@ -364,11 +418,17 @@ const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad) {
   if (!pw_eligible(a)) return nullptr;
   const bool ld = dgrad ? (a.mask || a.accumulate) : true;
   const int bn = pw_bn(a, dgrad && ld);
-  if (dgrad) {
-    if (ld) return bn == 128 ? "conv_pointwise_kernel<128, 4, true, true>" : "conv_pointwise_kernel<64, 4, true, true>";
-    return bn == 256 ? "conv_pointwise_kernel<256, 3, true, false>" : bn == 128 ? "conv_pointwise_kernel<128, 4, true, false>" : "conv_pointwise_kernel<64, 4, true, false>";
-  }
-  return bn == 256 ? "conv_pointwise_kernel<256, 3, false, true>" : bn == 128 ? "conv_pointwise_kernel<128, 4, false, true>" : "conv_pointwise_kernel<64, 4, false, true>";
+  const bool plain = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
+  static const char* names[2][2][2][3] = {      // [taps][dgrad][ld][bn 256 / 128 / 64]
+      {{{"conv_pointwise_kernel<256, 3, false, false, false>", "conv_pointwise_kernel<128, 4, false, false, false>", "conv_pointwise_kernel<64, 4, false, false, false>"},
+        {"conv_pointwise_kernel<256, 3, false, true, false>", "conv_pointwise_kernel<128, 4, false, true, false>", "conv_pointwise_kernel<64, 4, false, true, false>"}},
+       {{"conv_pointwise_kernel<256, 3, true, false, false>", "conv_pointwise_kernel<128, 4, true, false, false>", "conv_pointwise_kernel<64, 4, true, false, false>"},
+        {"conv_pointwise_kernel<256, 3, true, true, false>", "conv_pointwise_kernel<128, 4, true, true, false>", "conv_pointwise_kernel<64, 4, true, true, false>"}}},
+      {{{"conv_pointwise_kernel<256, 3, false, false, true>", "conv_pointwise_kernel<128, 4, false, false, true>", "conv_pointwise_kernel<64, 4, false, false, true>"},
+        {"conv_pointwise_kernel<256, 3, false, true, true>", "conv_pointwise_kernel<128, 4, false, true, true>", "conv_pointwise_kernel<64, 4, false, true, true>"}},
+       {{"conv_pointwise_kernel<256, 3, true, false, true>", "conv_pointwise_kernel<128, 4, true, false, true>", "conv_pointwise_kernel<64, 4, true, false, true>"},
+        {"conv_pointwise_kernel<256, 3, true, true, true>", "conv_pointwise_kernel<128, 4, true, true, true>", "conv_pointwise_kernel<64, 4, true, true, true>"}}}};
+  return names[plain ? 0 : 1][dgrad ? 1 : 0][ld ? 1 : 0][bn == 256 ? 0 : bn == 128 ? 1 : 2];
 }
 
 // DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to the flat-M kernel).

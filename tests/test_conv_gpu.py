@@ -28,6 +28,9 @@ SHAPES = [
     (2, 17, 45, 8, 64, 3, 3, 1), (1, 5, 1, 8, 64, 3, 3, 1), (3, 64, 100, 8, 64, 3, 3, 1),
     # pointwise convolutions: conv_pointwise.hip (K = 64 .. 2304 as in the deformable conv) and, for ragged Cout % 64, the flat-M kernel
     (2, 48, 48, 256, 256, 1, 1, 1), (1, 64, 72, 2304, 256, 1, 1, 1), (1, 65, 67, 64, 72, 1, 1, 1), (4, 40, 40, 1024, 1024, 1, 1, 1),
+    # windows on maps too small for the halo tiles, stride 2, 3x1 / 1x3, ragged pixel counts: the streaming kernel's tap-gather form
+    (4, 40, 40, 256, 512, 3, 3, 1), (8, 20, 20, 512, 1024, 3, 3, 1), (2, 40, 44, 128, 64, 3, 1, 1), (2, 40, 44, 64, 128, 1, 3, 1),
+    (6, 40, 40, 256, 256, 3, 3, 2), (3, 37, 41, 192, 320, 3, 3, 1), (7, 19, 23, 64, 64, 3, 3, 1),
 ]
 
 
