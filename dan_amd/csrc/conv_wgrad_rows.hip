@@ -72,8 +72,7 @@ struct RowStep {
   bool xvalid, yvalid;
 };
 
-// ABL (diagnosis builds, DANHIP_WGRAD_ABLATE): bit 0 no MFMA, bit 1 no DMA in the loop, bit 2 no fragment reads, bit 3 no epilogue atomics
-template <int COT, int ABL = 0>
+template <int COT>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad_rows_kernel(const WgRowsArgs a) {
   constexpr int TW = 32;
   constexpr int PITCH = 40;                           // X ring row: 34 pixels used, 5 DMA pieces of 8 pixels x 128 bytes
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto mem = [&](auto uc) __attribute__((always_inline)) {              // fragments of the K-step in ring slot U
     constexpr int U = decltype(uc)::value;
-    if constexpr (ABL & 4) return;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       const s16x4 lo = tr2(yaddr[o] + U * YS), hi = tr2(yaddr[o] + 4 * RBY + U * YS);
@@ -249,13 +247,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto mma = [&](auto uc) __attribute__((always_inline)) {              // newest window row is slot U % 3 = tap row 2
     constexpr int U = decltype(uc)::value;
-    if constexpr (ABL & 1) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(win[U % 3][j]));
-#pragma unroll
-      for (int o = 0; o < NO; ++o) asm volatile("" ::"v"(yf[o]));
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -295,7 +286,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int v = 0; v < V; v += DEPTH) {
       auto step = [&](auto uc) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
-        if constexpr (!(ABL & 2)) dma_step(std::integral_constant<int, (U + P) % DEPTH>{}, nxt);   // geometry from the previous phase
+        dma_step(std::integral_constant<int, (U + P) % DEPTH>{}, nxt);   // geometry from the previous phase
         __builtin_amdgcn_sched_barrier(0);
         mem(uc);
         __builtin_amdgcn_sched_barrier(0);
@@ -329,7 +320,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __builtin_amdgcn_sched_barrier(0);
         wr_wait_vmcnt<2 * (P - 1)>();
         __builtin_amdgcn_s_barrier();                // b1
-        if constexpr (!(ABL & 2)) dma_step(std::integral_constant<int, (U + 1 + P) % DEPTH>{}, nxt);
+        dma_step(std::integral_constant<int, (U + 1 + P) % DEPTH>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
         mem(std::integral_constant<int, (U + 1) % DEPTH>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -344,13 +335,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   wr_wait_vmcnt<0>();                                 // zero-fill pieces of the steps beyond the stream are still landing
 
   // ---- epilogue: lane holds dW[tap][ci = ci0 + wci*16 + g*4 + r][co = co0 + wco*NO*16 + o*16 + (lane & 15)]
-  if constexpr (ABL & 8) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int o = 0; o < NO; ++o) asm volatile("" ::"v"(acc[t][o]));
-    return;
-  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -379,10 +363,10 @@ int wr_cu_count() {
   return n;
 }
 
-template <int COT, int ABL = 0>
+template <int COT>
 int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   constexpr int LDS = 6 * (32 * COT * 2) + 6 * 40 * 128;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<COT, ABL>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<COT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   a.ci_tiles = a.C / 64;
@@ -396,7 +380,7 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   a.div_ci = make_fastdiv(a.ci_tiles);
   a.div_pairs = make_fastdiv(pairs);
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
-  hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT, ABL>), dim3(pairs * splits), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -428,20 +412,5 @@ int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const b
   a.total_rows = d->N * a.tiles_x * d->H;
   a.div_tx = make_fastdiv(a.tiles_x);
   a.div_h = make_fastdiv(d->H);
-#ifdef DANHIP_WGRAD_DIAG
-  static const int abl = [] { const char* e = getenv("DANHIP_WGRAD_ABLATE"); return e ? atoi(e) : 0; }();
-  if (co8 % 128 == 0) {
-    switch (abl) {
-      case 1: return launch_wg_rows<128, 1>(a, s);
-      case 2: return launch_wg_rows<128, 2>(a, s);
-      case 4: return launch_wg_rows<128, 4>(a, s);
-      case 6: return launch_wg_rows<128, 6>(a, s);
-      case 7: return launch_wg_rows<128, 7>(a, s);
-      case 8: return launch_wg_rows<128, 8>(a, s);
-      case 9: return launch_wg_rows<128, 9>(a, s);
-      default: break;
-    }
-  }
-#endif
   return co8 % 128 == 0 ? launch_wg_rows<128>(a, s) : launch_wg_rows<64>(a, s);
 }
