@@ -214,7 +214,9 @@ __global__ void bn_reduce_kernel(const bf16_t* __restrict__ a, const bf16_t* __r
   }
 }
 
-// mean/var from the sums; optionally updates the moving averages (TF: moving = moving*m + batch*(1-m), biased variance)
+// mean/var from the sums; optionally updates the moving averages: moving = moving*m + batch*(1-m).  tf.layers.batch_normalization on a
+// 4-D input takes TF1's FUSED path, which normalises with the biased batch variance but feeds the moving average the Bessel-corrected
+// one (var * M / (M - 1), nn_impl.fused_batch_norm's batch_var output)
 __global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ var_out, float* __restrict__ mov_mean, float* __restrict__ mov_var, float inv_m, float eps,
                                    float momentum, int C) {
@@ -227,7 +229,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __
   rstd[c] = rsqrtf(var + eps);
   if (var_out) var_out[c] = var;
   if (mov_mean) mov_mean[c] = mov_mean[c] * momentum + mu * (1.f - momentum);
-  if (mov_var) mov_var[c] = mov_var[c] * momentum + var * (1.f - momentum);
+  if (mov_var) {
+    const float m = 1.f / inv_m;
+    const float unbiased = m > 1.f ? var * (m / (m - 1.f)) : var;
+    mov_var[c] = mov_var[c] * momentum + unbiased * (1.f - momentum);
+  }
 }
 
 // y = (x - mean) * rstd * gamma + beta  (relu optional)

@@ -25,6 +25,25 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             outs.append(self.conv2d(merged, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
         return outs + [feature_layers[-1]]
 
+    def build_reverse_lfpn(self, feature_layers, skip_last=3, name=None):
+        """net/danet.py:382-412 (defined on the backbone, used by no script): the bottom-up counterpart of build_lfpn — for ind = 0 ..
+        skip_last-1 a 3x3 / stride-2 'downsample_conv' of the running map (the first level to start with) to the next level's channels,
+        a 1x1 'lateral' on that next level, their SUM carried on, and a 3x3 'fused_conv' to 256 channels as the level's output; no
+        activation anywhere; level 0 and the levels beyond skip_last pass through."""
+        name = name or "reverse_lfpn"
+        outs = []
+        down = None
+        for ind in range(0, skip_last):
+            sc = "{}/reverse_fpn_{}".format(name, ind)
+            down_channels = feature_layers[ind + 1].shape[-1]
+            if down is None:
+                down = feature_layers[ind]
+            down = self.conv2d(down, down_channels, (3, 3), 2, sc + "/downsample_conv", relu=False)
+            lateral = self.conv2d(feature_layers[ind + 1], down_channels, (1, 1), 1, sc + "/lateral", relu=False)
+            down = lateral + down
+            outs.append(self.conv2d(down, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
+        return [feature_layers[0]] + outs + list(feature_layers[skip_last + 1:])
+
     def _cr(self, inputs, filters, ksize, name):
         return self.conv2d(inputs, filters, ksize, 1, name, relu=True)
 

@@ -595,6 +595,10 @@ class _DetectionLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cls, loc, labels, loc_t, ratio, at_least_one, scale):
         B, A, _ = cls.shape
+        # the kernels read raw pointers: a wrong dtype would be misread silently
+        assert cls.dtype == torch.float32 and loc.dtype == torch.float32 and loc_t.dtype == torch.float32, "detection_loss: fp32 logits / targets"
+        assert labels.dtype == torch.int32 and labels.shape == (B, A), "detection_loss: labels must be int32 [B, A]"
+        assert cls.is_contiguous() and loc.is_contiguous() and labels.is_contiguous() and loc_t.is_contiguous()
         dev = cls.device
         score = torch.empty((B, A), dtype=torch.float32, device=dev)
         counts = torch.empty((B, 2), dtype=torch.int32, device=dev)

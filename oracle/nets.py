@@ -152,6 +152,24 @@ def build_bi_lfpn(P, feats, skip_last=3, name="lfpn"):
     return outs + [feats[-1]]
 
 
+def build_reverse_lfpn(P, feats, skip_last=3, name="reverse_lfpn"):
+    """net/danet.py:382-412: down = conv3x3/s2(down or feats[ind]) -> C_{ind+1}; lat = conv1x1(feats[ind+1]); down = lat + down;
+    out_ind = conv3x3(down) -> 256.  Returns [feats[0]] + outs + feats[skip_last+1:]."""
+    outs, down = [], None
+    for ind in range(0, skip_last):
+        sc = "{}/reverse_fpn_{}".format(name, ind)
+        dc = feats[ind + 1].shape[-1]
+        if down is None:
+            down = feats[ind]
+        down = conv(P, down, dc, (3, 3), 2, sc + "/downsample_conv", relu=False)
+        lat = conv(P, feats[ind + 1], dc, (1, 1), 1, sc + "/lateral", relu=False)
+        down = lat + down
+        if P.emulate_bf16:
+            down = T.round_bf16(down, True, True)
+        outs.append(conv(P, down, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
+    return [feats[0]] + outs + list(feats[skip_last + 1:])
+
+
 def context_pred_module(P, feats):
     """PyramidBox CPM — net/pb_net.py:158-183 (hard-coded 1024 channels)."""
     def block(x, nc, last_div, name):

@@ -146,11 +146,18 @@ def glorot_uniform_(shape, fan_in, fan_out, gen):
 
 def batch_norm_train(x, gamma, beta, eps):
     """tf.layers.batch_normalization(training=True, fused) over the channel axis of NHWC —
-    net/sfd_net.py:91-119. Returns (y, batch_mean, batch_var[biased])."""
+    net/sfd_net.py:91-119. Returns (y, batch_mean, batch_var[biased]).  (The moving_variance update of TF1's fused path uses the
+    Bessel-corrected variance: batch_norm_moving_variance below.)"""
     mean = x.mean((0, 1, 2))
     var = x.var((0, 1, 2), unbiased=False)
     y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
     return y, mean, var
+
+
+def batch_norm_moving_variance(moving_var, batch_var_biased, count, momentum):
+    """Moving-variance update of TF1's fused batch norm: the batch variance fed to the moving average is var * M / (M - 1)."""
+    unbiased = batch_var_biased * (count / (count - 1.0)) if count > 1 else batch_var_biased
+    return moving_var * momentum + unbiased * (1.0 - momentum)
 
 
 def batch_norm_infer(x, gamma, beta, mean, var, eps):

@@ -83,9 +83,11 @@ def test_batch_norm(shape, relu, dev):
     y.backward(dy.to(dev))
     torch.cuda.synchronize()
     assert (y.float().cpu() - y_ref.detach()).abs().max().item() <= 2.0 ** -7 * y_ref.abs().max().item() + 1e-3
-    # moving averages: moving*m + batch*(1-m), biased variance (TF)
+    # moving averages: moving*m + batch*(1-m); the fused TF1 path feeds the Bessel-corrected variance to moving_variance
     assert torch.allclose(mm.cpu(), mean_ref.detach() * (1 - 0.997), atol=1e-5)
-    assert torch.allclose(mv.cpu(), 0.997 + var_ref.detach() * (1 - 0.997), atol=1e-5)
+    count = float(x.numel() // C)
+    assert torch.allclose(mv.cpu(), T.batch_norm_moving_variance(torch.ones(C), var_ref.detach(), count, 0.997), atol=1e-6)
+    assert not torch.allclose(mv.cpu(), 0.997 + var_ref.detach() * (1 - 0.997), atol=1e-7) or count > 1e5
     if not relu:                                        # (with ReLU the mask is taken on bf16-rounded outputs: covered by the forward check)
         for got, want, name in ((xd.grad.float().cpu(), xr.grad, "dx"), (gd.grad.cpu(), gr.grad, "dgamma"), (bd.grad.cpu(), br.grad, "dbeta")):
             assert (got - want).abs().max().item() <= 2.0 ** -6 * want.abs().max().item() + 2e-3, name

@@ -186,3 +186,43 @@ def test_unused_variants_bi_lfpn_and_conv_only_heads(dev):
             # the conv_only heads sample un-normalised LFPN outputs (no ReLU before them): 2304-term sums of bf16-rounded samples
             # that largely cancel, so the error is judged against a looser fraction of the (small) output scale
             _check(a.float(), r, "%s[%d]" % (name, i), 0.06 if name == "bi_lfpn" else 0.12)
+
+
+def test_unused_variant_reverse_lfpn(dev):
+    """build_reverse_lfpn (net/danet.py:382-412; stride-2 3x3 convs on the 160 / 80 / 40 maps): forward parity against
+    the oracle graph on identical weights, and gradients of a fixed upstream gradient against the oracle's (bf16-storage emulation)."""
+    from dan_amd import synthetic
+    from dan_amd.net import danet, sfd_net
+    from dan_amd.net.variables import VariableStore
+    imgs = synthetic.make_images(2, 96, 128, "cpu", seed=19)
+    x = ON.preprocess_synthetic(imgs)
+
+    def fwd(P, xx):
+        return ON.build_reverse_lfpn(P, ON.get_featmaps(P, xx), skip_last=3)
+    P = _weights(fwd, x, 43)
+    params = {n: v.clone().requires_grad_(True) for n, v in P.t.items()}
+    ref = fwd(ON.Params(params, emulate_bf16=True), x.to(torch.bfloat16).float())
+    g = torch.Generator().manual_seed(2)
+    Gs = [torch.randn(r.shape, generator=g) for r in ref[1:4]]
+    sum((r * G).sum() for r, G in zip(ref[1:4], Gs)).backward()
+    vs = VariableStore(device=dev)
+    b = danet.VGG16Backbone("channels_last", variables=vs)
+    xin = sfd_net.prepare_input(imgs.to(dev))
+    with torch.no_grad():
+        b.build_reverse_lfpn(b.get_featmaps(xin, training=False))        # creates the variables
+    vs.load_tf_named(P.t)
+    assert set(n for n, _ in vs.named()) == set(P.t.keys())
+    out = b.build_reverse_lfpn(b.get_featmaps(xin, training=True))
+    assert len(out) == len(ref) == 6 and [tuple(o.shape) for o in out] == [tuple(r.shape) for r in ref]
+    for i, (a, r) in enumerate(zip(out, ref)):
+        _check(a.float().detach(), r.detach(), "reverse_lfpn[%d]" % i, 0.04)
+    torch.autograd.backward(list(out[1:4]), [G.to(dev).to(out[1].dtype) for G in Gs])
+    bad = []
+    for n, p in vs.named():
+        want = params[n].grad
+        if want is None or want.abs().max().item() < 1e-6:
+            continue
+        rel = (p.grad.detach().cpu().reshape(-1) - want.reshape(-1)).norm().item() / (want.norm().item() + 1e-12)
+        if rel > 0.2:
+            bad.append((n, round(rel, 3)))
+    assert not bad, bad[:8]
