@@ -60,7 +60,8 @@ SIGNATURES = {
     "danhip_resize_bilinear_add_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, P],
     "danhip_resize_bilinear_add_bwd": [P, P, I32, I32, I32, I32, I32, I32, ctypes.c_int, P],
     "danhip_avgpool2x2s1_same_fwd": [P, P, I32, I32, I32, I32, P],
-    "danhip_avgpool2x2s1_same_bwd": [P, P, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_avgpool2x2s1_same_bwd": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_slice_deliver": [P, I32, I32, I32, P, I32, P, I32, ctypes.c_int, I64, P],
     "danhip_batchnorm_fwd_train": [P, P, P, P, P, P, P, P, I64, I32, FL, FL, ctypes.c_int, P, P],
     "danhip_batchnorm_fwd_infer": [P, P, P, P, P, P, I64, I32, ctypes.c_int, P],
     "danhip_batchnorm_bwd": [P, P, P, P, P, P, P, P, I64, I32, P],

@@ -304,6 +304,71 @@ extern "C" int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float*
 }
 
 namespace {
+// ------------------------------------------------------------------ concat / residual-add backward: one input's slice of dY
+// vector form: every row offset is a multiple of 8 channels -> one 16-byte lane access per 8 channels
+__global__ void slice_deliver_vec_kernel(const bf16_t* __restrict__ dy, int ldy, int c0, int C, const bf16_t* __restrict__ mask, bf16_t* __restrict__ out,
+                                         int accumulate, long M) {
+  const int cg = C / 8;
+  const long total = M * cg;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / cg;
+    const int g = (int)(idx - m * cg);
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + m * ldy + c0 + g * 8), f);
+    if (mask) {
+      float k[8];
+      unpack8(*reinterpret_cast<const uint4*>(mask + idx * 8), k);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (!(k[i] > 0.f)) f[i] = 0.f;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + idx * 8);
+    if (accumulate) {
+      float old[8];
+      unpack8(*dst, old);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] += old[i];
+    }
+    *dst = pack8(f);
+  }
+}
+// ragged form (C or c0 not a multiple of 8): one element per lane
+__global__ void slice_deliver_elem_kernel(const bf16_t* __restrict__ dy, int ldy, int c0, int C, const bf16_t* __restrict__ mask, int ldm,
+                                          bf16_t* __restrict__ out, int Cpad, int accumulate, long M) {
+  const long total = M * Cpad;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / Cpad;
+    const int c = (int)(idx - m * Cpad);
+    float v = 0.f;
+    if (c < C) {
+      v = bf2f(dy[m * ldy + c0 + c]);
+      if (mask && !(bf2f(mask[m * ldm + c]) > 0.f)) v = 0.f;
+    }
+    if (accumulate) v += bf2f(out[idx]);
+    out[idx] = f2bf(v);
+  }
+}
+}  // namespace
+
+extern "C" int danhip_slice_deliver(const uint16_t* dy, int32_t ldy, int32_t c0, int32_t C, const uint16_t* mask, int32_t ldm, uint16_t* out,
+                                    int32_t Cpad, int accumulate, int64_t M, void* stream) {
+  DH_REQUIRE(dy && out && M > 0, DANHIP_EINVAL, "slice_deliver: bad arguments");
+  DH_REQUIRE(C > 0 && c0 >= 0 && c0 + C <= ldy && Cpad >= C && Cpad % 8 == 0 && Cpad - C < 8, DANHIP_EINVAL,
+             "slice_deliver: slice [%d, %d) of %d channels into rows of %d", c0, c0 + C, ldy, Cpad);
+  DH_REQUIRE(!mask || ldm >= C, DANHIP_EINVAL, "slice_deliver: mask rows of %d < %d channels", ldm, C);
+  const bool vec = C % 8 == 0 && c0 % 8 == 0 && ldy % 8 == 0 && (!mask || ldm == C);
+  const long total = vec ? M * (C / 8) : M * Cpad;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (vec)
+    hipLaunchKernelGGL(slice_deliver_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, c0, C, mask, out, accumulate, (long)M);
+  else
+    hipLaunchKernelGGL(slice_deliver_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, ldy, c0, C, mask, ldm, out, Cpad,
+                       accumulate, (long)M);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+namespace {
 __global__ void zero_fill_kernel(uint4* __restrict__ p16, long n16, unsigned* __restrict__ tail, int ntail) {
   const uint4 z = make_uint4(0, 0, 0, 0);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p16[i] = z;

@@ -137,7 +137,8 @@ __global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
   }
 }
 
-__global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H, int W, int C, int accumulate) {
+__global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xmask, bf16_t* __restrict__ dx, int N, int H, int W,
+                                   int C, int accumulate) {
   const int cg = C / 8;
   const long total = (long)N * H * W * cg;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -162,6 +163,12 @@ __global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __rest
         }
       }
     uint4* dst = reinterpret_cast<uint4*>(dx + idx * 8);
+    if (xmask) {                                          // x is a ReLU output: fold its backward in (x > 0)
+      float m[8];
+      unpack8(*reinterpret_cast<const uint4*>(xmask + idx * 8), m);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) s[i] = 0.f;
+    }
     if (accumulate) {
       float old[8];
       unpack8(*dst, old);
@@ -315,11 +322,11 @@ extern "C" int danhip_avgpool2x2s1_same_fwd(const uint16_t* x, uint16_t* y, int3
   return DANHIP_OK;
 }
 
-extern "C" int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C, int accumulate,
-                                            void* stream) {
+extern "C" int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, const uint16_t* x_mask, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            int accumulate, void* stream) {
   DH_REQUIRE(dy && dx, DANHIP_EINVAL, "avgpool2x2s1_same_bwd: null pointer");
   DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "avgpool2x2s1_same_bwd: bad dims (C %% 8 == 0)");
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, accumulate);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, x_mask, dx, N, H, W, C, accumulate);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

@@ -40,17 +40,19 @@ class VGG16Backbone(pb_net.VGG16Backbone):
                 down = feature_layers[ind]
             down = self.conv2d(down, down_channels, (3, 3), 2, sc + "/downsample_conv", relu=False)
             lateral = self.conv2d(feature_layers[ind + 1], down_channels, (1, 1), 1, sc + "/lateral", relu=False)
-            down = lateral + down
+            down = ops.add(lateral, down)
             outs.append(self.conv2d(down, 256, (3, 3), 1, sc + "/fused_conv", relu=False))
         return [feature_layers[0]] + outs + list(feature_layers[skip_last + 1:])
 
     def _cr(self, inputs, filters, ksize, name):
         return self.conv2d(inputs, filters, ksize, 1, name, relu=True)
 
-    def _residual(self, y, x):
-        """relu(conv) + x: fused into the conv epilogue when no gradient is tracked, a bf16 add otherwise (the fused form
-        would need the pre-residual ReLU mask in backward)."""
-        return y + x
+    def _residual_conv(self, hyper, filters, name, x):
+        """relu(conv1x1(hyper)) + x (net/danet.py:913-918): fused into the conv epilogue when no gradient is tracked; otherwise a
+        separate add whose backward hands dY to both producers (the fused form would need the pre-residual ReLU mask in backward)."""
+        if not torch.is_grad_enabled():
+            return self.conv2d(hyper, filters, (1, 1), 1, name, relu=True, residual=x)
+        return ops.add(self._cr(hyper, filters, (1, 1), name), x)
 
     def se_inception_block(self, inputs, name=None):
         """DAN context module V1 — net/danet.py:842-918."""
@@ -64,8 +66,8 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         b4 = self._cr(b4, 64, (3, 3), name + "/branch4_conv_3x3")
         b4a = self._cr(b4, 32, (3, 1), name + "/branch4_conv_1x3")       # (sic) the reference swaps these two names
         b4b = self._cr(b4, 32, (1, 3), name + "/branch4_conv_3x1")
-        hyper = torch.cat([b1, b2, b3a, b3b, b4a, b4b], dim=-1)
-        return self._residual(self._cr(hyper, c, (1, 1), name + "/residual_conv"), inputs)
+        hyper = ops.concat([b1, b2, b3a, b3b, b4a, b4b])
+        return self._residual_conv(hyper, c, name + "/residual_conv", inputs)
 
     def get_features_stage1(self, feature_layers, name=None):
         """net/danet.py:920-929."""
@@ -81,7 +83,7 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             c = f.shape[-1]
             s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))      # (sic)
             rs = self._cr(f, c - c // 3, (1, 1), "{}/residual_conv_1x1_{}".format(name, i))
-            outs.append(self.se_inception_block(torch.cat([s1, rs], dim=-1), "{}/predict_stage2_{}".format(name, i)))
+            outs.append(self.se_inception_block(ops.concat([s1, rs]), "{}/predict_stage2_{}".format(name, i)))
         return outs
 
     def get_predict_module(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name=None):

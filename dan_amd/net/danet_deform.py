@@ -3,6 +3,7 @@
 + residual)."""
 import torch
 
+from .. import ops
 from ..utility import custom_op
 from . import danet
 
@@ -14,7 +15,7 @@ class VGG16Backbone(danet.VGG16Backbone):
         d = self._cr(inputs, 256, (1, 1), name + "/conv_1x1_down")
         y = custom_op.deform_conv_2d(d, 256, 3, 3, stride=1, dilate_rate=1, deformable_group=4, data_format="channels_last", no_bias=False,
                                      name=name + "/deform_conv", variables=self.vs, relu=True)
-        return self._residual(self._cr(y, c, (1, 1), name + "/conv_1x1_up"), inputs)
+        return self._residual_conv(y, c, name + "/conv_1x1_up", inputs)
 
     def _deform_relu(self, feat, name):
         return custom_op.deform_conv_2d(feat, feat.shape[-1], 3, 3, stride=1, dilate_rate=1, deformable_group=4, data_format="channels_last",
@@ -34,5 +35,5 @@ class VGG16Backbone(danet.VGG16Backbone):
             c = f.shape[-1]
             s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))            # (sic)
             rs = self._cr(f, c - c // 3, (1, 1), "{}/residual_conv_1x1_{}".format(name, i))
-            outs.append(self._deform_relu(torch.cat([s1, rs], dim=-1), "{}/predict_stage2_conv{}".format(name, i)))
+            outs.append(self._deform_relu(ops.concat([s1, rs]), "{}/predict_stage2_conv{}".format(name, i)))
         return outs

@@ -39,7 +39,7 @@ class VGG16Backbone(sfd_net.VGG16Backbone):
             branch2_1 = block(branch2, nc, 8, "cpm/branch{}_2_1".format(ind))
             branch2_2_1 = block(branch2, nc, 8, "cpm/branch{}_2_2_1".format(ind))
             branch2_2_2 = block(branch2_2_1, nc, 8, "cpm/branch{}_2_2_2".format(ind))
-            output_layers.append(torch.cat([branch1, branch2_1, branch2_2_2], dim=-1))
+            output_layers.append(ops.concat([branch1, branch2_1, branch2_2_2]))
         return output_layers
 
     def get_predict_module(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name=None):

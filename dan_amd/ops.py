@@ -215,8 +215,10 @@ class GradSlot(object):
 
     __slots__ = ("shape", "dtype", "device", "is_relu", "buf", "count")
 
-    def __init__(self, t, is_relu):
+    def __init__(self, t, is_relu, channels=None):
         self.shape, self.dtype, self.device, self.is_relu = t.shape, t.dtype, t.device, is_relu
+        if channels is not None:                         # ragged Cout: the buffer carries the channel-padded gradient layout
+            self.shape = tuple(t.shape[:-1]) + (channels,)
         self.buf, self.count = None, 0
 
     def target(self):
@@ -413,8 +415,13 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
         blk = (1 if _sink_trainable(w) else 0) | (2 if (b is not None and _sink_trainable(b)) else 0)
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out, padding == "valid", blk)
     if yslot is not None:
-        yslot.__init__(y, relu)
-        y._dh_slot = yslot
+        cout = w.shape[-1]
+        if cout % 8 == 0:
+            yslot.__init__(y, relu)
+            y._dh_slot = yslot
+        else:                                            # only ops.concat knows the padded layout (a ragged tensor feeds no conv directly)
+            yslot.__init__(y, relu, (cout + 7) // 8 * 8)
+            y._dh_pslot = yslot
     if pool_out:
         y._dh_pooled = pool_out[0]
     return y
@@ -691,19 +698,33 @@ class _AvgPool2x2S1(torch.autograd.Function):
     """tf.layers.average_pooling2d((2,2), 1, 'same') — net/danet.py:854."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, xslot, yslot):
         N, H, W, C = x.shape
         y = torch.empty_like(x)
         call("danhip_avgpool2x2s1_same_fwd", ptr(x), ptr(y), N, H, W, C, stream())
         ctx.dims = (N, H, W, C)
+        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x if (xslot is not None and xslot.is_relu) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         N, H, W, C = ctx.dims
-        dx = torch.empty((N, H, W, C), dtype=ACT, device=dy.device)
-        call("danhip_avgpool2x2s1_same_bwd", ptr(dy.contiguous()), ptr(dx), N, H, W, C, 0, stream())
-        return dx
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return None, None, None
+        xs = ctx.xslot
+        if xs is not None:                               # deliver into the producer's slot (+ its ReLU backward)
+            (x,) = ctx.saved_tensors
+            buf, acc = xs.target()
+            call("danhip_avgpool2x2s1_same_bwd", ptr(g), ptr(x), ptr(buf), N, H, W, C, acc, stream())
+            return None, None, None
+        dx = torch.empty((N, H, W, C), dtype=ACT, device=g.device)
+        call("danhip_avgpool2x2s1_same_bwd", ptr(g), None, ptr(dx), N, H, W, C, 0, stream())
+        return dx, None, None
 
 
 def avg_pool_2x2_s1(x):
@@ -713,7 +734,110 @@ def avg_pool_2x2_s1(x):
         call("danhip_avgpool2x2s1_same_fwd_f32", ptr(x.contiguous()), ptr(y), N, H, W, C, stream())
         return y
     assert x.dtype == ACT and x.is_contiguous() and x.shape[-1] % 8 == 0
-    return _AvgPool2x2S1.apply(x)
+    track = torch.is_grad_enabled() and x.requires_grad
+    yslot = _new_slot(track)
+    y = _AvgPool2x2S1.apply(x, _slot_of(x) if track else None, yslot)
+    if yslot is not None:
+        yslot.__init__(y, False)
+        y._dh_slot = yslot
+    return y
+
+
+class _Concat(torch.autograd.Function):
+    """tf.concat(values, axis=-1) (net/danet.py:911, :951; net/pb_net.py:306).  Backward hands each input its slice of dY directly
+    (one pass: slice + the input's ReLU backward + accumulate), instead of autograd's strided views + .contiguous() + clone + mask."""
+
+    @staticmethod
+    def forward(ctx, slots, yslot, all_relu, *xs):
+        y = torch.cat(xs, dim=-1)
+        ctx.slots, ctx.yslot, ctx.all_relu = slots, yslot, all_relu
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*[x if (s is not None and s.is_relu) else None for x, s in zip(xs, slots)])
+        ctx.widths = [x.shape[-1] for x in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        premasked = ctx.all_relu and dy is None          # slot deliveries arrive multiplied by (y > 0) = every input's own mask
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return (None,) * (3 + len(ctx.widths))
+        grads, c0 = [], 0
+        for i, (C, s, x) in enumerate(zip(ctx.widths, ctx.slots, ctx.saved_tensors)):
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+            elif s is None:
+                grads.append(g[..., c0:c0 + C])
+            else:
+                buf, acc = s.target()
+                call("danhip_slice_deliver", ptr(g), g.shape[-1], c0, C, ptr(x) if (s.is_relu and not premasked) else None, C, ptr(buf),
+                     buf.shape[-1], acc, g.numel() // g.shape[-1], stream())
+                grads.append(None)
+            c0 += C
+        return (None, None, None) + tuple(grads)
+
+
+def concat(tensors):
+    """Channel concatenation of NHWC activations."""
+    tensors = list(tensors)
+    track = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+    if tensors[0].dtype != ACT or not track or not USE_SLOTS:
+        return torch.cat(tensors, dim=-1)
+    slots = [(getattr(t, "_dh_slot", None) or getattr(t, "_dh_pslot", None)) if t.requires_grad else None for t in tensors]
+    all_relu = all(s is not None and s.is_relu for s in slots)
+    yslot = _new_slot(True)
+    y = _Concat.apply(slots, yslot, all_relu, *tensors)
+    yslot.__init__(y, all_relu)
+    if y.shape[-1] % 8 == 0:
+        y._dh_slot = yslot
+    else:
+        y._dh_pslot = yslot
+    return y
+
+
+class _Add(torch.autograd.Function):
+    """a + b of two activations (the context module's residual, net/danet.py:913-918): backward delivers dY into both producers' slots,
+    each with its own ReLU backward folded in."""
+
+    @staticmethod
+    def forward(ctx, a, b, sa, sb, yslot):
+        ctx.slots, ctx.yslot = (sa, sb), yslot
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*[t if (s is not None and s.is_relu) else None for t, s in ((a, sa), (b, sb))])
+        return a + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return (None,) * 5
+        out = []
+        for i, (s, t) in enumerate(zip(ctx.slots, ctx.saved_tensors)):
+            if not ctx.needs_input_grad[i]:
+                out.append(None)
+            elif s is None:
+                out.append(g)
+            else:
+                buf, acc = s.target()
+                C = g.shape[-1]
+                call("danhip_slice_deliver", ptr(g), C, 0, C, ptr(t) if s.is_relu else None, C, ptr(buf), C, acc, g.numel() // C, stream())
+                out.append(None)
+        return out[0], out[1], None, None, None
+
+
+def add(a, b):
+    track = torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)
+    if a.dtype != ACT or not track or not USE_SLOTS or a.shape != b.shape or a.shape[-1] % 8:
+        return a + b
+    yslot = _new_slot(True)
+    y = _Add.apply(a, b, _slot_of(a) if a.requires_grad else None, _slot_of(b) if b.requires_grad else None, yslot)
+    yslot.__init__(y, False)
+    y._dh_slot = yslot
+    return y
 
 
 class _BatchNorm(torch.autograd.Function):

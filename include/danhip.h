@@ -140,8 +140,14 @@ int danhip_resize_bilinear_add_bwd(const uint16_t* dout, uint16_t* dup, int32_t 
                                    int32_t C, int accumulate, void* stream);
 /* tf.layers.average_pooling2d((2,2), 1, 'same') — net/danet.py:854: pad (0,1), divisor = number of valid taps. */
 int danhip_avgpool2x2s1_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
-int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C, int accumulate,
-                                 void* stream);
+/* x_mask (may be NULL): the pooled tensor when it is a ReLU output — dx is then multiplied by (x > 0). */
+int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, const uint16_t* x_mask, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 int accumulate, void* stream);
+/* Backward of tf.concat(axis=-1) / of a residual add (net/danet.py:911-918), one input at a time:
+ *   out[m][c] (+)= (mask == NULL || mask[m*ldm + c] > 0) ? dy[m*ldy + c0 + c] : 0      for c < C,   out[m][c] = 0 for C <= c < Cpad (first write)
+ * out rows have Cpad (>= C, multiple of 8) elements: the channel-padded gradient layout danhip_conv2d_bwd_* take for a ragged Cout. */
+int danhip_slice_deliver(const uint16_t* dy, int32_t ldy, int32_t c0, int32_t C, const uint16_t* mask, int32_t ldm, uint16_t* out, int32_t Cpad,
+                         int accumulate, int64_t M, void* stream);
 /* tf.layers.batch_normalization over the channel axis of [M,C] (M = N*H*W) — the conv_bn_relu / bn_relu / conv_bn surface of
  * net/sfd_net.py:91-119 (momentum 0.997, eps 1e-5).  Training: batch statistics (biased variance), optional moving-average
  * update, optional fused ReLU; workspace = 2*C floats.  Inference: caller passes mean and rstd = rsqrt(var + eps).
