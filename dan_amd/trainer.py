@@ -155,6 +155,42 @@ class GradBuckets(object):
         # with what the gradient buffer holds then — any difference is a gradient written AFTER its bucket had been reduced
         self.check = os.environ.get("DANHIP_DP_CHECK") == "1"
         self.snapshots = []
+        # Two alternatives to the plain fp32 all-reduce, both device collectives only (RCCL), selected by environment:
+        #   DANHIP_DP_COMM=rs_ag         reduce-scatter + all-gather of each bucket (the two halves of a ring all-reduce as separate
+        #                                calls: the form a sharded optimizer would split between gradient and parameter traffic)
+        #   DANHIP_DP_BUCKET_DTYPE=bf16  buckets travel as bf16 (half the xGMI bytes; each rank's gradient rounded once before the sum)
+        self.comm = os.environ.get("DANHIP_DP_COMM", "allreduce")
+        self.wire_bf16 = os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32") == "bf16"
+        if self.comm not in ("allreduce", "rs_ag"):
+            raise ValueError("DANHIP_DP_COMM must be allreduce or rs_ag")
+        self.stage = None
+        if self.enabled and (self.comm != "allreduce" or self.wire_bf16):
+            if not self.device_collectives or self.fake:
+                raise RuntimeError("DANHIP_DP_COMM / DANHIP_DP_BUCKET_DTYPE need device collectives (the RCCL backend)")
+            w = dist.get_world_size()
+            longest = max(-(-(e - s) // w) * w for s, e in self.bounds)
+            self.stage = [torch.zeros(longest, dtype=torch.bfloat16 if self.wire_bf16 else torch.float32, device=flat.g.device)
+                          for _ in self.bounds]      # one staging buffer per bucket: several reductions are in flight at once
+
+    def _reduce(self, b, s, e):
+        """Sum flat.g[s:e] over the ranks on the current (communication) stream; -> work handle or None."""
+        g = self.flat.g[s:e]
+        if self.stage is None:
+            return dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+        w, r = dist.get_world_size(), dist.get_rank()
+        n = e - s
+        padded = -(-n // w) * w
+        st = self.stage[b][:padded]
+        st[:n].copy_(g)                                 # (casts when the wire type is bf16; the padding tail stays zero)
+        if self.comm == "rs_ag":
+            per = padded // w
+            shard = st[r * per:(r + 1) * per]
+            dist.reduce_scatter_tensor(shard, st, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(st, shard)
+        else:
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        g.copy_(st[:n])
+        return None
 
     def begin_step(self):
         self.next_bucket = 0
@@ -198,10 +234,11 @@ class GradBuckets(object):
                     if self.fake:
                         self.flat.g[s:e].mul_(1.0)
                     else:
-                        wk = dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True)
-                        self.pending.append(wk)
-                        if self.check:
-                            wk.wait()                # (orders the snapshot behind the collective on this stream; host-blocking for gloo)
+                        wk = self._reduce(self.next_bucket, s, e)
+                        if wk is not None:
+                            self.pending.append(wk)
+                            if self.check:
+                                wk.wait()            # (orders the snapshot behind the collective on this stream; host-blocking for gloo)
                     if self.check:
                         self.snapshots.append((s, e, self.flat.g[s:e].clone()))
             else:                                    # gloo / CPU tensors (unit tests)
