@@ -34,6 +34,7 @@ struct HaloGeom {
   int NB;                   // output-channel blocks (Co / BN)
   int cch;                  // 64-channel chunks of the input (C / 64)
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
+  int crem;                 // C % 64 != 0: 16-byte pieces of the LAST input chunk that exist ((C % 64) / 8); 0 = whole chunks only
   FastDiv div_tx, div_txy, div_nb;
 };
 
@@ -199,7 +200,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   const __amdgpu_buffer_rsrc_t rsrc_x =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)((unsigned)a.Co * (unsigned)a.Kpad * 2u), 0x00020000);
+  // packed weight rows exist (as zeros) up to the next multiple of 64 output channels (danhip_conv_packed_dims); thin heads read past
+  // their 16 rows into the zero fill of the descriptor's range check
+  const unsigned wrows = NCU ? (unsigned)a.Co : (unsigned)((a.Co + 63) & ~63);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)(wrows * (unsigned)a.Kpad * 2u), 0x00020000);
   int p_v = blockIdx.x, p_cc = 0, p_idx = 0;       // patch cursor: next chunk to load; p_idx selects the buffer
   int p_sp, p_nb;
   bool p_ok = decode(p_v, p_sp, p_nb);
@@ -218,11 +222,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
   auto issue_patch = [&]() __attribute__((always_inline)) {   // loads chunk (p_v, p_cc) into buffer p_idx & 1, advances the cursor
     char* dst = smem + (p_idx & 1) * PBYTES;
+    // ragged C (C % 64 != 0, e.g. the data gradient of a 72-channel offsets conv): the last chunk's pieces beyond C are zero-filled,
+    // which also cancels whatever the weight tile holds in those K columns (they belong to the next tap)
+    const bool ragged_chunk = g.crem != 0 && p_cc == g.cch - 1;
 #pragma unroll
     for (int k = 0; k < PL; ++k) {
       int piece = k * 8 + wave;
       if (piece > PPIECES - 1) piece = PPIECES - 1;
-      bufdma16(rsrc_x, psrc[k], (unsigned)(p_cc * 128), dst + piece * 1024);
+      unsigned voff = psrc[k];
+      if (ragged_chunk && ((lane & 7) ^ (pgeo[k] & 7)) >= g.crem) voff = 0xFFFFFFFFu;
+      bufdma16(rsrc_x, voff, (unsigned)(p_cc * 128), dst + piece * 1024);
     }
     ++p_idx;
     if (++p_cc == g.cch) {
@@ -379,10 +388,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       constexpr int NPAIR = NCT / 2 > 0 ? NCT / 2 : 1;
       const int cb = c_nb * BN + wn * TC + fq * 8;    // this lane's 8 consecutive channels of pair 0 (+32 per pair)
       float bv[NPAIR][8];
+      bool cok[NPAIR];                               // ragged Cout (Co % 64 != 0, Co % 8 == 0): this lane's 8 channels exist
 #pragma unroll
-      for (int q = 0; q < NPAIR; ++q)
+      for (int q = 0; q < NPAIR; ++q) {
+        cok[q] = cb + q * 32 < a.Co;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && a.bias) ? a.bias[cb + q * 32 + r] : 0.f;
+        for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && a.bias && cok[q]) ? a.bias[cb + q * 32 + r] : 0.f;
+      }
       [[maybe_unused]] u32x4 pk[POOL ? NPAIR : 1][POOL ? NPT : 1];      // POOL: packed outputs (zero where the pixel is outside)
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (ok) {
 #pragma unroll
           for (int q = 0; q < NPAIR; ++q) {
+            if (!cok[q]) continue;
             if (!DGRAD) {
               if (a.resid && !a.out_f32) in0[q] = *reinterpret_cast<const uint4*>(a.resid + o0 + q * 32);
             } else {
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
           u32x4 r = {0u, 0u, 0u, 0u};
-          if (ok) r = halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
+          if (ok && cok[q]) r = halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
           if constexpr (POOL) pk[q][p] = r;
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -567,10 +580,12 @@ bool plan_halo(const ConvArgs& a, HaloPlan* p) {
   if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dstride == 1 && a.pad_t == 1 && a.pad_l == 1)) return false;
   if (a.H != a.Ho || a.W != a.Wo) return false;
   p->head = 0;
-  if (a.C % 64 != 0 || a.C > 2048) return false;
+  if (a.C % 8 != 0 || a.C < 64 || a.C > 2048) return false;               // C % 64 != 0: the last chunk is zero-filled beyond C
   if (a.Co % 64 != 0) {
-    if (a.Co > 16 || a.mask || a.resid || a.accumulate) return false;      // thin head (forward only)
-    p->head = 1;
+    if (a.Co <= 16) {
+      if (a.mask || a.resid || a.accumulate) return false;                 // thin head (forward only)
+      p->head = 1;
+    } else if (a.Co % 8 != 0 || a.Co <= 32) return false;                  // ragged Cout: whole 8-channel groups, packed rows padded to 64
   }
   if ((int64_t)a.Co * a.Kpad >= (1ll << 31)) return false;
   auto util = [&](int th, int tw) {
@@ -580,7 +595,7 @@ bool plan_halo(const ConvArgs& a, HaloPlan* p) {
   const double u1 = util(8, 32), u2 = util(16, 16);
   if (u1 >= u2) { p->th = 8; p->tw = 32; } else { p->th = 16; p->tw = 16; }
   if ((u1 > u2 ? u1 : u2) < 0.78) return false;      // 40x40 maps (0.69): measured equal to the flat-M kernel (tile + round quantisation)
-  p->bn = p->head ? 64 : ((a.Co % 128 == 0) ? 128 : 64);
+  p->bn = p->head ? 64 : ((((a.Co + 63) & ~63) % 128 == 0) ? 128 : 64);
   return true;
 }
 
@@ -606,8 +621,9 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.tiles_x = (a.W + TW - 1) / TW;
   g.tiles_y = (a.H + TH - 1) / TH;
   g.sp_items = a.N * g.tiles_x * g.tiles_y;
-  g.NB = NCU ? 1 : a.Co / BN;
-  g.cch = a.C / 64;
+  g.NB = NCU ? 1 : (a.Co + BN - 1) / BN;
+  g.cch = (a.C + 63) / 64;
+  g.crem = (a.C % 64) / 8;
   g.div_tx = make_fastdiv(g.tiles_x);
   g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
   g.div_nb = make_fastdiv(g.NB);
@@ -658,7 +674,7 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
 
 bool danhip_conv_halo_pool_fusable(const ConvArgs& a) {
   HaloPlan p;
-  if (!plan_halo(a, &p) || p.head || p.bn != 128) return false;
+  if (!plan_halo(a, &p) || p.head || p.bn != 128 || a.Co % 64 != 0) return false;
   return a.bias && a.relu && !a.resid && !a.out_f32 && !a.mask && !a.accumulate;      // forward conv_relu only
 }
 

@@ -387,10 +387,13 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// output-channel tile: 128 when the 64-padded channel count is a multiple of 128 (72 -> 128: one tile, 56 zero-filled columns)
+static int wg_rows_cot(const danhip_conv_desc* d) { return ((d->Cout + 63) / 64 * 64) % 128 == 0 ? 128 : 64; }
+
 static bool wg_rows_eligible(const danhip_conv_desc* d) {
   if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W)) return false;      // 'same' 3x3 only
   const int co8 = (d->Cout + 7) / 8 * 8;
-  if (d->Cin % 64 != 0 || (co8 % 64 != 0 && co8 > 64)) return false;      // thin heads (co8 < 64) run as one zero-padded 64-wide tile
+  if (d->Cin % 64 != 0) return false;      // any Cout: channel chunks beyond Co8 are zero-filled (thin heads: one 64-wide tile; 72 -> one 128-wide tile)
   const int tw = 32;
   const double util = (double)d->W / (double)((d->W + tw - 1) / tw * tw);
   return util >= 0.6;       // 40- and 20-wide maps (0.625) still beat the per-tap kernel
@@ -398,7 +401,7 @@ static bool wg_rows_eligible(const danhip_conv_desc* d) {
 
 const char* danhip_wgrad_rows_label(const danhip_conv_desc* d) {
   if (!wg_rows_eligible(d)) return nullptr;
-  return ((d->Cout + 7) / 8 * 8) % 128 == 0 ? "conv_wgrad_rows_kernel<128>" : "conv_wgrad_rows_kernel<64>";
+  return wg_rows_cot(d) == 128 ? "conv_wgrad_rows_kernel<128>" : "conv_wgrad_rows_kernel<64>";
 }
 
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
@@ -412,5 +415,5 @@ int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const b
   a.total_rows = d->N * a.tiles_x * d->H;
   a.div_tx = make_fastdiv(a.tiles_x);
   a.div_h = make_fastdiv(d->H);
-  return co8 % 128 == 0 ? launch_wg_rows<128>(a, s) : launch_wg_rows<64>(a, s);
+  return wg_rows_cot(d) == 128 ? launch_wg_rows<128>(a, s) : launch_wg_rows<64>(a, s);
 }

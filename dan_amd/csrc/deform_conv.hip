@@ -29,45 +29,77 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return u;
 }
 
-// one thread per (output pixel m, tap t, 8-channel chunk): S[m][t*C + 8*chunk .. +8]
-__global__ void deform_sample_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, bf16_t* __restrict__ S, DeformGeom g) {
+// A 256-thread block owns SAMPLE_PXB consecutive output pixels of ONE output row: (image, row, first column) are block-uniform
+// (scalar registers) and a thread's item q -> (pixel in the block, tap, 8-channel chunk) is 32-bit arithmetic — the earlier form (one
+// flat 64-bit index per thread, five 64-bit divisions each) spent more instructions on its index than on the four 16-byte gathers.
+// Items run chunk-fastest, then tap: a wave stores 1 KiB of S contiguously and its corner loads are whole 128-byte group rows.
+constexpr int SAMPLE_PXB = 8;
+__global__ __launch_bounds__(256) void deform_sample_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, bf16_t* __restrict__ S,
+                                                                DeformGeom g, int segs, int cch_shift) {
   const int taps = g.kh * g.kw, cch = g.C / 8, cpg8 = g.C / g.dg / 8;
-  const long total = (long)g.N * g.Ho * g.Wo * taps * cch;
   const int offc = g.dg * 2 * taps;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int chunk = (int)(idx % cch);
-    long r = idx / cch;
-    const int t = (int)(r % taps);
-    const long m = r / taps;
-    const int wo = (int)(m % g.Wo);
-    const int ho = (int)((m / g.Wo) % g.Ho);
-    const int n = (int)(m / ((long)g.Wo * g.Ho));
-    const int grp = chunk / cpg8;
-    const int i = t / g.kw, j = t % g.kw;
-    const int h_in = ho * g.stride - g.pad_t, w_in = wo * g.stride - g.pad_l;
-    const bf16_t* op = offs + m * offc + (grp * taps + t) * 2;
-    const float off_h = bf2f(op[0]), off_w = bf2f(op[1]);
-    const float h_im = (float)(h_in + i * g.dil) + off_h;             // deform_conv.cu:261-262
-    const float w_im = (float)(w_in + j * g.dil) + off_w;
-    float out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (h_im >= 0 && w_im >= 0 && h_im < g.H && w_im < g.W) {         // :263
+  const int seg = (int)(blockIdx.x % (unsigned)segs);
+  const int rowid = (int)(blockIdx.x / (unsigned)segs);                 // n * Ho + ho
+  const int ho = rowid % g.Ho, n = rowid / g.Ho;
+  const int wo0 = seg * SAMPLE_PXB;
+  const int npx = min(SAMPLE_PXB, g.Wo - wo0);
+  const int items = npx * taps * cch;
+  const int h_in = ho * g.stride - g.pad_t;
+  const long m0 = (long)rowid * g.Wo + wo0;
+  const bf16_t* xn = x + ((long)n * g.H * g.W) * g.C;
+  const int cur_h = g.H - h_in;
+  // Three items per trip: the three offset words are fetched first, then all twelve corner rows are in flight together — a trip
+  // costs two dependent memory latencies instead of six (the kernel is latency bound, not bandwidth bound: 16 bytes per lane and load).
+  constexpr int U = 3;
+  for (int q0 = threadIdx.x; q0 < items; q0 += 256 * U) {
+    int chunk[U], t[U], pxl[U], grp[U];
+    bool live[U];
+    unsigned oraw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int q = q0 + u * 256;
+      live[u] = q < items;
+      if (!live[u]) q = items - 1;
+      int r;
+      if (cch_shift >= 0) { chunk[u] = q & (cch - 1); r = q >> cch_shift; } else { chunk[u] = q % cch; r = q / cch; }
+      pxl[u] = r / taps; t[u] = r - pxl[u] * taps;
+      grp[u] = chunk[u] / cpg8;
+      oraw[u] = *reinterpret_cast<const unsigned*>(offs + (m0 + pxl[u]) * offc + (grp[u] * taps + t[u]) * 2);
+    }
+    uint4 c4[U][4];
+    float wq[U][4];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = t[u] / g.kw, j = t[u] - i * g.kw;
+      const int w_in = (wo0 + pxl[u]) * g.stride - g.pad_l;
+      const float off_h = bf2f((bf16_t)(oraw[u] & 0xffffu)), off_w = bf2f((bf16_t)(oraw[u] >> 16));
+      const float h_im = (float)(h_in + i * g.dil) + off_h;             // deform_conv.cu:261-262
+      const float w_im = (float)(w_in + j * g.dil) + off_w;
+      in[u] = h_im >= 0 && w_im >= 0 && h_im < g.H && w_im < g.W;       // :263
       float mh = (float)(i * g.dil) + off_h, mw = (float)(j * g.dil) + off_w;     // :264-265 (relative to (h_in, w_in))
-      const int cur_h = g.H - h_in, cur_w = g.W - w_in;               // :266-268
+      if (!in[u]) { mh = (float)(-h_in); mw = (float)(-w_in); }         // (any valid address: the result is discarded)
+      const int cur_w = g.W - w_in;                                     // :266-268
       int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;       // deformable_im2col_bilinear :94-112
       if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
       if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
       const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
-      const bf16_t* base = x + ((long)n * g.H * g.W) * g.C + chunk * 8;
-      float v1[8], v2[8], v3[8], v4[8];
-      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_low) * g.W + (w_in + w_low)) * g.C), v1);
-      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_low) * g.W + (w_in + w_high)) * g.C), v2);
-      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_high) * g.W + (w_in + w_low)) * g.C), v3);
-      unpack8(*reinterpret_cast<const uint4*>(base + ((long)(h_in + h_high) * g.W + (w_in + w_high)) * g.C), v4);
-      const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;         // :118-125
-#pragma unroll
-      for (int e = 0; e < 8; ++e) out[e] = w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e];
+      wq[u][0] = hh * hw; wq[u][1] = hh * lw; wq[u][2] = lh * hw; wq[u][3] = lh * lw;         // :118-125
+      const bf16_t* base = xn + chunk[u] * 8;
+      const int rl = (h_in + h_low) * g.W + w_in, rh = (h_in + h_high) * g.W + w_in;      // pixel indices inside image n
+      c4[u][0] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_low) * g.C);
+      c4[u][1] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_high) * g.C);
+      c4[u][2] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_low) * g.C);
+      c4[u][3] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_high) * g.C);
     }
-    *reinterpret_cast<uint4*>(S + (m * taps + t) * g.C + chunk * 8) = pack8(out);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v1[8], v2[8], v3[8], v4[8], out[8];
+      unpack8(c4[u][0], v1); unpack8(c4[u][1], v2); unpack8(c4[u][2], v3); unpack8(c4[u][3], v4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[e] = in[u] ? wq[u][0] * v1[e] + wq[u][1] * v2[e] + wq[u][2] * v3[e] + wq[u][3] * v4[e] : 0.f;
+      if (live[u]) *reinterpret_cast<uint4*>(S + ((m0 + pxl[u]) * taps + t[u]) * g.C + chunk[u] * 8) = pack8(out);
+    }
   }
 }
 
@@ -283,61 +315,75 @@ __device__ __forceinline__ float corner_weight_at(float inv_h, float inv_w, int 
   return axis_factor(inv_h, h, H) * axis_factor(inv_w, w, W);
 }
 
-// dOffset (+ the far corners' atomics into the fp32 side buffer): one wave per (output pixel, group).  The sampling geometry of the
-// nine taps is wave-uniform, and this ISA has no scalar float unit: it is therefore computed ONCE, tap t in lane t, and handed to the
-// whole wave through readlane (corner element offsets land in SGPRs, so the 45 loads use scalar base + lane addressing).
+// dOffset (+ the far corners' atomics into the fp32 side buffer): EIGHT LANES per (output pixel, group) — lane l8 owns 8 of the group's
+// 64 channels, i.e. one 16-byte piece of every row it touches, so the 45 loads of an item are 16-byte lane accesses (the earlier
+// wave-per-item form issued them as 2-byte ones: eight times the load instructions for the same bytes).  The sampling geometry is
+// recomputed by each of the 8 lanes (cheaper than handing it around); the 18 sums are reduced over the 8 lanes with a transposing
+// butterfly (14 + 6 shuffles) after which lane l8 holds the (dh, dw) pair of tap (4*b0 + 2*b1 + b2) and stores it as one 32-bit word.
 __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
                                                                    const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
                                                                    bf16_t* __restrict__ doffs, DeformGeom g) {
   const int offc = g.dg * 18;
-  const int lane = threadIdx.x & 63;
-  const long nwork = (long)g.N * g.Ho * g.Wo * g.dg;
-  const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+  const int lane = threadIdx.x & 63, l8 = lane & 7;
+  const unsigned nwork = (unsigned)g.N * g.Ho * g.Wo * g.dg;            // (< 2^31: checked by the launcher)
   const float Hf = (float)g.H, Wf = (float)g.W;
-  const int tl = lane < 9 ? lane : 0;                                   // this lane's tap during the geometry phase
-  for (long wk = wave0; wk < nwork; wk += nwaves) {
-    const int grp = (int)(wk % g.dg);
-    const long m = wk / g.dg;
-    const int wo = (int)(m % g.Wo);
-    const int ho = (int)((m / g.Wo) % g.Ho);
-    const int n = (int)(m / ((long)g.Wo * g.Ho));
+  const float lim = (float)(DEFORM_R - 1);
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  for (unsigned wbase = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8u; wbase < nwork; wbase += gridDim.x * (blockDim.x >> 6) * 8u) {
+    const unsigned item = wbase + (lane >> 3);
+    const bool live = item < nwork;
+    const unsigned wk = live ? item : nwork - 1;
+    const int grp = (int)(wk % (unsigned)g.dg);
+    const unsigned m = wk / (unsigned)g.dg;
+    const int wo = (int)(m % (unsigned)g.Wo);
+    const unsigned mr = m / (unsigned)g.Wo;
+    const int ho = (int)(mr % (unsigned)g.Ho), n = (int)(mr / (unsigned)g.Ho);
     const int h_in = ho - g.pad_t, w_in = wo - g.pad_l;
-    const bf16_t* ub = x + ((long)n * g.H * g.W) * g.C + grp * 64;      // wave-uniform bases
-    const bf16_t* ud = dS + m * 9 * g.C + grp * 64;
-    // ---- geometry, lane = tap
-    const unsigned oraw = *reinterpret_cast<const unsigned*>(offs + m * offc + grp * 18 + 2 * tl);
-    const float off_h = bf2f((bf16_t)(oraw & 0xffffu)), off_w = bf2f((bf16_t)(oraw >> 16));
-    const float inv_h = (float)(h_in + (tl / 3) * g.dil) + off_h, inv_w = (float)(w_in + (tl % 3) * g.dil) + off_w;
-    const bool in = !(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf);
-    float ih = in ? inv_h : 0.f, iw = in ? inv_w : 0.f;
-    int hl = (int)ih, wl = (int)iw, hh, wh;
-    if (hl >= g.H - 1) { hh = hl = g.H - 1; ih = (float)hl; } else hh = hl + 1;
-    if (wl >= g.W - 1) { wh = wl = g.W - 1; iw = (float)wl; } else wh = wl + 1;
-    const int o00 = (hl * g.W + wl) * g.C, o01 = (hl * g.W + wh) * g.C, o10 = (hh * g.W + wl) * g.C, o11 = (hh * g.W + wh) * g.C;
-    const float ca_w = in ? (float)(wl + 1) - iw : 0.f, cb_w = in ? iw - (float)wl : 0.f;      // get_coordinate_weight (:177-221)
-    const float ca_h = in ? (float)(hl + 1) - ih : 0.f, cb_h = in ? ih - (float)hl : 0.f;
-    // ---- all 45 loads of the nine taps in flight, lane = channel
-    bf16_t v[9][4], cgr[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      v[t][0] = (ub + __builtin_amdgcn_readlane(o00, t))[lane];
-      v[t][1] = (ub + __builtin_amdgcn_readlane(o01, t))[lane];
-      v[t][2] = (ub + __builtin_amdgcn_readlane(o10, t))[lane];
-      v[t][3] = (ub + __builtin_amdgcn_readlane(o11, t))[lane];
-      cgr[t] = (ud + t * g.C)[lane];
-    }
+    const bf16_t* ub = x + ((long)n * g.H * g.W) * g.C + grp * 64 + l8 * 8;
+    const bf16_t* ud = dS + (long)m * 9 * g.C + grp * 64 + l8 * 8;
+    const bf16_t* uo = offs + (long)m * offc + grp * 18;
     float sv[18];
+    unsigned farm = 0;                                                  // taps whose offset may reach a corner beyond +-R
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float cg = bf2f(cgr[t]);
-      const float vll = bf2f(v[t][0]), vlh = bf2f(v[t][1]), vhl = bf2f(v[t][2]), vhh = bf2f(v[t][3]);
-      const float a_w = lane_f(ca_w, t), b_w = lane_f(cb_w, t), a_h = lane_f(ca_h, t), b_h = lane_f(cb_h, t);
-      sv[2 * t] = (-1.f * a_w * vll + -1.f * b_w * vlh + a_w * vhl + b_w * vhh) * cg;
-      sv[2 * t + 1] = (-1.f * a_h * vll + a_h * vlh + -1.f * b_h * vhl + b_h * vhh) * cg;
+    for (int tb = 0; tb < 3; ++tb) {
+      uint4 v[3][4], cgr[3];
+      float ca_w[3], cb_w[3], ca_h[3], cb_h[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int t = tb * 3 + u;
+        const unsigned oraw = *reinterpret_cast<const unsigned*>(uo + 2 * t);
+        const float off_h = bf2f((bf16_t)(oraw & 0xffffu)), off_w = bf2f((bf16_t)(oraw >> 16));
+        if (off_h < -lim || off_h >= lim || off_w < -lim || off_w >= lim) farm |= 1u << t;
+        const float inv_h = (float)(h_in + tb * g.dil) + off_h, inv_w = (float)(w_in + u * g.dil) + off_w;
+        const bool in = !(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf);
+        float ih = in ? inv_h : 0.f, iw = in ? inv_w : 0.f;
+        int hl = (int)ih, wl = (int)iw, hh, wh;
+        if (hl >= g.H - 1) { hh = hl = g.H - 1; ih = (float)hl; } else hh = hl + 1;
+        if (wl >= g.W - 1) { wh = wl = g.W - 1; iw = (float)wl; } else wh = wl + 1;
+        ca_w[u] = in ? (float)(wl + 1) - iw : 0.f; cb_w[u] = in ? iw - (float)wl : 0.f;      // get_coordinate_weight (:177-221)
+        ca_h[u] = in ? (float)(hl + 1) - ih : 0.f; cb_h[u] = in ? ih - (float)hl : 0.f;
+        v[u][0] = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wl) * g.C);
+        v[u][1] = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wh) * g.C);
+        v[u][2] = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wl) * g.C);
+        v[u][3] = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wh) * g.C);
+        cgr[u] = *reinterpret_cast<const uint4*>(ud + t * g.C);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float vll[8], vlh[8], vhl[8], vhh[8], cg[8];
+        unpack8(v[u][0], vll); unpack8(v[u][1], vlh); unpack8(v[u][2], vhl); unpack8(v[u][3], vhh); unpack8(cgr[u], cg);
+        const float a_w = ca_w[u], b_w = cb_w[u], a_h = ca_h[u], b_h = cb_h[u];
+        float s_h = 0.f, s_w = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s_h += (-1.f * a_w * vll[e] + -1.f * b_w * vlh[e] + a_w * vhl[e] + b_w * vhh[e]) * cg[e];
+          s_w += (-1.f * a_h * vll[e] + a_h * vlh[e] + -1.f * b_h * vhl[e] + b_h * vhh[e]) * cg[e];
+        }
+        sv[2 * (tb * 3 + u)] = s_h;
+        sv[2 * (tb * 3 + u) + 1] = s_w;
+      }
     }
-    // 16 of the 18 sums: transposing butterfly — after the step with partner distance d a lane keeps the half its bit selects
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    // 16 of the 18 sums: after the step with partner distance d a lane keeps the half its bit selects
     float r8[8], r4[4], r2[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) r8[j] = (b0 ? sv[j + 8] : sv[j]) + __shfl_xor(b0 ? sv[j] : sv[j + 8], 1, 64);
@@ -345,40 +391,38 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
     for (int j = 0; j < 4; ++j) r4[j] = (b1 ? r8[j + 4] : r8[j]) + __shfl_xor(b1 ? r8[j] : r8[j + 4], 2, 64);
 #pragma unroll
     for (int j = 0; j < 2; ++j) r2[j] = (b2 ? r4[j + 2] : r4[j]) + __shfl_xor(b2 ? r4[j] : r4[j + 2], 4, 64);
-    float r1 = (b3 ? r2[1] : r2[0]) + __shfl_xor(b3 ? r2[0] : r2[1], 8, 64);
-    r1 += __shfl_xor(r1, 16, 64);
-    r1 += __shfl_xor(r1, 32, 64);
     float e0 = sv[16], e1 = sv[17];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); }
-    bf16_t* dp = doffs + m * offc + grp * 18;
-    if (lane < 16) dp[(b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0) + (b3 ? 1 : 0)] = f2bf(r1);
-    if (lane == 16) dp[16] = f2bf(e0);
-    if (lane == 17) dp[17] = f2bf(e1);
+    for (int o = 1; o < 8; o <<= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); }
+    if (live) {
+      bf16_t* dp = doffs + (long)m * offc + grp * 18;                   // (an even element index: 32-bit aligned pairs)
+      *reinterpret_cast<unsigned*>(dp + (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0)) = pack2bf(r2[0], r2[1]);
+      if (l8 == 0) *reinterpret_cast<unsigned*>(dp + 16) = pack2bf(e0, e1);
+    }
     // ---- far corners: not reachable by the gather kernel's +-R enumeration.  A corner sits floor(o) or floor(o)+1 from the nominal
     // position (one less under the high-edge clamp), so offsets in [-(R-1), R-1) cannot produce one: skip the whole search then
-    const float lim = (float)(DEFORM_R - 1);
-    if (!__any(lane < 9 && (off_h < -lim || off_h >= lim || off_w < -lim || off_w >= lim))) continue;
-    // ... otherwise the exact test, still tap t in lane t, and only the taps that own a far corner are replayed by the whole wave
-    bool mine = false;
-    {
-      const int nh = h_in + (tl / 3) * g.dil, nw = w_in + (tl % 3) * g.dil;
-      const CornerSet cs = corner_set(inv_h, inv_w, g.H, g.W);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) mine = mine || (cs.ok[k] && (abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R));
-    }
-    unsigned long long todo = __ballot(mine && lane < 9);
-    const int c = grp * 64 + lane;
-    while (todo) {
-      const int t = __builtin_ctzll(todo);
-      todo &= todo - 1;
+    if (!__any(live && farm != 0)) continue;
+    if (!live) farm = 0;
+    while (farm) {                                                      // (uniform inside an 8-lane item; rare)
+      const int t = __builtin_ctz(farm);
+      farm &= farm - 1;
+      const unsigned oraw = *reinterpret_cast<const unsigned*>(uo + 2 * t);
       const int nh = h_in + (t / 3) * g.dil, nw = w_in + (t % 3) * g.dil;
-      const CornerSet cs = corner_set(lane_f(inv_h, t), lane_f(inv_w, t), g.H, g.W);
-      const float cg = bf2f((ud + t * g.C)[lane]);
+      const CornerSet cs = corner_set((float)nh + bf2f((bf16_t)(oraw & 0xffffu)), (float)nw + bf2f((bf16_t)(oraw >> 16)), g.H, g.W);
+      bool any_far = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) any_far = any_far || (cs.ok[k] && (abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R));
+      if (!any_far) continue;
+      float cg[8];
+      unpack8(*reinterpret_cast<const uint4*>(ud + t * g.C), cg);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool far = abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R;
-        if (cs.ok[k] && far) atomicAdd(far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + c, cs.wg[k] * cg);
+        if (cs.ok[k] && far) {
+          float* dst = far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + grp * 64 + l8 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) atomicAdd(dst + e, cs.wg[k] * cg[e]);
+        }
       }
     }
   }
@@ -499,8 +543,12 @@ extern "C" int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offse
   DeformGeom g;
   int rc = make_geom(&g, N, H, W, C, kh, kw, stride, dilation, deformable_group, "deform_sample_fwd");
   if (rc) return rc;
-  const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
-  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, offsets, S, g);
+  const int segs = (g.Wo + SAMPLE_PXB - 1) / SAMPLE_PXB, cch = C / 8;
+  const long blocks = (long)N * g.Ho * segs;
+  DH_REQUIRE(blocks < (1l << 31), DANHIP_EINVAL, "deform_sample_fwd: %ld output row segments", blocks);
+  int shift = -1;
+  if ((cch & (cch - 1)) == 0) { shift = 0; while ((1 << shift) < cch) ++shift; }
+  hipLaunchKernelGGL(deform_sample_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, offsets, S, g, segs, shift);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -517,9 +565,9 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
   { const int zrc = danhip_zero_async(workspace, sizeof(float) * nx, s); if (zrc) return zrc; }
-  if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31)) {
+  if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9) {
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
-    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 31) / 32 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
     hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, dim3(grid_for((ng + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, offsets, dS, workspace, dx, g,
                        accumulate);
     DH_LAUNCH_CHECK();

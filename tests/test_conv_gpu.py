@@ -31,6 +31,10 @@ SHAPES = [
     # windows on maps too small for the halo tiles, stride 2, 3x1 / 1x3, ragged pixel counts: the streaming kernel's tap-gather form
     (4, 40, 40, 256, 512, 3, 3, 1), (8, 20, 20, 512, 1024, 3, 3, 1), (2, 40, 44, 128, 64, 3, 1, 1), (2, 40, 44, 64, 128, 1, 3, 1),
     (6, 40, 40, 256, 256, 3, 3, 2), (3, 37, 41, 192, 320, 3, 3, 1), (7, 19, 23, 64, 64, 3, 3, 1),
+    # channel counts that are multiples of 8 but not of 64 on the halo / row-streaming kernels (the deformable block's 256 -> 72 offsets
+    # conv, net/danet_deform.py:267-290): ragged Cout (zero weight rows, guarded stores), ragged Cin (zero-filled last chunk), both
+    (2, 32, 64, 256, 72, 3, 3, 1), (1, 24, 32, 128, 40, 3, 3, 1), (2, 16, 32, 72, 128, 3, 3, 1), (1, 32, 32, 136, 200, 3, 3, 1),
+    (9, 40, 64, 64, 72, 3, 3, 1),
 ]
 
 
@@ -232,6 +236,19 @@ def test_pointwise_data_gradient_ragged_channels(accumulate, dev):
 # The 12 distinct 3x3 shapes of the VGG-16 backbone at BASELINE.json's 640x640 (SURVEY §7 "minimum slice", Appendix B) plus conv1_1 and
 # the two heavy pointwise shapes, at N = 1 and FULL spatial size, against the CPU oracle convolution (oneDNN fp32 on bf16-rounded
 # operands): forward with bias + ReLU, data gradient, weight gradient, bias gradient.
+def test_ragged_channel_counts_run_on_the_halo_and_row_streaming_kernels(dev):
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import lib
+    d = ops._desc(2, 32, 64, 256, 72, 3, 3, 1)
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 1).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
+    assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_rows_kernel<128>"
+    d = ops._desc(1, 24, 32, 128, 40, 3, 3, 1)
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv3x3_halo_kernel<8, 32, 64")
+    assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_rows_kernel<64>"
+
+
 FULL_SHAPES = [
     ("conv1_1", 640, 8, 64, 3, 1), ("conv1_2", 640, 64, 64, 3, 1), ("conv2_1", 320, 64, 128, 3, 1), ("conv2_2", 320, 128, 128, 3, 1),
     ("conv3_1", 160, 128, 256, 3, 1), ("conv3_2", 160, 256, 256, 3, 1), ("conv4_1", 80, 256, 512, 3, 1), ("conv4_2", 80, 512, 512, 3, 1),
