@@ -155,7 +155,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   static_assert(2 * PBYTES + NSW * WBYTES <= 160 * 1024, "LDS budget");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WRING = 2 * PBYTES;                // LDS map: [patch 0][patch 1][weight ring: NSW stages]
+  constexpr int WRING = 2 * PBYTES;                // LDS map: [patch 0][patch 1][weight ring: NSW stages][bias: Co floats (forward)]
+  constexpr int SBIAS = WRING + NSW * WBYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,6 +356,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (w_ok) issue_w();
+  // The bias vector lives in LDS for the whole launch: an epilogue that read it from global memory had to wait on vmcnt, i.e. behind
+  // every weight / patch DMA already queued for the NEXT steps — one drained prefetch queue per item (measured: forward 13 % slower than
+  // the same loop with a store-only epilogue).
+  if constexpr (!DGRAD && NCU == 0) {
+    float* sb = reinterpret_cast<float*>(smem + SBIAS);
+    for (int i = tid; i < a.Co; i += 512) sb[i] = a.bias ? a.bias[i] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -393,26 +402,52 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int q = 0; q < NPAIR; ++q) {
         cok[q] = cb + q * 32 < a.Co;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && a.bias && cok[q]) ? a.bias[cb + q * 32 + r] : 0.f;
+        for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && cok[q]) ? reinterpret_cast<const float*>(smem + SBIAS)[cb + q * 32 + r] : 0.f;
       }
       [[maybe_unused]] u32x4 pk[POOL ? NPAIR : 1][POOL ? NPT : 1];      // POOL: packed outputs (zero where the pixel is outside)
+      if constexpr (DGRAD) {
+        // Data gradient: the ReLU mask / the value to accumulate into are read-modify inputs from HBM.  ALL of them are issued before the
+        // first one is consumed — one exposed memory latency per item instead of one per pixel fragment (the forward epilogue only stores).
+        uint4 in0[NPT][NPAIR], in1[NPT][NPAIR];
+        bool okp[NPT];
+        size_t o0p[NPT];
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const int t = wm * TP + p * 16 + frow;
+          const int y = y0 + t / TW, x = x0 + t % TW;
+          okp[p] = y < a.H && x < a.W;
+          o0p[p] = (size_t)((n * a.H + y) * a.W + x) * a.Co + cb;
+          if (okp[p]) {
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+              if (!cok[q]) continue;
+              if (a.mask) in0[p][q] = *reinterpret_cast<const uint4*>(a.mask + o0p[p] + q * 32);
+              if (a.accumulate) in1[p][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.y) + o0p[p] + q * 32);
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q) {
+            if (okp[p] && cok[q]) halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[p][q], in1[p][q], o0p[p] + q * 32);
+            acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      } else {
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * TP + p * 16 + frow;
         const int y = y0 + t / TW, x = x0 + t % TW;
         const bool ok = y < a.H && x < a.W;
         const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + cb;
-        uint4 in0[NPAIR], in1[NPAIR];              // every read-modify input is issued before the first store
+        uint4 in0[NPAIR], in1[NPAIR];              // the residual is read before the first store
         if (ok) {
 #pragma unroll
           for (int q = 0; q < NPAIR; ++q) {
             if (!cok[q]) continue;
-            if (!DGRAD) {
-              if (a.resid && !a.out_f32) in0[q] = *reinterpret_cast<const uint4*>(a.resid + o0 + q * 32);
-            } else {
-              if (a.mask) in0[q] = *reinterpret_cast<const uint4*>(a.mask + o0 + q * 32);
-              if (a.accumulate) in1[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.y) + o0 + q * 32);
-            }
+            if (a.resid && !a.out_f32) in0[q] = *reinterpret_cast<const uint4*>(a.resid + o0 + q * 32);
           }
         }
 #pragma unroll
@@ -423,6 +458,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      }
       }
       if constexpr (POOL) {
         // 2x2 / stride-2 SAME max-pool of this wave's rows (tf.layers.max_pooling2d after the block, net/sfd_net.py:132-143) from
@@ -480,6 +516,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int STEP = decltype(stepc)::value;
         // ---- mem phase: fragment reads first (their LDS latency runs under the epilogue / DMA issue below)
         const int wbase = offW + stage_of(STEP) * WBYTES;
+        if constexpr (DGRAD) {                       // its HBM reads first: the fragment registers are not live across them
+          if (pending) { epilogue(); pending = false; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         load_frags(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
         if (pending) { epilogue(); pending = false; }
@@ -539,9 +579,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int NSTEP = (STEP + 1) % SPC;
         const int nstage = TPS == 3 ? NSTEP : (chunk + STEP + 1) & (NSW - 1);
         const int npofs = STEP == SPC - 1 ? (PBYTES - pofs) : pofs;
+        bool ep_done = false;
+        if constexpr (DGRAD) {
+          if (STEP == SPC - 1 && cc + 1 == g.cch) {
+            epilogue();
+            if (!c_ok) last = true;
+            ep_done = true;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
         load_frags(offW + nstage * WBYTES, npofs, std::integral_constant<int, NSTEP>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (STEP == SPC - 1 && cc + 1 == g.cch) {  // the item ended with this step
+        if (!ep_done && STEP == SPC - 1 && cc + 1 == g.cch) {  // the item ended with this step
           epilogue();
           if (!c_ok) last = true;
         }
@@ -587,7 +636,7 @@ bool plan_halo(const ConvArgs& a, HaloPlan* p) {
       p->head = 1;
     } else if (a.Co % 8 != 0 || a.Co <= 32) return false;                  // ragged Cout: whole 8-channel groups, packed rows padded to 64
   }
-  if ((int64_t)a.Co * a.Kpad >= (1ll << 31)) return false;
+  if ((int64_t)a.Co * a.Kpad >= (1ll << 31) || a.Co > 2048) return false;          // (the forward keeps Co bias floats in 8 KiB of LDS)
   auto util = [&](int th, int tw) {
     const double ph = (double)((a.H + th - 1) / th * th), pw = (double)((a.W + tw - 1) / tw * tw);
     return (double)a.H * a.W / (ph * pw);
@@ -612,7 +661,8 @@ int cu_count() {
 template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, int NCU = 0, bool POOL = false>
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
-  constexpr int LDS = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
+  constexpr int LDS0 = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
+  constexpr int LDS = LDS0 + ((!DGRAD && NCU == 0) ? 8192 : 0);     // + the bias vector (Co <= 2048 floats)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU, POOL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;

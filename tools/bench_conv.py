@@ -62,10 +62,16 @@ def run(shape, iters, which, check):
     def dgrad():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 0, stream())
 
+    def dgrad_nomask():
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
+
+    def dgrad_acc():
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 1, stream())
+
     def wgrad():
         call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, stream())
 
-    fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}
+    fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad, "dgrad_nomask": dgrad_nomask, "dgrad_acc": dgrad_acc}
     out = []
     for wname in which:
         fn = fns[wname]
@@ -81,7 +87,7 @@ def run(shape, iters, which, check):
         ms = e0.elapsed_time(e1) / iters
         label = ""
         if wname != "wgrad":
-            label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else 5).decode()   # dgrad() passes a ReLU mask
+            label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else (1 if wname == "dgrad_nomask" else 5)).decode()
         out.append((wname, ms, flops / ms / 1e9, label))
     errs = {}
     if check:
