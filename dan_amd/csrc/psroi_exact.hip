@@ -1,9 +1,10 @@
 // Deformable position-sensitive ROI pooling (cpp/Deform/deform_psroi_pooling_op.cc:37-97 op defs, deform_psroi_pooling_op_gpu.cu:47-125
 // forward, :187-300 backward; Python names utility/custom_op.py:93-126) — SURVEY §8f row 4.  Same tensors and attributes as the TF op:
 // data fp32 NCHW [B,C,H,W], rois fp32 [R,5] (batch index, x1, y1, x2, y2), trans fp32 [R, 2*num_classes, part, part];
-// top_data / mapping_channel (= sample count) fp32 [R, output_dim, pooled, pooled].  Arithmetic follows the reference statement by
-// statement (float data, the double-typed literals it mixes in, C round()); compiled with -ffp-contract=off so the forward pass is
-// bit-exact against oracle/deform.py.  The backward pass scatters with fp32 atomics exactly as the reference does.
+// top_data / mapping_channel (= sample count) fp32 [R, output_dim, pooled, pooled].  The per-sample arithmetic (psroi_bin, psroi_sample,
+// the bilinear term) follows the reference expression by expression (float data, the double-typed literals it mixes in, C round());
+// compiled with -ffp-contract=off so the forward pass is bit-exact against oracle/deform.py.  The work decomposition is this file's own
+// (see above the kernels): wave per (roi, bin, class) with channels in the lanes, atomic-free deterministic shift gradient.
 #include "common.h"
 
 namespace {
@@ -64,66 +65,112 @@ __device__ __forceinline__ bool psroi_sample(const PsroiArgs& a, const PsroiBin&
   return true;
 }
 
-__global__ void psroi_fwd_kernel(const float* __restrict__ data, const float* __restrict__ rois, const float* __restrict__ trans, PsroiArgs a,
-                                 float* __restrict__ top, float* __restrict__ top_count) {
-  const long count = (long)a.R * a.output_dim * a.pooled * a.pooled;
-  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < count; index += (long)gridDim.x * blockDim.x) {
-    const int pw = (int)(index % a.pooled), ph = (int)((index / a.pooled) % a.pooled);
-    const int ctop = (int)((index / a.pooled / a.pooled) % a.output_dim), n = (int)(index / a.pooled / a.pooled / a.output_dim);
-    const PsroiBin b = psroi_bin(a, rois, trans, n, ctop, ph, pw, false);
+// ---- work decomposition (MI355X): the geometry of a bin — ROI corners, bin size, the learned shift of its part cell, its group cell —
+// depends on (roi, bin, class) only, while the op's channels map onto planes that nothing else shares (c = (ctop*G + gh)*G + gw).  So:
+//   forward : ONE WAVE per (roi, bin, class); the lanes are the class's output channels.  The geometry is wave-uniform, the sample loop has
+//             no divergence, and a lane adds its samples in the reference's (ih, iw) order — the pooled value stays bit-exact.
+//   backward: ONE WAVE per (roi, class, part cell); it walks the bins that share the cell's shift, lanes = channels again.  The shift
+//             gradient of the cell is then a per-lane sum followed by one wave reduction and ONE plain store: no atomics and no zero-fill
+//             for trans_diff, and the same bits on every run (the reference issues two atomics per sample and channel).  data_diff keeps
+//             the atomics — ROIs overlap arbitrarily — as in the reference.
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void psroi_fwd_kernel(const float* __restrict__ data, const float* __restrict__ rois, const float* __restrict__ trans,
+                                                        PsroiArgs a, float* __restrict__ top, float* __restrict__ top_count) {
+  const int lane = threadIdx.x & 63;
+  const int cec = a.output_dim / a.num_classes;
+  const long units = (long)a.R * a.pooled * a.pooled * a.num_classes;
+  for (long u = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * (blockDim.x >> 6)) {
+    const int cls = (int)(u % a.num_classes);
+    long r = u / a.num_classes;
+    const int pw = (int)(r % a.pooled);
+    r /= a.pooled;
+    const int ph = (int)(r % a.pooled), n = (int)(r / a.pooled);
+    const PsroiBin b = psroi_bin(a, rois, trans, n, cls * cec, ph, pw, false);
     const float* base = data + (long)b.roi_batch_ind * a.C * a.H * a.W;
-    float sum = 0.f;
-    int cnt = 0;
-    for (int ih = 0; ih < a.sample_per_part; ++ih)
-      for (int iw = 0; iw < a.sample_per_part; ++iw) {
-        float w, h;
-        if (!psroi_sample(a, b, ih, iw, w, h)) continue;
-        const int c = (ctop * a.group_size + b.gh) * a.group_size + b.gw;
-        const float* d = base + (long)c * a.H * a.W;
-        const int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
-        const float dx = w - (float)x1, dy = h - (float)y1;
-        const float v11 = d[y1 * a.W + x1], v12 = d[y2 * a.W + x1], v21 = d[y1 * a.W + x2], v22 = d[y2 * a.W + x2];
-        const float val = (1 - dx) * (1 - dy) * v11 + (1 - dx) * dy * v12 + dx * (1 - dy) * v21 + dx * dy * v22;      // :42-43
-        sum += val;
-        ++cnt;
-      }
-    top[index] = cnt == 0 ? 0.f : sum / (float)cnt;
-    top_count[index] = (float)cnt;
+    for (int k = lane; k < cec; k += 64) {
+      const int ctop = cls * cec + k;
+      const float* d = base + (long)((ctop * a.group_size + b.gh) * a.group_size + b.gw) * a.H * a.W;
+      float sum = 0.f;
+      int cnt = 0;
+      for (int ih = 0; ih < a.sample_per_part; ++ih)
+        for (int iw = 0; iw < a.sample_per_part; ++iw) {
+          float w, h;
+          if (!psroi_sample(a, b, ih, iw, w, h)) continue;              // (wave-uniform)
+          const int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+          const float dx = w - (float)x1, dy = h - (float)y1;
+          const float v11 = d[y1 * a.W + x1], v12 = d[y2 * a.W + x1], v21 = d[y1 * a.W + x2], v22 = d[y2 * a.W + x2];
+          sum += (1 - dx) * (1 - dy) * v11 + (1 - dx) * dy * v12 + dx * (1 - dy) * v21 + dx * dy * v22;      // :42-43
+          ++cnt;
+        }
+      const long index = (((long)n * a.output_dim + ctop) * a.pooled + ph) * a.pooled + pw;
+      top[index] = cnt == 0 ? 0.f : sum / (float)cnt;
+      top_count[index] = (float)cnt;
+    }
   }
 }
 
-__global__ void psroi_bwd_kernel(const float* __restrict__ top_diff, const float* __restrict__ top_count, const float* __restrict__ data,
-                                 const float* __restrict__ rois, const float* __restrict__ trans, PsroiArgs a, float* __restrict__ data_diff,
-                                 float* __restrict__ trans_diff) {
-  const long count = (long)a.R * a.output_dim * a.pooled * a.pooled;
-  for (long index = (long)blockIdx.x * blockDim.x + threadIdx.x; index < count; index += (long)gridDim.x * blockDim.x) {
-    const int pw = (int)(index % a.pooled), ph = (int)((index / a.pooled) % a.pooled);
-    const int ctop = (int)((index / a.pooled / a.pooled) % a.output_dim), n = (int)(index / a.pooled / a.pooled / a.output_dim);
-    if (top_count[index] <= 0) continue;
-    const PsroiBin b = psroi_bin(a, rois, trans, n, ctop, ph, pw, true);
-    const float diff_val = top_diff[index] / top_count[index];
-    const long boff = (long)b.roi_batch_ind * a.C * a.H * a.W;
-    for (int ih = 0; ih < a.sample_per_part; ++ih)
-      for (int iw = 0; iw < a.sample_per_part; ++iw) {
-        float w, h;
-        if (!psroi_sample(a, b, ih, iw, w, h)) continue;
-        const int c = (ctop * a.group_size + b.gh) * a.group_size + b.gw;
-        const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
-        const float dx = w - (float)x0, dy = h - (float)y0;
-        const long cb = boff + (long)c * a.H * a.W;
-        atomicAdd(data_diff + cb + y0 * a.W + x0, (1 - dx) * (1 - dy) * diff_val);
-        atomicAdd(data_diff + cb + y1 * a.W + x0, (1 - dx) * dy * diff_val);
-        atomicAdd(data_diff + cb + y0 * a.W + x1, dx * (1 - dy) * diff_val);
-        atomicAdd(data_diff + cb + y1 * a.W + x1, dx * dy * diff_val);
-        if (a.no_trans) continue;
-        const float U00 = data[cb + y0 * a.W + x0], U01 = data[cb + y1 * a.W + x0], U10 = data[cb + y0 * a.W + x1], U11 = data[cb + y1 * a.W + x1];
-        float gx = (U11 * dy + U10 * (1 - dy) - U01 * dy - U00 * (1 - dy)) * a.trans_std * diff_val;
-        gx *= b.roi_width;
-        float gy = (U11 * dx + U01 * (1 - dx) - U10 * dx - U00 * (1 - dx)) * a.trans_std * diff_val;
-        gy *= b.roi_height;
-        atomicAdd(trans_diff + (((n * a.num_classes + b.class_id) * 2) * a.part_size + b.part_h) * a.part_size + b.part_w, gx);
-        atomicAdd(trans_diff + (((n * a.num_classes + b.class_id) * 2 + 1) * a.part_size + b.part_h) * a.part_size + b.part_w, gy);
+__global__ __launch_bounds__(256) void psroi_bwd_kernel(const float* __restrict__ top_diff, const float* __restrict__ top_count,
+                                                        const float* __restrict__ data, const float* __restrict__ rois, const float* __restrict__ trans,
+                                                        PsroiArgs a, float* __restrict__ data_diff, float* __restrict__ trans_diff) {
+  const int lane = threadIdx.x & 63;
+  const int cec = a.output_dim / a.num_classes;
+  const int cells = a.no_trans ? a.pooled : a.part_size;                // cell grid: the part cells, or the bins themselves without shifts
+  const long units = (long)a.R * a.num_classes * cells * cells;
+  for (long u = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < units; u += (long)gridDim.x * (blockDim.x >> 6)) {
+    const int cw = (int)(u % cells);
+    long r = u / cells;
+    const int chh = (int)(r % cells);
+    r /= cells;
+    const int cls = (int)(r % a.num_classes), n = (int)(r / a.num_classes);
+    float gx_sum = 0.f, gy_sum = 0.f;
+    for (int ph = 0; ph < a.pooled; ++ph) {
+      const int cell_h = a.no_trans ? ph : (int)floorf((float)ph / (float)a.pooled * (float)a.part_size);
+      if (cell_h != chh) continue;
+      for (int pw = 0; pw < a.pooled; ++pw) {
+        const int cell_w = a.no_trans ? pw : (int)floorf((float)pw / (float)a.pooled * (float)a.part_size);
+        if (cell_w != cw) continue;
+        const PsroiBin b = psroi_bin(a, rois, trans, n, cls * cec, ph, pw, true);
+        const long boff = (long)b.roi_batch_ind * a.C * a.H * a.W;
+        for (int k = lane; k < cec; k += 64) {
+          const int ctop = cls * cec + k;
+          const long index = (((long)n * a.output_dim + ctop) * a.pooled + ph) * a.pooled + pw;
+          if (top_count[index] <= 0) continue;
+          const float diff_val = top_diff[index] / top_count[index];
+          const long cb = boff + (long)((ctop * a.group_size + b.gh) * a.group_size + b.gw) * a.H * a.W;
+          for (int ih = 0; ih < a.sample_per_part; ++ih)
+            for (int iw = 0; iw < a.sample_per_part; ++iw) {
+              float w, h;
+              if (!psroi_sample(a, b, ih, iw, w, h)) continue;
+              const int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+              const float dx = w - (float)x0, dy = h - (float)y0;
+              atomicAdd(data_diff + cb + y0 * a.W + x0, (1 - dx) * (1 - dy) * diff_val);
+              atomicAdd(data_diff + cb + y1 * a.W + x0, (1 - dx) * dy * diff_val);
+              atomicAdd(data_diff + cb + y0 * a.W + x1, dx * (1 - dy) * diff_val);
+              atomicAdd(data_diff + cb + y1 * a.W + x1, dx * dy * diff_val);
+              if (a.no_trans) continue;
+              const float U00 = data[cb + y0 * a.W + x0], U01 = data[cb + y1 * a.W + x0], U10 = data[cb + y0 * a.W + x1], U11 = data[cb + y1 * a.W + x1];
+              float gx = (U11 * dy + U10 * (1 - dy) - U01 * dy - U00 * (1 - dy)) * a.trans_std * diff_val;
+              gx *= b.roi_width;
+              float gy = (U11 * dx + U01 * (1 - dx) - U10 * dx - U00 * (1 - dx)) * a.trans_std * diff_val;
+              gy *= b.roi_height;
+              gx_sum += gx;
+              gy_sum += gy;
+            }
+        }
       }
+    }
+    if (a.no_trans) continue;
+    gx_sum = wave_sum64(gx_sum);
+    gy_sum = wave_sum64(gy_sum);
+    if (lane == 0) {
+      trans_diff[(((long)(n * a.num_classes + cls) * 2) * a.part_size + chh) * a.part_size + cw] = gx_sum;
+      trans_diff[(((long)(n * a.num_classes + cls) * 2 + 1) * a.part_size + chh) * a.part_size + cw] = gy_sum;
+    }
   }
 }
 
@@ -155,13 +202,13 @@ extern "C" int danhip_deform_psroi_pool_fwd(const float* data, const float* rois
   int rc = psroi_check(&a, R, C, H, W, output_dim, group_size, pooled_size, part_size, sample_per_part, spatial_scale, trans_std, no_trans, num_classes,
                        "deform_psroi_pool_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(psroi_fwd_kernel, dim3(psroi_grid((long)R * output_dim * pooled_size * pooled_size)), dim3(256), 0, (hipStream_t)stream, data,
+  hipLaunchKernelGGL(psroi_fwd_kernel, dim3(psroi_grid((long)R * pooled_size * pooled_size * num_classes * 64)), dim3(256), 0, (hipStream_t)stream, data,
                      rois, trans, a, top_data, mapping_channel);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
 
-/* data_diff fp32 [B,C,H,W] and trans_diff fp32 (trans's shape) are zeroed inside, then accumulated with fp32 atomics. */
+/* data_diff fp32 [B,C,H,W] is zeroed inside, then accumulated with fp32 atomics; trans_diff fp32 (trans's shape) is written once per cell. */
 extern "C" int danhip_deform_psroi_pool_bwd(const float* top_diff, const float* mapping_channel, const float* data, const float* rois,
                                             const float* trans, float* data_diff, float* trans_diff, int32_t B, int32_t R, int32_t C, int32_t H,
                                             int32_t W, int32_t output_dim, int32_t group_size, int32_t pooled_size, int32_t part_size,
@@ -176,11 +223,9 @@ extern "C" int danhip_deform_psroi_pool_bwd(const float* top_diff, const float* 
   hipStream_t s = (hipStream_t)stream;
   rc = danhip_zero_async(data_diff, sizeof(float) * (size_t)B * C * H * W, s);
   if (rc) return rc;
-  if (!no_trans) {
-    rc = danhip_zero_async(trans_diff, sizeof(float) * (size_t)R * 2 * num_classes * part_size * part_size, s);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(psroi_bwd_kernel, dim3(psroi_grid((long)R * output_dim * pooled_size * pooled_size)), dim3(256), 0, s, top_diff, mapping_channel,
+  const int cells = no_trans ? pooled_size : part_size;                 // (every trans_diff cell is written exactly once: no zero-fill)
+  DH_REQUIRE(cells > 0, DANHIP_EINVAL, "deform_psroi_pool_bwd: part_size must be positive when shifts are learned");
+  hipLaunchKernelGGL(psroi_bwd_kernel, dim3(psroi_grid((long)R * num_classes * cells * cells * 64)), dim3(256), 0, s, top_diff, mapping_channel,
                      data, rois, trans, a, data_diff, trans_diff);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;

@@ -27,7 +27,9 @@ def _case(seed, B, H, W, output_dim, G, P, part, spp, ncls, no_trans, scale, tra
 
 
 @pytest.mark.parametrize("cfg", [(0, 2, 12, 15, 4, 3, 3, 3, 2, 2, False, 0.25, 0.1), (1, 1, 9, 9, 2, 2, 4, 2, 3, 1, False, 0.5, 0.2),
-                                 (2, 2, 10, 8, 3, 1, 2, 2, 1, 3, False, 1.0, 0.05), (3, 1, 7, 11, 2, 3, 3, 3, 2, 1, True, 0.125, 0.0)])
+                                 (2, 2, 10, 8, 3, 1, 2, 2, 1, 3, False, 1.0, 0.05), (3, 1, 7, 11, 2, 3, 3, 3, 2, 1, True, 0.125, 0.0),
+                                 # more channels per class than lanes in a wave; fewer part cells than bins (several bins share one shift)
+                                 (4, 1, 8, 8, 70, 1, 2, 2, 2, 1, False, 0.5, 0.1), (5, 2, 14, 14, 6, 2, 6, 3, 2, 2, False, 0.25, 0.3)])
 def test_deform_psroi_pool_forward_backward(cfg, dev):
     from dan_amd.utility import custom_op
     data, rois, trans, at = _case(*cfg)
@@ -48,6 +50,26 @@ def test_deform_psroi_pool_forward_backward(cfg, dev):
         assert t.grad is None
     else:
         assert np.allclose(t.grad.cpu().numpy(), dt_ref, rtol=1e-4, atol=1e-5 * max(np.abs(dt_ref).max(), 1e-3))
+
+
+def test_shift_gradient_is_written_once_per_cell_without_atomics(dev):
+    """The kernel owns one wave per (roi, class, part cell): the shift gradient is a plain store of a fixed-order sum — identical bits on
+    every run, and no dependence on what the output buffer held before (it is not zero-filled)."""
+    from dan_amd._lib import call, ptr, stream
+    data, rois, trans, at = _case(5, 2, 14, 14, 6, 2, 6, 3, 2, 2, False, 0.25, 0.3)
+    _, cnt_ref = OD.deform_psroi_pool_forward(data, rois, trans, **at)
+    g = np.random.RandomState(3).randn(*cnt_ref.shape).astype(np.float32)
+    d, r, t = (torch.from_numpy(a).to(dev) for a in (data, rois, trans))
+    outs = []
+    for fill in (0.0, 123.0, float("nan")):
+        dd = torch.empty_like(d)
+        dt = torch.full_like(t, fill)
+        call("danhip_deform_psroi_pool_bwd", ptr(torch.from_numpy(g).to(dev)), ptr(torch.from_numpy(cnt_ref).to(dev)), ptr(d), ptr(r), ptr(t), ptr(dd),
+             ptr(dt), 2, r.shape[0], d.shape[1], 14, 14, 6, 2, 6, 3, 2, 0.25, 0.3, 0, 2, stream())
+        torch.cuda.synchronize()
+        outs.append(dt.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert outs[0].abs().max().item() > 0
 
 
 def test_deform_psroi_pool_argument_checks(dev):
