@@ -78,6 +78,33 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   };
 
+  // ---- epilogue inputs through LDS.  A global load in the epilogue is a full memory latency with nothing to hide it (both waves of a
+  // SIMD are in the same epilogue).  Forward: the 64 bias floats are staged once.  Data gradient: the ReLU mask and the value to accumulate
+  // into are DMA'd at the START of the tile into a region private to the wave that consumes them — 64 pixels x its 32 channels = 4 KiB,
+  // lane l of DMA k fetches the 16 bytes that lane (frow = l >> 2, fq = l & 3) of fragment k reads back — land under the tile's 144 MFMAs
+  // and are covered by the tile-end vmcnt(0).  No other wave touches the region: no barrier, no double buffer.
+  constexpr int RWBASE = 2 * PBYTES;               // LDS map: [patch 0][patch 1][forward: bias | dgrad: 8 x 4 KiB mask, 8 x 4 KiB old]
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_m =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.mask ? a.mask : a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_o =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.y), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+  auto issue_rw = [&](int sp) __attribute__((always_inline)) {
+    int n, y0, x0;
+    sp_coords(sp, n, y0, x0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int t = wm * 64 + k * 16 + (ln >> 2);
+      const int y = y0 + t / TW, x = x0 + t % TW;
+      const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * 128u + (unsigned)((wn * 4 + (ln & 3)) << 4) : 0xFFFFFFFFu;
+      if (a.mask) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (LDS_AS void*)(smem + RWBASE + wave * 4096 + k * 1024), 16, off, 0, 0, 0);
+      if (a.accumulate)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_o, (LDS_AS void*)(smem + RWBASE + 32768 + wave * 4096 + k * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  const int rwaddr = RWBASE + wave * 4096 + ((frow * 4 + fq) << 4);     // + p * 1024 (+ 32768: old value)
+
   int pxaddr[3][NPT];                              // fragment p at tap column j, k-slice 0, in the CURRENT buffer (flipped per tile)
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
@@ -110,12 +137,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int sp = blockIdx.x;
   if (sp >= g.sp_items) return;
   issue_patch(sp, 0);
+  if constexpr (!DGRAD) {
+    if (tid < 64) reinterpret_cast<float*>(smem + RWBASE)[tid] = a.bias ? a.bias[tid] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   c64_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   int buf = 0;
   for (;;) {
     const int nsp = sp + G;
     const bool has_next = nsp < g.sp_items;
+    if constexpr (DGRAD) issue_rw(sp);             // this tile's mask / old value (its own reads of the region ended with its last epilogue)
     if (has_next) issue_patch(nsp, buf ^ 1);       // the other buffer was released by the barrier that ended the previous tile
     // ---- 18 half-taps (tap, k-slice); pixel fragments software-pipelined TWO half-taps ahead through three rotating
     //      register sets (a ds_read_b128 under load takes longer than the 8 MFMAs of one half-tap)
@@ -147,11 +179,39 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int cbase = wn * 32 + fq * 8;                     // this lane's 8 consecutive output channels
       float bv[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) bv[r] = (!DGRAD && a.bias) ? a.bias[cbase + r] : 0.f;
+      for (int r = 0; r < 8; ++r) bv[r] = DGRAD ? 0.f : reinterpret_cast<const float*>(smem + RWBASE)[cbase + r];
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
       u32x4 pk[NPT];                                         // packed outputs of this lane (zero outside the image), for the fused pool
 #pragma unroll
       for (int p = 0; p < NPT; ++p) pk[p] = u32x4{0u, 0u, 0u, 0u};
+      // Data gradient: the staged mask, then the staged old value, are folded into the accumulators for ALL fragments before the first
+      // store — the compiler orders an LDS read behind everything vmcnt counts (it cannot tell a DMA from a store), so a read issued
+      // after a store would wait out a full write latency.  Two passes keep the live set at one 16-byte vector per fragment.
+      if constexpr (DGRAD) {
+        if (a.mask) {
+          uint4 m[NPT];
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) m[p] = *reinterpret_cast<const uint4*>(smem + rwaddr + p * 1024);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const bf16_t* mp = reinterpret_cast<const bf16_t*>(&m[p]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (!(bf2f(mp[r]) > 0.f)) acc[r >> 2][p][r & 3] = 0.f;
+          }
+        }
+        if (a.accumulate) {
+          uint4 o[NPT];
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) o[p] = *reinterpret_cast<const uint4*>(smem + rwaddr + 32768 + p * 1024);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const bf16_t* op = reinterpret_cast<const bf16_t*>(&o[p]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r >> 2][p][r & 3] += bf2f(op[r]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int t = wm * 64 + p * 16 + frow;
@@ -174,18 +234,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               for (int r = 0; r < 8; ++r) v[r] += bf2f(rp[r]);
             }
           } else {
-            if (a.mask) {
-              const uint4 in = *reinterpret_cast<const uint4*>(a.mask + o0);
-              const bf16_t* mp = reinterpret_cast<const bf16_t*>(&in);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
-            }
-            if (a.accumulate) {
-              const uint4 in = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.y) + o0);
-              const bf16_t* op = reinterpret_cast<const bf16_t*>(&in);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) v[r] += bf2f(op[r]);
-            }
+            // (mask and old value were folded into acc above)
           }
           const u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
           __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
@@ -243,7 +292,7 @@ bool c64_eligible(const ConvArgs& a) {
 
 template <bool DGRAD>
 int launch_c64(const ConvArgs& a, hipStream_t s) {
-  constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024;
+  constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024 + (DGRAD ? 65536 : 256);      // patches + (mask, old) tiles | bias
   static const bool attr_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
