@@ -135,6 +135,8 @@ def lib():
         L.danhip_augment_workspace_bytes.argtypes = []
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
+        L.danhip_deform_conv_fused.restype = ctypes.c_int
+        L.danhip_deform_conv_fused.argtypes = [I32] * 9
         L.danhip_bbox_vote_workspace_bytes.argtypes = [I32, I32]
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the export is missing

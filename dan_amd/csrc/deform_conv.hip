@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void deform_sample_fwd_kernel(const bf16_t* __
       float v1[8], v2[8], v3[8], v4[8], out[8];
       unpack8(c4[u][0], v1); unpack8(c4[u][1], v2); unpack8(c4[u][2], v3); unpack8(c4[u][3], v4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) out[e] = in[u] ? wq[u][0] * v1[e] + wq[u][1] * v2[e] + wq[u][2] * v3[e] + wq[u][3] * v4[e] : 0.f;
+      for (int e = 0; e < 8; ++e)       // (explicit fma chain: the fused kernel of deform_fused.hip must round the same way)
+        out[e] = in[u] ? fmaf(wq[u][3], v4[e], fmaf(wq[u][2], v3[e], fmaf(wq[u][1], v2[e], wq[u][0] * v1[e]))) : 0.f;
       if (live[u]) *reinterpret_cast<uint4*>(S + ((m0 + pxl[u]) * taps + t[u]) * g.C + chunk[u] * 8) = pack8(out);
     }
   }
@@ -607,11 +608,33 @@ static int deform_gemm_desc(danhip_conv_desc* d, int32_t N, int32_t H, int32_t W
   return 0;
 }
 
+bool danhip_deform_fused_eligible(int N, int H, int W, int C, int Cout, int kh, int kw, int stride, int dg);
+int danhip_launch_deform_fused_fwd(const uint16_t* x, const uint16_t* wf_packed, int kpad, const float* bias, const uint16_t* offsets, uint16_t* y,
+                                   uint16_t* col, int N, int H, int W, int C, int Cout, int stride, int dil, int dg, int relu, hipStream_t s);
+
+extern "C" int danhip_deform_conv_fused(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                        int32_t deformable_group) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || stride <= 0 || deformable_group <= 0) return 0;
+  return danhip_deform_fused_eligible(N, H, W, C, Cout, kh, kw, stride, deformable_group) ? 1 : 0;
+}
+
 extern "C" int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_packed, const float* bias, const uint16_t* offsets, uint16_t* y,
                                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
                                       int32_t dilation, int32_t deformable_group, int relu, void* workspace, size_t workspace_bytes,
                                       void* stream) {
-  DH_REQUIRE(x && wf_packed && offsets && y && workspace, DANHIP_EINVAL, "deform_conv_fwd: null pointer");
+  DH_REQUIRE(x && wf_packed && offsets && y, DANHIP_EINVAL, "deform_conv_fwd: null pointer");
+  if (danhip_deform_conv_fused(N, H, W, C, Cout, kh, kw, stride, deformable_group)) {
+    // one kernel: sampling feeds the GEMM through LDS; the column buffer is written only if the caller hands a workspace for it
+    DeformGeom g;
+    int rc = make_geom(&g, N, H, W, C, kh, kw, stride, dilation, deformable_group, "deform_conv_fwd");
+    if (rc) return rc;
+    DH_REQUIRE(!workspace || workspace_bytes >= danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0), DANHIP_EWORKSPACE,
+               "deform_conv_fwd: workspace too small for the column buffer");
+    const int kpad = (kh * kw * C + 63) / 64 * 64;
+    return danhip_launch_deform_fused_fwd(x, wf_packed, kpad, bias, offsets, y, (uint16_t*)workspace, N, H, W, C, Cout, stride, dilation,
+                                          deformable_group, relu, (hipStream_t)stream);
+  }
+  DH_REQUIRE(workspace, DANHIP_EINVAL, "deform_conv_fwd: this shape needs the column-buffer workspace");
   DH_REQUIRE(workspace_bytes >= danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0) && workspace_bytes > 0, DANHIP_EWORKSPACE,
              "deform_conv_fwd: workspace too small");
   uint16_t* col = (uint16_t*)workspace;

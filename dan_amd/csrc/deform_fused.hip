@@ -1,0 +1,281 @@
+// DeformConvOp forward as ONE kernel: the deformable im2col (cpp/Deform/deform_conv.cu:229-275 + deformable_im2col_bilinear :91-126) feeds
+// the GEMM (deform_conv.cc:505-530) through LDS instead of through a [M, kh*kw*C] column buffer in HBM — SURVEY §8 row a16.
+//
+// For the shape the context modules use (C / deformable_group == 64) a 64-channel K-step of the GEMM is exactly one (tap, deformable
+// group) pair, so every pixel of the tile has ONE sampling position per K-step:
+//   * a 512-thread workgroup owns 128 output pixels x all Cout (<= 256) channels; per K-step thread (pixel = tid / 4, quarter = tid % 4)
+//     reads the tap's offset pair, gathers 16 channels of the four bilinear corners (eight 16-byte loads, issued one K-step ahead),
+//     blends them in fp32, rounds to the 16-bit activation type — the same values the column buffer would hold — and writes them into the
+//     [128 px][64 ch] A tile in LDS (XOR-swizzled 16-byte pieces);
+//   * the weight tile [Cout][64 k] of the step arrives by LDS-DMA (inline asm, so the compiler does not drain it before the fragment
+//     reads of the CURRENT step);
+//   * eight waves (2 x 4) run v_mfma_f32_16x16x32 on 64 px x Cout/4 wave tiles, weights = A operand (a lane owns 4 consecutive output
+//     channels of one pixel), fp32 accumulators across the 9 * dg K-steps, bias / ReLU epilogue.
+// `col` (optional): the rounded samples are ALSO stored as the column buffer, for a caller that keeps it for the filter gradient
+// (dan_amd/ops.py KEEP_DEFORM_COL); inference passes NULL and the 9x activation-sized buffer never exists.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned df_u32x4;
+
+__device__ __forceinline__ void df_dma16(df_u32x4 rsrc, unsigned voff, unsigned lds_addr) {      // voff out of range: zeros land in LDS
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void df_unpack8(const uint4& u, float* f) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2bf(w[i], f[2 * i], f[2 * i + 1]);
+}
+
+struct FusedArgs {
+  const bf16_t* x;        // [N,H,W,C]
+  const bf16_t* offs;     // [N,Ho,Wo,dg*18]
+  const bf16_t* w;        // packed [Cout_pad][Kpad], k = tap*C + c
+  const float* bias;      // [Cout] or null
+  bf16_t* y;              // [N,Ho,Wo,Cout]
+  bf16_t* col;            // [N*Ho*Wo, 9*C] or null
+  int N, H, W, C, Ho, Wo, Cout, Kpad, dg, stride, dil, pad_t, pad_l, relu;
+  long M;
+};
+
+template <int BN>
+__global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a) {
+  constexpr int BM = 128, NPT = 4, NCT = BN / 64;          // wave tile 64 px x BN/4 co
+  constexpr int ABYTES = BM * 128, WBYTES = BN * 128;       // one stage each
+  constexpr int WPW = BN / 64;                              // weight DMA pieces (1 KiB = 8 rows) per wave and K-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS map: [A stage 0][A stage 1][W stage 0][W stage 1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int ksteps = 9 * a.dg;
+  const int offc = a.dg * 18;
+
+  // ---- this thread's pixel of the tile (fixed for the whole K loop)
+  const int px = tid >> 2, q4 = tid & 3;
+  const long m = (long)blockIdx.x * BM + px;
+  const bool live = m < a.M;
+  const long mm = live ? m : a.M - 1;
+  const int wo = (int)(mm % a.Wo);
+  const long mr = mm / a.Wo;
+  const int ho = (int)(mr % a.Ho), n = (int)(mr / a.Ho);
+  const int h_in = ho * a.stride - a.pad_t, w_in = wo * a.stride - a.pad_l;
+  const int cur_h = a.H - h_in, cur_w = a.W - w_in;
+  const bf16_t* xq = a.x + ((long)n * a.H * a.W) * a.C + q4 * 16;
+  const bf16_t* op = a.offs + mm * offc;
+  const unsigned a_dst = (unsigned)(px * 128);
+  const int sw0 = ((2 * q4) ^ (px & 7)) << 4, sw1 = ((2 * q4 + 1) ^ (px & 7)) << 4;
+
+  // ---- weight DMA: piece = 8 rows x 128 B; lane -> (row = piece*8 + lane/8, 16-byte chunk lane%8), chunk c of row r lands at c ^ (r & 7)
+  const df_u32x4 rsrc_w = {(unsigned)(unsigned long long)a.w, (unsigned)((unsigned long long)a.w >> 32) & 0xFFFFu,
+                           (unsigned)((a.Cout + 63) / 64 * 64) * (unsigned)a.Kpad * 2u, 0x00020000u};
+  unsigned wvoff[WPW];
+#pragma unroll
+  for (int k = 0; k < WPW; ++k) {
+    const int row = (wave * WPW + k) * 8 + (lane >> 3);
+    wvoff[k] = (unsigned)row * (unsigned)a.Kpad * 2u + (unsigned)(((lane & 7) ^ (row & 7)) << 4);
+  }
+  auto issue_w = [&](int ks, int stage) __attribute__((always_inline)) {
+    const unsigned lds = (unsigned)(2 * ABYTES + stage * WBYTES);
+#pragma unroll
+    for (int k = 0; k < WPW; ++k) df_dma16(rsrc_w, wvoff[k] + (unsigned)ks * 128u, lds + (unsigned)(wave * WPW + k) * 1024u);
+  };
+
+  // ---- gather of K-step ks: loads now, blend + LDS write later
+  struct Taps { uint4 cn[4][2]; float wq[4]; bool in; };               // the four corner rows (16 channels each), their weights
+  // the offset pair of a K-step is fetched one step before its gather (a dependent load in front of the eight corner loads would put a
+  // memory latency at the head of every K-step)
+  auto load_off = [&](int ks) __attribute__((always_inline)) -> unsigned {
+    const int t = ks / a.dg, grp = ks - t * a.dg;
+    return *reinterpret_cast<const unsigned*>(op + (grp * 9 + t) * 2);
+  };
+  unsigned oraw_next = load_off(0);
+  auto gather = [&](Taps& g, int ks) __attribute__((always_inline)) {
+    const int t = ks / a.dg, grp = ks - t * a.dg;
+    const int i = t / 3, j = t - i * 3;
+    const unsigned oraw = oraw_next;
+    oraw_next = load_off(ks + 1 < ksteps ? ks + 1 : ks);              // (always issued: the hand-counted waits below rely on 9 loads per gather)
+    const float off_h = bf2f((bf16_t)(oraw & 0xffffu)), off_w = bf2f((bf16_t)(oraw >> 16));
+    const float h_im = (float)(h_in + i * a.dil) + off_h;               // deform_conv.cu:261-262
+    const float w_im = (float)(w_in + j * a.dil) + off_w;
+    const bool in = h_im >= 0 && w_im >= 0 && h_im < a.H && w_im < a.W; // :263
+    g.in = in;
+    float mh = (float)(i * a.dil) + off_h, mw = (float)(j * a.dil) + off_w;       // :264-265 (relative to (h_in, w_in))
+    if (!in) { mh = (float)(-h_in); mw = (float)(-w_in); }              // (any valid address: the result is discarded)
+    int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;         // deformable_im2col_bilinear :94-112
+    if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
+    if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
+    const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
+    g.wq[0] = hh * hw; g.wq[1] = hh * lw; g.wq[2] = lh * hw; g.wq[3] = lh * lw;  // :118-125
+    const bf16_t* base = xq + grp * 64;
+    const int rl = (h_in + h_low) * a.W + w_in, rh = (h_in + h_high) * a.W + w_in;
+    const bf16_t* p0 = base + (long)(rl + w_low) * a.C;
+    const bf16_t* p1 = base + (long)(rl + w_high) * a.C;
+    const bf16_t* p2 = base + (long)(rh + w_low) * a.C;
+    const bf16_t* p3 = base + (long)(rh + w_high) * a.C;
+    g.cn[0][0] = *reinterpret_cast<const uint4*>(p0); g.cn[0][1] = *reinterpret_cast<const uint4*>(p0 + 8);
+    g.cn[1][0] = *reinterpret_cast<const uint4*>(p1); g.cn[1][1] = *reinterpret_cast<const uint4*>(p1 + 8);
+    g.cn[2][0] = *reinterpret_cast<const uint4*>(p2); g.cn[2][1] = *reinterpret_cast<const uint4*>(p2 + 8);
+    g.cn[3][0] = *reinterpret_cast<const uint4*>(p3); g.cn[3][1] = *reinterpret_cast<const uint4*>(p3 + 8);
+  };
+  uint4 pend[2];
+  int pend_ks = -1;
+  auto blend_store = [&](const Taps& g, int ks, int stage) __attribute__((always_inline)) {
+    uint4 outv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v1[8], v2[8], v3[8], v4[8], o[8];
+      df_unpack8(g.cn[0][h], v1); df_unpack8(g.cn[1][h], v2); df_unpack8(g.cn[2][h], v3); df_unpack8(g.cn[3][h], v4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)       // (the explicit fma chain of deform_sample_fwd_kernel: identical column values)
+        o[e] = fmaf(g.wq[3], v4[e], fmaf(g.wq[2], v3[e], fmaf(g.wq[1], v2[e], g.wq[0] * v1[e])));
+      const bool keep = g.in && live;               // a select on the packed words (a branch around the blend costs more than the blend)
+      outv[h].x = keep ? pack2bf(o[0], o[1]) : 0u; outv[h].y = keep ? pack2bf(o[2], o[3]) : 0u;
+      outv[h].z = keep ? pack2bf(o[4], o[5]) : 0u; outv[h].w = keep ? pack2bf(o[6], o[7]) : 0u;
+    }
+    char* dst = smem + stage * ABYTES + a_dst;
+    *reinterpret_cast<uint4*>(dst + sw0) = outv[0];                     // (measured: this order is the conflict-free one; swapping the two
+    *reinterpret_cast<uint4*>(dst + sw1) = outv[1];                     //  stores for odd pixel pairs costs 50 %)
+    pend[0] = outv[0]; pend[1] = outv[1]; pend_ks = ks;                 // the column-buffer copy is stored at the start of the next step
+  };
+  auto flush_col = [&]() __attribute__((always_inline)) {              // (there its stores are OLDER than the step's DMA in the wave's queue)
+    if (a.col && live && pend_ks >= 0) {
+      const int t = pend_ks / a.dg, grp = pend_ks - t * a.dg;
+      bf16_t* cp = a.col + (m * 9 + t) * a.C + grp * 64 + q4 * 16;
+      *reinterpret_cast<uint4*>(cp) = pend[0];
+      *reinterpret_cast<uint4*>(cp + 8) = pend[1];
+    }
+    pend_ks = -1;
+  };
+
+  // ---- fragment addresses: weights = A operand (row = output channel), pixels = B operand
+  int waddr[NCT], xaddr[NPT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int row = wn * (BN / 4) + c * 16 + frow;
+    waddr[c] = 2 * ABYTES + row * 128 + ((fq ^ (row & 7)) << 4);       // k-slice 1: ^ 64
+  }
+#pragma unroll
+  for (int p = 0; p < NPT; ++p) {
+    const int r = wm * 64 + p * 16 + frow;
+    xaddr[p] = r * 128 + ((fq ^ (r & 7)) << 4);
+  }
+  f32x4 acc[NCT][NPT];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: K-step 0 staged, the gather of K-step 1 in flight
+  Taps s0, s1;                                      // K-step s blends from set s & 1
+  gather(s0, 0);
+  if (ksteps > 1) gather(s1, 1);
+  issue_w(0, 0);
+  blend_store(s0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // One K-step.  The corner rows are gathered TWO steps ahead (memory latency is several K-steps of MFMA time and all eight waves of the
+  // single resident workgroup move in lockstep): queue of a wave at its wait, oldest first =
+  //   [rows(ks+1) | column-buffer stores of the previous blend | W(ks+1) | rows(ks+2)]
+  // so "W(ks+1) landed" = at most the 9 loads of rows(ks+2) outstanding.
+  auto step = [&](int ks, const Taps& nxt, Taps& refill, int st) __attribute__((always_inline)) {
+    const bool more = ks + 1 < ksteps, more2 = ks + 2 < ksteps;
+    flush_col();
+    if (more) issue_w(ks + 1, st ^ 1);
+    if (more2) gather(refill, ks + 2);
+    bf16x8 wf[2][NCT], xf[2][NPT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) wf[s2][c] = *reinterpret_cast<const bf16x8*>(smem + ((waddr[c] + st * WBYTES) ^ (s2 * 64)));
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) xf[s2][p] = *reinterpret_cast<const bf16x8*>(smem + ((xaddr[p] + st * ABYTES) ^ (s2 * 64)));
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(wf[s2][c], xf[s2][p], acc[c][p]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) blend_store(nxt, ks + 1, st ^ 1);
+    if (!more2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int ks = 0; ks < ksteps; ks += 2) {
+    step(ks, s1, s0, 0);
+    if (ks + 1 < ksteps) step(ks + 1, s0, s1, 1);
+  }
+  flush_col();
+
+  // ---- epilogue: lane owns channels co0 + c*16 + fq*4 .. +3 of pixel (wm*64 + p*16 + frow)
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) {
+    const int co = wn * (BN / 4) + c * 16 + fq * 4;
+    if (co >= a.Cout) continue;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+      const float4 t = *reinterpret_cast<const float4*>(a.bias + co);
+      b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+    }
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const long mo = (long)blockIdx.x * BM + wm * 64 + p * 16 + frow;
+      if (mo >= a.M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[c][p][r] + b4[r];
+        if (a.relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      uint2 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(a.y + mo * a.Cout + co) = o;
+    }
+  }
+}
+
+template <int BN>
+int launch_fused(const FusedArgs& a, hipStream_t s) {
+  constexpr int LDS = 2 * 128 * 128 + 2 * BN * 128;
+  static const bool attr_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fused_fwd_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)attr_ok;
+  const long tiles = (a.M + 127) / 128;
+  hipLaunchKernelGGL((deform_fused_fwd_kernel<BN>), dim3((unsigned)tiles), dim3(512), LDS, s, a);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+}  // namespace
+
+bool danhip_deform_fused_eligible(int N, int H, int W, int C, int Cout, int kh, int kw, int stride, int dg) {
+  if (!(kh == 3 && kw == 3 && dg > 0 && C % dg == 0 && C / dg == 64)) return false;
+  if (Cout % 64 != 0 || Cout > 256 || Cout == 192) return false;         // one N tile = the whole Cout (64 / 128 / 256)
+  const long Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  return (long)N * Ho * Wo * 9 * C < (1l << 40) && (long)N * H * W * C < (1l << 31);
+}
+
+// Returns DANHIP_OK when launched.  `col` may be NULL (no column buffer is written).
+int danhip_launch_deform_fused_fwd(const uint16_t* x, const uint16_t* wf_packed, int kpad, const float* bias, const uint16_t* offsets, uint16_t* y,
+                                   uint16_t* col, int N, int H, int W, int C, int Cout, int stride, int dil, int dg, int relu, hipStream_t s) {
+  FusedArgs a{};
+  a.x = x; a.offs = offsets; a.w = wf_packed; a.bias = bias; a.y = y; a.col = col;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.Cout = Cout; a.Kpad = kpad; a.dg = dg; a.stride = stride; a.dil = dil; a.relu = relu;
+  a.Ho = (H + stride - 1) / stride;
+  a.Wo = (W + stride - 1) / stride;
+  int th = (a.Ho - 1) * stride + 3 - H; if (th < 0) th = 0;            // SAME pad_before from the undilated kernel (deform_conv.cc:473-479)
+  int tw = (a.Wo - 1) * stride + 3 - W; if (tw < 0) tw = 0;
+  a.pad_t = th / 2; a.pad_l = tw / 2;
+  a.M = (long)N * a.Ho * a.Wo;
+  if (Cout == 256) return launch_fused<256>(a, s);
+  if (Cout == 128) return launch_fused<128>(a, s);
+  return launch_fused<64>(a, s);
+}

@@ -935,15 +935,19 @@ class _DeformConv(torch.autograd.Function):
         need_bwd = w.requires_grad or x.requires_grad or offsets.requires_grad
         wf, wb = pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
         y = torch.empty((N, Ho, Wo, cout), dtype=ACT, device=x.device)
-        nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0)
-        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        keep = KEEP_DEFORM_COL and need_bwd
+        if not keep and _lib.lib().danhip_deform_conv_fused(N, H, W, C, cout, kh, kw, stride, dg):
+            ws, nws = None, 0                            # the fused kernel samples straight into the GEMM's LDS tile: no column buffer
+        else:
+            nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 0)
+            ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         call("danhip_deform_conv_fwd", ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(offsets), ptr(y), N, H, W, C, cout, kh, kw,
-             stride, dilation, dg, int(relu), ptr(ws), nws, stream())
+             stride, dilation, dg, int(relu), ptr(ws) if ws is not None else None, nws, stream())
         ctx.cfg = (kh, kw, stride, dilation, dg, cout, relu)
         ctx.b_param, ctx.yslot, ctx.has_bias = b_param, yslot, b is not None
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, offsets, wb, y if relu else None)
-        ctx.col = ws if (KEEP_DEFORM_COL and need_bwd) else None
+        ctx.col = ws if keep else None
         return y
 
     @staticmethod

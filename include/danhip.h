@@ -276,6 +276,11 @@ int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const u
  *   dy     : bf16 [N,Ho,Wo,Cout] gradient w.r.t. the op's output (after the caller's ReLU backward if relu was fused), Cout % 8 == 0.
  *   dx = | += (accumulate_dx) bf16 [N,H,W,C]; d_offsets bf16 like offsets (overwritten). */
 size_t danhip_deform_conv_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int backward);
+/* 1 when danhip_deform_conv_fwd runs this shape as ONE kernel (csrc/deform_fused.hip: 3x3 taps, C / deformable_group == 64, Cout in
+ * {64, 128, 256}) — sampling feeds the GEMM through LDS.  The forward then takes workspace = NULL (no column buffer exists at all:
+ * inference), or a workspace of danhip_deform_conv_workspace_bytes(.., 0) into which the kernel ALSO writes the column buffer for a caller
+ * that keeps it for danhip_deform_conv_bwd_with_col.  Other shapes: sampling kernel + GEMM, workspace required. */
+int danhip_deform_conv_fused(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride, int32_t deformable_group);
 int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_packed, const float* bias, const uint16_t* offsets, uint16_t* y,
                            int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
                            int32_t dilation, int32_t deformable_group, int relu, void* workspace, size_t workspace_bytes, void* stream);

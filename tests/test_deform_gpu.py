@@ -46,6 +46,40 @@ def test_deform_conv_forward_backward(seed, N, H, W, C, Cout, dg, off_scale, dev
         assert err <= 2.0 ** -5 * scale + 2e-3, (name, err, scale)      # dS (bf16) feeds both gradients: 3 roundings
 
 
+@pytest.mark.parametrize("seed,N,H,W,C,Cout,dg,off_scale", [(11, 1, 6, 10, 256, 256, 4, 0.7), (12, 3, 19, 23, 128, 128, 2, 2.5), (13, 2, 16, 16, 64, 64, 1, 6.0),
+                                                            (14, 1, 40, 40, 256, 256, 4, 1.0), (15, 1, 5, 5, 256, 128, 4, 0.3)])
+def test_fused_sampling_gemm_kernel(seed, N, H, W, C, Cout, dg, off_scale, dev):
+    """csrc/deform_fused.hip (row a16: the deformable im2col feeds the GEMM through LDS): with gradients off no column buffer exists; its
+    output equals the training forward (same kernel, column buffer also written) bit for bit and meets the oracle; the column buffer
+    the training forward leaves behind equals the stand-alone sampling kernel's."""
+    from dan_amd import ops
+    from dan_amd._lib import lib
+    x, w, off = _case(seed, N, H, W, C, Cout, dg, off_scale)
+    assert lib().danhip_deform_conv_fused(N, H, W, C, Cout, 3, 3, 1, dg) == 1
+    g = torch.Generator().manual_seed(seed)
+    b = torch.randn(Cout, generator=g)
+    ref = OD.deform_conv_forward(x.float().permute(0, 3, 1, 2), w, off.float().permute(0, 3, 1, 2), 1, 1, dg).permute(0, 2, 3, 1) + b
+    w1 = w.permute(2, 3, 1, 0).reshape(1, 1, 9 * C, Cout).contiguous().to(dev)
+    xd, od, bd = x.to(dev), off.to(dev), b.to(dev)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        y0 = ops.deform_conv(xd, w1, bd, od, 3, 3, deformable_group=dg, relu=False)
+    torch.cuda.synchronize()
+    if 9 * x.numel() * 2 > (4 << 20):                                   # (the packed filter, 1.2 MB, dwarfs the tiny cases' buffers)
+        assert torch.cuda.max_memory_allocated() - base < 9 * x.numel() * 2, "inference allocated something as large as the column buffer"
+    assert (y0.float().cpu() - ref).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item() + 1e-3
+    y1 = ops.deform_conv(xd.clone().requires_grad_(True), w1.clone().requires_grad_(True), bd, od, 3, 3, deformable_group=dg, relu=False)
+    assert torch.equal(y0, y1.detach())
+    col = y1.grad_fn.col
+    assert col is not None
+    S = ops.deform_sample(xd, od, 3, 3, deformable_group=dg)
+    assert torch.equal(col[: S.numel() * 2].view(torch.bfloat16).view(S.shape), S)
+    with torch.no_grad():                                               # ReLU epilogue
+        yr = ops.deform_conv(xd, w1, bd, od, 3, 3, deformable_group=dg, relu=True)
+    assert torch.equal(yr, torch.relu(y0))
+
+
 def test_deform_conv_rejects_bad_arguments(dev):
     from dan_amd.utility import custom_op
     x, w, off = _case(0, 1, 4, 4, 64, 64, 4, 0.0)
