@@ -1,0 +1,33 @@
+#!/bin/bash
+# Collects the per-round evidence under gpurun_out/<tag>/ (copy what is kept into profiles/<round>/):
+#   bench line, rocprofv3 kernel stats of the same command, PMC traffic, the other graphs' lines, the small-batch (strong-scaling shard) lines.
+# usage (on the GPU box): bash tools/collect_round_profiles.sh c
+set -u
+TAG=${1:-c}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py > $OUT/s3fd_b16_bench_line.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp && cd $ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o s3fd -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/s3fd_b16_bench_line_under_rocprof.json 2> $OUT/prof.err
+cp $OUT/prof/*kernel_stats.csv $OUT/s3fd_b16_kernel_stats.csv 2>/dev/null || find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/s3fd_b16_kernel_stats.csv \;
+bash tools/pmc_bench.sh r2 > $OUT/pmc.log 2>&1
+cp gpurun_out/pmc_bench_traffic.json $OUT/ 2>/dev/null
+: > $OUT/models_bench_lines.jsonl
+for m in pb dan dan_deform; do
+  python3 bench.py --model $m --no-cpu-baseline --no-serialized-roofline 2>/dev/null | tail -1 >> $OUT/models_bench_lines.jsonl
+  python3 bench.py --model $m --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/models_bench_lines.jsonl
+done
+python3 bench.py --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/models_bench_lines.jsonl
+: > $OUT/s3fd_small_batch_lines.jsonl
+for b in 2 4 8; do
+  python3 bench.py --batch-per-gpu $b --steps 20 --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/s3fd_small_batch_lines.jsonl
+done
+for m in sfd dan dan_deform pb; do
+  DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_$m -o s -- python3 bench.py --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_$m.log 2>&1
+  python3 tools/prof_db.py $OUT/serial_$m/s_results.db 6 60 > $OUT/${m}_b16_serialized_kernels.txt
+  rm -rf $OUT/serial_$m
+done
+rm -rf $OUT/prof
+ls -la $OUT
