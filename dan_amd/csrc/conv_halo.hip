@@ -696,7 +696,7 @@ template <bool DGRAD>
 int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
   if (p.head) {
     if (DGRAD) return 1;
-    return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 1, 4, false, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 1, 4, false, 1>(a, s);
+    return p.th == 8 ? launch_halo_cfg<8, 32, 64, 8, 1, 3, 3, false, 1>(a, s) : launch_halo_cfg<16, 16, 64, 8, 1, 3, 3, false, 1>(a, s);
   }
   if constexpr (!DGRAD) {
     if (a.pool_y && p.bn == 128)                   // fused 2x2 max-pool epilogue (the 128-wide tiles own whole row pairs per wave)
@@ -733,7 +733,7 @@ const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad) {
   if (!plan_halo(a, &p)) return nullptr;
   if (p.head) {
     if (dgrad) return nullptr;
-    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 1, 4, false, 1, false>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 1, 4, false, 1, false>";
+    return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 64, 8, 1, 3, 3, false, 1, false>" : "conv3x3_halo_kernel<16, 16, 64, 8, 1, 3, 3, false, 1, false>";
   }
   if (!dgrad && a.pool_y && danhip_conv_halo_pool_fusable(a))
     return p.th == 8 ? "conv3x3_halo_kernel<8, 32, 128, 4, 2, 1, 4, false, 0, true>" : "conv3x3_halo_kernel<16, 16, 128, 4, 2, 1, 4, false, 0, true>";

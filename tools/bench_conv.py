@@ -37,6 +37,11 @@ BIG = [("b1_2", 16, 1024, 1024, 64, 64, 3, 1), ("b2_2", 8, 512, 512, 128, 128, 3
        ("b4_2", 8, 128, 128, 512, 512, 3, 1), ("b5_1", 8, 64, 64, 512, 512, 3, 1), ("bfc6", 8, 32, 32, 512, 1024, 3, 1),
        ("odd1", 3, 203, 331, 64, 64, 3, 1), ("odd2", 3, 102, 166, 128, 128, 3, 1), ("odd3", 2, 51, 83, 256, 256, 3, 1),
        ("odd4", 2, 26, 42, 512, 512, 3, 1), ("oddh", 2, 102, 166, 256, 8, 3, 1)]
+# the rest of the S3FD graph: extra layers (net/sfd_net.py:146-156) and the six loc+cls heads (Cout = 4 + 2, conv3_3 head with max-out: 4 + 4)
+TAIL = [("conv6_1", 16, 20, 20, 1024, 256, 1, 1), ("conv6_2", 16, 20, 20, 256, 512, 3, 2), ("conv7_1", 16, 10, 10, 512, 128, 1, 1),
+        ("conv7_2", 16, 10, 10, 128, 256, 3, 2), ("head3_3", 16, 160, 160, 256, 8, 3, 1), ("head4_3", 16, 80, 80, 512, 6, 3, 1),
+        ("head5_3", 16, 40, 40, 512, 6, 3, 1), ("headfc7", 16, 20, 20, 1024, 6, 3, 1), ("head6_2", 16, 10, 10, 512, 6, 3, 1),
+        ("head7_2", 16, 5, 5, 256, 6, 3, 1)]
 SMALL = [("s64", 2, 32, 64, 64, 64, 3, 1), ("s128", 2, 24, 40, 128, 128, 3, 1), ("s256", 1, 48, 48, 256, 256, 3, 1)]
 
 
@@ -120,7 +125,7 @@ def main():
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG}[args.set]
+    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG, "tail": TAIL}[args.set]
     if args.only:
         shapes = [s for s in shapes if s[0] in args.only.split(",")]
     which = args.which.split(",")
