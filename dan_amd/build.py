@@ -51,11 +51,12 @@ def _build_variant(out, objdir, defines, force, verbose):
         r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, capture_output=True, text=True)      # no vendor GEMM / conv library is linked: every kernel is in csrc/
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
-    import ctypes
-    try:                       # an address-space cast the host pass rejects silently leaves a kernel's host stub undefined: catch it here
-        ctypes.CDLL(out)
-    except OSError as e:
-        raise RuntimeError("%s does not load: %s" % (out, e))
+    # An address-space cast the host pass rejects silently leaves a kernel's host stub undefined: catch it here.  The check runs in a
+    # child process: loading the library HERE would bring the system HIP runtime into this process before PyTorch's own copy, and a
+    # process that then uses torch.cuda (build() followed by smoke() in one interpreter) finds "no ROCm-capable device".
+    r = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", out], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("%s does not load: %s" % (out, r.stderr.strip()[-2000:]))
     return out
 
 
