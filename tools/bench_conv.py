@@ -42,6 +42,10 @@ TAIL = [("conv6_1", 16, 20, 20, 1024, 256, 1, 1), ("conv6_2", 16, 20, 20, 256, 5
         ("conv7_2", 16, 10, 10, 128, 256, 3, 2), ("head3_3", 16, 160, 160, 256, 8, 3, 1), ("head4_3", 16, 80, 80, 512, 6, 3, 1),
         ("head5_3", 16, 40, 40, 512, 6, 3, 1), ("headfc7", 16, 20, 20, 1024, 6, 3, 1), ("head6_2", 16, 10, 10, 512, 6, 3, 1),
         ("head7_2", 16, 5, 5, 256, 6, 3, 1)]
+# DAN context module V1 at the 160x160 level (net/danet.py:842-918): branch 1x1s, 3x1 / 1x3 (as 3x3 here: kh = kw in this tool), residual 1x1
+DANB = [("b_1x1", 16, 160, 160, 256, 64, 1, 1), ("b4_3x3", 16, 160, 160, 64, 64, 3, 1), ("res_1x1", 16, 160, 160, 192, 256, 1, 1),
+        ("s2_mix_a", 16, 160, 160, 256, 88, 1, 1), ("s2_mix_b", 16, 160, 160, 256, 176, 1, 1), ("b_1x1_80", 16, 80, 80, 512, 64, 1, 1),
+        ("res_80", 16, 80, 80, 192, 512, 1, 1)]
 SMALL = [("s64", 2, 32, 64, 64, 64, 3, 1), ("s128", 2, 24, 40, 128, 128, 3, 1), ("s256", 1, 48, 48, 256, 256, 3, 1)]
 
 
@@ -125,7 +129,7 @@ def main():
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG, "tail": TAIL}[args.set]
+    shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG, "tail": TAIL, "dan": DANB}[args.set]
     if args.only:
         shapes = [s for s in shapes if s[0] in args.only.split(",")]
     which = args.which.split(",")
