@@ -1,0 +1,74 @@
+"""The four graphs at the BASELINE spatial size (640 x 640, one image — BASELINE.json configs[0] is "S3FD forward, one 640x640 image"),
+END TO END against the CPU oracle: the 16-bit path's logits at the tolerance tests/test_models_gpu.py uses at 64-200 px (accumulation
+depth does not grow with the image: the bound holds unchanged), and the fp32 inference path's decoded boxes at the north-star 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import anchors as OA
+from oracle import nets as ON
+
+pytestmark = pytest.mark.gpu
+S = 640
+
+
+def _weights(forward, x, seed):
+    P = ON.Params(create=True, seed=seed)
+    with torch.no_grad():
+        forward(P, x)
+    g = torch.Generator().manual_seed(99)
+    for n in P.t:
+        if n.endswith("/bias"):
+            P.t[n] = 0.05 * torch.randn(P.t[n].shape, generator=g)
+    return P
+
+
+@pytest.mark.parametrize("which", ["sfd", "pb", "dan", "dan_deform"])
+def test_graph_at_640_fp32_boxes_and_16bit_logits(which, dev):
+    from dan_amd import synthetic
+    from dan_amd.train_dan import DANModel, dan_anchor_config
+    from dan_amd.train_pb import PBModel
+    from dan_amd.train_sfd import AnchorConfig, SFDModel
+    imgs = synthetic.make_images(1, S, S, "cpu", seed=640)
+    x = ON.preprocess_synthetic(imgs)
+    if which == "sfd":
+        ofwd = ON.sfd_forward
+    elif which == "pb":
+        ofwd = lambda P, xx: ON.pb_forward(P, xx)["face"]
+    else:
+        ofwd = lambda P, xx: ON.dan_forward(P, xx, deform=(which == "dan_deform"))[0]      # stage-1 logits (no discrete routing decision)
+    full = {"sfd": ON.sfd_forward, "pb": ON.pb_forward}.get(which, lambda P, xx: ON.dan_forward(P, xx, deform=(which == "dan_deform")))
+    P = _weights(full, x, 21)
+    with torch.no_grad():
+        loc_r, cls_r = ofwd(ON.Params(P.t), x)
+    model = {"sfd": SFDModel, "pb": PBModel}.get(which, lambda device: DANModel(device=device, deform=(which == "dan_deform")))(device=dev)
+    model.vs.load_tf_named(P.t)
+    anchors = (dan_anchor_config if which.startswith("dan") else AnchorConfig)(S, S, dev)
+
+    def logits():
+        with torch.no_grad():
+            out = model.forward(imgs.to(dev))
+        if which == "sfd":
+            return out
+        if which == "pb":
+            return out["face"]
+        return out[0]
+
+    # ---- 16-bit path
+    loc, cls = logits()
+    for got, want, name in ((loc, loc_r, "loc"), (cls, cls_r, "cls")):
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err <= 0.06 * want.abs().max().item(), (which, name, err, want.abs().max().item())
+    # ---- fp32 path: logits 1e-4 of scale, decoded boxes 1e-4 px-relative
+    model.precision = "fp32"
+    loc32, cls32 = logits()
+    model.precision = "act"
+    assert loc32.dtype == torch.float32
+    for got, want, name in ((loc32, loc_r, "loc"), (cls32, cls_r, "cls")):
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 1e-4 * want.abs().max().item(), (which, name, err)
+    a4 = [t.cpu().numpy() for t in anchors.anchors[:4]]
+    ref_b = OA.decode_anchors(loc_r[0].numpy(), a4, [0.1, 0.1, 0.2, 0.2])
+    got_b = OA.decode_anchors(loc32[0].cpu().numpy(), a4, [0.1, 0.1, 0.2, 0.2])
+    assert got_b.shape[0] == anchors.num_anchors
+    assert (np.abs(got_b - ref_b) <= 1e-4 * np.maximum(1.0, np.abs(ref_b))).all()
