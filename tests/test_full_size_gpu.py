@@ -72,3 +72,30 @@ def test_graph_at_640_fp32_boxes_and_16bit_logits(which, dev):
     got_b = OA.decode_anchors(loc32[0].cpu().numpy(), a4, [0.1, 0.1, 0.2, 0.2])
     assert got_b.shape[0] == anchors.num_anchors
     assert (np.abs(got_b - ref_b) <= 1e-4 * np.maximum(1.0, np.abs(ref_b))).all()
+
+
+def test_s3fd_training_step_at_640(dev):
+    """BASELINE.json configs[1]'s shape (640 x 640; one image so that the CPU oracle finishes in seconds): loss terms and the gradient of
+    EVERY variable against the oracle in bf16-storage emulation, at the per-tensor bound tests/test_sfd_gpu.py uses at 128 x 128."""
+    import test_sfd_gpu as TS
+    from oracle import train as OT
+    from dan_amd.train_sfd import SFDTrainer
+    P, model, anchors, imgs, x, loc_t, cls_t = TS._setup(dev, B=1, H=S, W=S)
+    tr = SFDTrainer(model, world=1)
+    params = {n: v.clone().requires_grad_(True) for n, v in P.t.items()}
+    PO = ON.Params(params, emulate_bf16=True)
+    loc_ref, cls_ref = ON.sfd_forward(PO, x.to(torch.bfloat16).float())
+    ce, locl, _ = OT.detection_loss(cls_ref, loc_ref, cls_t.cpu().long(), loc_t.cpu())
+    (ce + locl).backward()
+    tr.train_step(imgs.to(dev), loc_t, cls_t)
+    g_ce, g_loc, g_l2, _ = tr.losses()
+    assert abs(g_ce - ce.item()) <= 0.03 * abs(ce.item()) + 1e-3, (g_ce, ce.item())
+    assert abs(g_loc - locl.item()) <= 0.03 * abs(locl.item()) + 1e-3, (g_loc, locl.item())
+    bad = []
+    for name, prm in dict(model.vs.named()).items():
+        got = prm.grad.detach().reshape(-1).cpu()
+        want = params[name].grad.reshape(-1)
+        rel = (got - want).norm().item() / (want.norm().item() + 1e-8)
+        if rel > 0.08 and want.abs().max().item() > 1e-6:
+            bad.append((name, rel))
+    assert not bad, bad[:8]
