@@ -366,32 +366,78 @@ extern "C" int danhip_conv_packed_dims(const danhip_conv_desc* d, int which, int
 }
 
 namespace {
-// one thread per packed element
-__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb, int kh, int kw,
-                                   int cin, int cin_real, int cout, int rows_f, int cols_f, int rows_b, int cols_b, int co8) {
-  const long total_f = (long)rows_f * cols_f, total_b = wb ? (long)rows_b * cols_b : 0;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)gridDim.x * blockDim.x) {
-    if (idx < total_f) {
-      const int co = (int)(idx / cols_f), k = (int)(idx % cols_f);
-      const int tap = k / cin, c = k % cin;
+// ---- weight packing.  Source: HWIO fp32 w[tap][c][co] (co contiguous).  Forward packing wf[co][k = tap*cin + c] is a TRANSPOSE of it:
+// an element-wise kernel reads the source at a stride of cout floats (one 64-byte sector per 4 bytes used — 1.2 ms per PyramidBox step);
+// here a workgroup moves a 64 k x 32 co tile through LDS: source rows read as 128-byte lines, packed rows written as 16-byte vectors.
+// Backward packing wb[ci][k = tap_flipped*co8 + co] keeps co contiguous: element-wise with 32-bit index arithmetic.
+// An entry's workgroups: the first e.pad_ ( = forward tiles) do the tiles, the rest stride over the backward elements.
+__device__ __forceinline__ void pack_entry_block(const danhip_pack_entry& e, int lb, int nb, float (*tile)[33]) {
+  const float* __restrict__ w = e.w_hwio;
+  const int taps = e.kh * e.kw;
+  const int tid = threadIdx.x;
+  if (lb < e.pad_) {
+    bf16_t* __restrict__ wf = e.wf_packed;
+    const int ctiles = (e.rows_f + 31) / 32;
+    const int tco = lb % ctiles, tk = lb / ctiles;
+    const int co0 = tco * 32, k0 = tk * 64;
+    const int tx = tid & 31, ty = tid >> 5;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int kl = ty + 8 * r, k = k0 + kl;
+      const int tap = k / e.cin, c = k - tap * e.cin;
       float v = 0.f;
-      if (co < cout && tap < kh * kw && c < cin_real) v = w[((long)tap * cin_real + c) * cout + co];
-      wf[idx] = f2bf(v);
-    } else {
-      const long j = idx - total_f;
-      const int ci = (int)(j / cols_b), k = (int)(j % cols_b);
-      const int tapf = k / co8, co = k % co8;          // flipped tap index
-      float v = 0.f;
-      if (ci < cin_real && tapf < kh * kw && co < cout) {
-        const int fi = tapf / kw, fj = tapf % kw;
-        const int tap = (kh - 1 - fi) * kw + (kw - 1 - fj);
-        v = w[((long)tap * cin_real + ci) * cout + co];
-      }
-      wb[j] = f2bf(v);
+      if (co0 + tx < e.cout && tap < taps && c < e.cin_real) v = w[((long)tap * e.cin_real + c) * e.cout + co0 + tx];
+      tile[kl][tx] = v;
     }
+    __syncthreads();
+    const int col = tid >> 3, kq = tid & 7;           // 32 output rows x eight 16-byte pieces
+    if (co0 + col < e.rows_f) {
+      uint4 o;
+      o.x = pack2bf(tile[kq * 8 + 0][col], tile[kq * 8 + 1][col]);
+      o.y = pack2bf(tile[kq * 8 + 2][col], tile[kq * 8 + 3][col]);
+      o.z = pack2bf(tile[kq * 8 + 4][col], tile[kq * 8 + 5][col]);
+      o.w = pack2bf(tile[kq * 8 + 6][col], tile[kq * 8 + 7][col]);
+      *reinterpret_cast<uint4*>(wf + (long)(co0 + col) * e.cols_f + k0 + kq * 8) = o;
+    }
+    return;
+  }
+  bf16_t* __restrict__ wb = e.wb_packed;
+  if (!wb) return;
+  const unsigned total_b = (unsigned)e.rows_b * (unsigned)e.cols_b;      // (< 2^31: danhip_pack_entry_init checks)
+  const unsigned nbb = (unsigned)(nb - e.pad_);
+  for (unsigned j = (unsigned)(lb - e.pad_) * 256u + tid; j < total_b; j += nbb * 256u) {
+    const unsigned ci = j / (unsigned)e.cols_b, k = j - ci * (unsigned)e.cols_b;
+    const unsigned tapf = k / (unsigned)e.co8, co = k - tapf * (unsigned)e.co8;          // flipped tap index
+    float v = 0.f;
+    if ((int)ci < e.cin_real && (int)tapf < taps && (int)co < e.cout) {
+      const int fi = tapf / e.kw, fj = tapf - fi * e.kw;
+      const int tap = (e.kh - 1 - fi) * e.kw + (e.kw - 1 - fj);
+      v = w[((long)tap * e.cin_real + ci) * e.cout + co];
+    }
+    wb[j] = f2bf(v);
   }
 }
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const danhip_pack_entry e) {
+  __shared__ float tile[64][33];
+  pack_entry_block(e, (int)blockIdx.x, (int)gridDim.x, tile);
+}
+
+// All conv weights of a model in ONE launch (the per-layer launches cost more than the packing itself: 28 per S3FD step,
+// 230 per DAN step).  Block b works on entry e = the last one with first_block[e] <= b (binary search over <= a few hundred).
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const danhip_pack_entry* __restrict__ tab, int n) {
+  __shared__ float tile[64][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const danhip_pack_entry e = tab[lo];
+  const int nb = (lo + 1 < n ? tab[lo + 1].first_block : (int)gridDim.x) - e.first_block;
+  pack_entry_block(e, (int)blockIdx.x - e.first_block, nb, tile);
+}
 }  // namespace
+
 
 
 namespace {
@@ -475,59 +521,14 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
 
 extern "C" int danhip_pack_conv_weight(const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real, uint16_t* wf_packed,
                                        uint16_t* wb_packed, void* stream) {
-  int rc = check_desc(d);
+  danhip_pack_entry e;
+  int32_t blocks = 0;
+  int rc = danhip_pack_entry_init(&e, d, w_hwio, cin_real, wf_packed, wb_packed, 0, &blocks);
   if (rc) return rc;
-  DH_REQUIRE(w_hwio && wf_packed, DANHIP_EINVAL, "pack_conv_weight: null pointer");
-  DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "pack_conv_weight: cin_real=%d out of range", cin_real);
-  int64_t rf, cf, rb, cb;
-  danhip_conv_packed_dims(d, 0, &rf, &cf);
-  danhip_conv_packed_dims(d, 1, &rb, &cb);
-  const long total = rf * cf + (wb_packed ? rb * cb : 0);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, wf_packed, wb_packed, d->kh, d->kw,
-                     d->Cin, cin_real, d->Cout, (int)rf, (int)cf, (int)rb, (int)cb, round_up(d->Cout, 8));
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, e);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
-
-namespace {
-// All conv weights of a model in ONE launch (the per-layer launches cost more than the packing itself: 28 per S3FD step,
-// 230 per DAN step).  Block b works on entry e = the last one with first_block[e] <= b (binary search over <= a few hundred).
-__global__ void pack_weights_batched_kernel(const danhip_pack_entry* __restrict__ tab, int n) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const danhip_pack_entry e = tab[lo];
-  const int nb = (lo + 1 < n ? tab[lo + 1].first_block : (int)gridDim.x) - e.first_block;
-  const float* __restrict__ w = e.w_hwio;
-  bf16_t* __restrict__ wf = e.wf_packed;
-  bf16_t* __restrict__ wb = e.wb_packed;
-  const long total_f = (long)e.rows_f * e.cols_f, total_b = wb ? (long)e.rows_b * e.cols_b : 0;
-  for (long idx = (long)(blockIdx.x - e.first_block) * blockDim.x + threadIdx.x; idx < total_f + total_b; idx += (long)nb * blockDim.x) {
-    if (idx < total_f) {
-      const int co = (int)(idx / e.cols_f), k = (int)(idx % e.cols_f);
-      const int tap = k / e.cin, c = k % e.cin;
-      float v = 0.f;
-      if (co < e.cout && tap < e.kh * e.kw && c < e.cin_real) v = w[((long)tap * e.cin_real + c) * e.cout + co];
-      wf[idx] = f2bf(v);
-    } else {
-      const long j = idx - total_f;
-      const int ci = (int)(j / e.cols_b), k = (int)(j % e.cols_b);
-      const int tapf = k / e.co8, co = k % e.co8;
-      float v = 0.f;
-      if (ci < e.cin_real && tapf < e.kh * e.kw && co < e.cout) {
-        const int fi = tapf / e.kw, fj = tapf % e.kw;
-        const int tap = (e.kh - 1 - fi) * e.kw + (e.kw - 1 - fj);
-        v = w[((long)tap * e.cin_real + ci) * e.cout + co];
-      }
-      wb[j] = f2bf(v);
-    }
-  }
-}
-}  // namespace
 
 extern "C" int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_desc* d, const float* w_hwio, int32_t cin_real,
                                       uint16_t* wf_packed, uint16_t* wb_packed, int32_t first_block, int32_t* blocks) {
@@ -542,9 +543,12 @@ extern "C" int danhip_pack_entry_init(danhip_pack_entry* e, const danhip_conv_de
   e->kh = d->kh; e->kw = d->kw; e->cin = d->Cin; e->cin_real = cin_real; e->cout = d->Cout;
   e->rows_f = (int)rf; e->cols_f = (int)cf; e->rows_b = (int)rb; e->cols_b = (int)cb; e->co8 = round_up(d->Cout, 8);
   e->first_block = first_block;
-  const long total = rf * cf + (wb_packed ? rb * cb : 0);
-  long nb = (total + 1023) / 1024;                      // 4 elements per thread (fc6: 9.4 M elements -> 9 k workgroups)
-  if (nb > 16384) nb = 16384;
+  DH_REQUIRE(rf * cf < (1ll << 31) && rb * cb < (1ll << 31), DANHIP_EINVAL, "pack_entry_init: packed matrix exceeds 2^31 elements");
+  const long tiles_f = ((rf + 31) / 32) * (cf / 64);      // forward: 64 k x 32 co tiles (cols_f is a multiple of 64)
+  long nbb = wb_packed ? (rb * cb + 1023) / 1024 : 0;      // backward: 4 elements per thread
+  if (nbb > 8192) nbb = 8192;
+  e->pad_ = (int)tiles_f;
+  const long nb = tiles_f + nbb;
   *blocks = (int)nb;
   return DANHIP_OK;
 }

@@ -343,3 +343,42 @@ def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
     want_b = dy.float().reshape(-1, Cout).sum(0) + 1.0
     assert (dw.cpu().reshape(Cin, Cout) - want_w).abs().max().item() <= 2e-3 * want_w.abs().max().item(), shape
     assert (db.cpu() - want_b).abs().max().item() <= 2e-3 * want_b.abs().max().item() + 1e-2, shape
+
+
+@pytest.mark.parametrize("kh,kw,cin,cin_real,cout", [(3, 3, 64, 64, 128), (3, 3, 8, 3, 64), (1, 1, 256, 256, 85), (3, 3, 256, 256, 72), (3, 3, 512, 512, 6),
+                                                     (3, 1, 64, 64, 32), (1, 1, 1024, 1024, 1024), (3, 3, 72, 72, 200)])
+def test_weight_packing_layouts(kh, kw, cin, cin_real, cout, dev):
+    """danhip_pack_conv_weight (one weight) and the batched form (one launch for a table of weights) against the layouts DESIGN §1 states:
+    wf[co][tap*Cin + c] = w[tap][c][co], wb[ci][tap_flipped*Cout8 + co] = w[tap][ci][co], zeros in every padding row / column."""
+    import ctypes
+    from dan_amd import ops, _lib
+    from dan_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(kh * 100 + cin + cout)
+    w = torch.randn((kh, kw, cin_real, cout), generator=g)
+    d = ops._desc(1, 8, 8, cin, cout, kh, kw, 1)
+    (rf, cf), (rb, cb) = ops.packed_dims(d, 0), ops.packed_dims(d, 1)
+    taps, co8 = kh * kw, (cout + 7) // 8 * 8
+    wt = w.to(torch.bfloat16).reshape(taps, cin_real, cout)
+    want_f = torch.zeros((rf, cf), dtype=torch.bfloat16)
+    want_b = torch.zeros((rb, cb), dtype=torch.bfloat16)
+    for t in range(taps):
+        want_f[:cout, t * cin:t * cin + cin_real] = wt[t].t()
+        fi, fj = divmod(t, kw)
+        tf_ = (kh - 1 - fi) * kw + (kw - 1 - fj)                          # the data gradient runs the taps flipped
+        want_b[:cin_real, tf_ * co8:tf_ * co8 + cout] = wt[t]
+    wd = w.to(dev)
+    wf = torch.full((rf, cf), 7.0, dtype=torch.bfloat16, device=dev)
+    wb = torch.full((rb, cb), 7.0, dtype=torch.bfloat16, device=dev)
+    call("danhip_pack_conv_weight", ctypes.byref(d), ptr(wd), cin_real, ptr(wf), ptr(wb), stream())
+    assert torch.equal(wf.cpu(), want_f) and torch.equal(wb.cpu(), want_b)
+    # batched: this weight twice in one table (second entry forward-only), non-zero first_block for the second
+    wf1, wb1, wf2 = torch.full_like(wf, 3.0), torch.full_like(wb, 3.0), torch.full_like(wf, 3.0)
+    arr = (_lib.PackEntry * 2)()
+    nb = ctypes.c_int32()
+    call("danhip_pack_entry_init", ctypes.byref(arr[0]), ctypes.byref(d), ptr(wd), cin_real, ptr(wf1), ptr(wb1), 0, ctypes.byref(nb))
+    first = nb.value
+    call("danhip_pack_entry_init", ctypes.byref(arr[1]), ctypes.byref(d), ptr(wd), cin_real, ptr(wf2), None, first, ctypes.byref(nb))
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    call("danhip_pack_conv_weights_batched", ptr(tab), 2, first + nb.value, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wf1.cpu(), want_f) and torch.equal(wb1.cpu(), want_b) and torch.equal(wf2.cpu(), want_f)
