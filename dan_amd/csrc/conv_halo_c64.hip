@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int srow = lane >> 3, frow = lane & 15, fq = lane >> 4;
+  const int frow = lane & 15, fq = lane >> 4;
   const int G = gridDim.x;
 
   // ---- this wave's weights -> registers: A fragment (tap, ks, ct): W[co][k = tap*64 + ks*32 + fq*8 ..] with the rows of the two

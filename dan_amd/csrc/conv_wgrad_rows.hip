@@ -88,7 +88,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int lane_ = lane;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wci = wave & 3;
   const int grp = wave >> 2;                          // phase group (0 = A, 1 = B) and co half
@@ -392,7 +391,6 @@ static int wg_rows_cot(const danhip_conv_desc* d) { return ((d->Cout + 63) / 64 
 
 static bool wg_rows_eligible(const danhip_conv_desc* d) {
   if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->Ho == d->H && d->Wo == d->W)) return false;      // 'same' 3x3 only
-  const int co8 = (d->Cout + 7) / 8 * 8;
   if (d->Cin % 64 != 0) return false;      // any Cout: channel chunks beyond Co8 are zero-filled (thin heads: one 64-wide tile; 72 -> one 128-wide tile)
   const int tw = 32;
   const double util = (double)d->W / (double)((d->W + tw - 1) / tw * tw);
