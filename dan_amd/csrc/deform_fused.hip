@@ -15,6 +15,10 @@
 // (dan_amd/ops.py KEEP_DEFORM_COL); inference passes NULL and the 9x activation-sized buffer never exists.
 #include "common.h"
 
+#ifndef FUSED_BM
+#define FUSED_BM 128
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned df_u32x4;
@@ -41,11 +45,12 @@ struct FusedArgs {
   long M;
 };
 
-template <int BN>
-__global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a) {
-  constexpr int BM = 128, NPT = 4, NCT = BN / 64;          // wave tile 64 px x BN/4 co
+template <int BN, int BM>
+__global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const FusedArgs a) {
+  constexpr int NW = BM / 16;                               // waves: (BM / 64) x 4
+  constexpr int NPT = 4, NCT = BN / 64;                     // wave tile 64 px x BN/4 co
   constexpr int ABYTES = BM * 128, WBYTES = BN * 128;       // one stage each
-  constexpr int WPW = BN / 64;                              // weight DMA pieces (1 KiB = 8 rows) per wave and K-step
+  constexpr int WPW = BN / 8 / NW;                          // weight DMA pieces (1 KiB = 8 rows) per wave and K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS map: [A stage 0][A stage 1][W stage 0][W stage 1]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -55,20 +60,30 @@ __global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a
   const int ksteps = 9 * a.dg;
   const int offc = a.dg * 18;
 
-  // ---- this thread's pixel of the tile (fixed for the whole K loop)
-  const int px = tid >> 2, q4 = tid & 3;
-  const long m = (long)blockIdx.x * BM + px;
-  const bool live = m < a.M;
-  const long mm = live ? m : a.M - 1;
-  const int wo = (int)(mm % a.Wo);
-  const long mr = mm / a.Wo;
-  const int ho = (int)(mr % a.Ho), n = (int)(mr / a.Ho);
-  const int h_in = ho * a.stride - a.pad_t, w_in = wo * a.stride - a.pad_l;
-  const int cur_h = a.H - h_in, cur_w = a.W - w_in;
-  const bf16_t* xq = a.x + ((long)n * a.H * a.W) * a.C + q4 * 16;
-  const bf16_t* op = a.offs + mm * offc;
-  const unsigned a_dst = (unsigned)(px * 128);
-  const int sw0 = ((2 * q4) ^ (px & 7)) << 4, sw1 = ((2 * q4 + 1) ^ (px & 7)) << 4;
+  // ---- this thread's TWO pixels of the tile (fixed for the whole K loop) and its 16-byte chunk of their 64-channel rows: a wave's load
+  // instruction then covers 8 pixels x 128 contiguous bytes (8 cache lines fully used; the (pixel, 32-byte quarter) mapping touched
+  // 16 lines half-used per instruction and every line twice), and an LDS write covers 1 KiB contiguously like a DMA piece
+  constexpr int HP = BM / 2;
+  const int ck = tid & 7;
+  int px2[2], h_in2[2], w_in2[2];
+  long m2[2];
+  bool live2[2];
+  const bf16_t* xq2[2];
+  const bf16_t* op2[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    px2[u] = (tid >> 3) + u * HP;
+    m2[u] = (long)blockIdx.x * BM + px2[u];
+    live2[u] = m2[u] < a.M;
+    const long mm = live2[u] ? m2[u] : a.M - 1;
+    const int wo = (int)(mm % a.Wo);
+    const long mr = mm / a.Wo;
+    const int ho = (int)(mr % a.Ho), n = (int)(mr / a.Ho);
+    h_in2[u] = ho * a.stride - a.pad_t;
+    w_in2[u] = wo * a.stride - a.pad_l;
+    xq2[u] = a.x + ((long)n * a.H * a.W) * a.C + ck * 8;
+    op2[u] = a.offs + mm * offc;
+  }
 
   // ---- weight DMA: piece = 8 rows x 128 B; lane -> (row = piece*8 + lane/8, 16-byte chunk lane%8), chunk c of row r lands at c ^ (r & 7)
   const df_u32x4 rsrc_w = {(unsigned)(unsigned long long)a.w, (unsigned)((unsigned long long)a.w >> 32) & 0xFFFFu,
@@ -86,68 +101,70 @@ __global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a
   };
 
   // ---- gather of K-step ks: loads now, blend + LDS write later
-  struct Taps { uint4 cn[4][2]; float wq[4]; bool in; };               // the four corner rows (16 channels each), their weights
-  // the offset pair of a K-step is fetched one step before its gather (a dependent load in front of the eight corner loads would put a
+  struct Taps { uint4 cn[2][4]; float wq[2][4]; bool in[2]; };         // per pixel: the four corner pieces (8 channels each), their weights
+  // the offset pairs of a K-step are fetched one step before its gather (a dependent load in front of the eight corner loads would put a
   // memory latency at the head of every K-step)
-  auto load_off = [&](int ks) __attribute__((always_inline)) -> unsigned {
+  unsigned oraw_next[2];
+  auto load_off = [&](int ks) __attribute__((always_inline)) {
     const int t = ks / a.dg, grp = ks - t * a.dg;
-    return *reinterpret_cast<const unsigned*>(op + (grp * 9 + t) * 2);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) oraw_next[u] = *reinterpret_cast<const unsigned*>(op2[u] + (grp * 9 + t) * 2);
   };
-  unsigned oraw_next = load_off(0);
+  load_off(0);
   auto gather = [&](Taps& g, int ks) __attribute__((always_inline)) {
     const int t = ks / a.dg, grp = ks - t * a.dg;
     const int i = t / 3, j = t - i * 3;
-    const unsigned oraw = oraw_next;
-    oraw_next = load_off(ks + 1 < ksteps ? ks + 1 : ks);              // (always issued: the hand-counted waits below rely on 9 loads per gather)
-    const float off_h = bf2f((bf16_t)(oraw & 0xffffu)), off_w = bf2f((bf16_t)(oraw >> 16));
-    const float h_im = (float)(h_in + i * a.dil) + off_h;               // deform_conv.cu:261-262
-    const float w_im = (float)(w_in + j * a.dil) + off_w;
-    const bool in = h_im >= 0 && w_im >= 0 && h_im < a.H && w_im < a.W; // :263
-    g.in = in;
-    float mh = (float)(i * a.dil) + off_h, mw = (float)(j * a.dil) + off_w;       // :264-265 (relative to (h_in, w_in))
-    if (!in) { mh = (float)(-h_in); mw = (float)(-w_in); }              // (any valid address: the result is discarded)
-    int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;         // deformable_im2col_bilinear :94-112
-    if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
-    if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
-    const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
-    g.wq[0] = hh * hw; g.wq[1] = hh * lw; g.wq[2] = lh * hw; g.wq[3] = lh * lw;  // :118-125
-    const bf16_t* base = xq + grp * 64;
-    const int rl = (h_in + h_low) * a.W + w_in, rh = (h_in + h_high) * a.W + w_in;
-    const bf16_t* p0 = base + (long)(rl + w_low) * a.C;
-    const bf16_t* p1 = base + (long)(rl + w_high) * a.C;
-    const bf16_t* p2 = base + (long)(rh + w_low) * a.C;
-    const bf16_t* p3 = base + (long)(rh + w_high) * a.C;
-    g.cn[0][0] = *reinterpret_cast<const uint4*>(p0); g.cn[0][1] = *reinterpret_cast<const uint4*>(p0 + 8);
-    g.cn[1][0] = *reinterpret_cast<const uint4*>(p1); g.cn[1][1] = *reinterpret_cast<const uint4*>(p1 + 8);
-    g.cn[2][0] = *reinterpret_cast<const uint4*>(p2); g.cn[2][1] = *reinterpret_cast<const uint4*>(p2 + 8);
-    g.cn[3][0] = *reinterpret_cast<const uint4*>(p3); g.cn[3][1] = *reinterpret_cast<const uint4*>(p3 + 8);
+    const unsigned oraw[2] = {oraw_next[0], oraw_next[1]};
+    load_off(ks + 1 < ksteps ? ks + 1 : ks);                            // (always issued: the hand-counted waits below rely on 10 loads per gather)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int h_in = h_in2[u], w_in = w_in2[u];
+      const int cur_h = a.H - h_in, cur_w = a.W - w_in;
+      const float off_h = bf2f((bf16_t)(oraw[u] & 0xffffu)), off_w = bf2f((bf16_t)(oraw[u] >> 16));
+      const float h_im = (float)(h_in + i * a.dil) + off_h;             // deform_conv.cu:261-262
+      const float w_im = (float)(w_in + j * a.dil) + off_w;
+      const bool in = h_im >= 0 && w_im >= 0 && h_im < a.H && w_im < a.W;         // :263
+      g.in[u] = in;
+      float mh = (float)(i * a.dil) + off_h, mw = (float)(j * a.dil) + off_w;     // :264-265 (relative to (h_in, w_in))
+      if (!in) { mh = (float)(-h_in); mw = (float)(-w_in); }            // (any valid address: the result is discarded)
+      int h_low = (int)floorf(mh), w_low = (int)floorf(mw), h_high, w_high;       // deformable_im2col_bilinear :94-112
+      if (h_low >= cur_h - 1) { h_high = h_low = cur_h - 1; mh = (float)h_low; } else h_high = h_low + 1;
+      if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
+      const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
+      g.wq[u][0] = hh * hw; g.wq[u][1] = hh * lw; g.wq[u][2] = lh * hw; g.wq[u][3] = lh * lw;          // :118-125
+      const bf16_t* base = xq2[u] + grp * 64;
+      const int rl = (h_in + h_low) * a.W + w_in, rh = (h_in + h_high) * a.W + w_in;
+      g.cn[u][0] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_low) * a.C);
+      g.cn[u][1] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_high) * a.C);
+      g.cn[u][2] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_low) * a.C);
+      g.cn[u][3] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_high) * a.C);
+    }
   };
   uint4 pend[2];
   int pend_ks = -1;
   auto blend_store = [&](const Taps& g, int ks, int stage) __attribute__((always_inline)) {
-    uint4 outv[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int u = 0; u < 2; ++u) {
       float v1[8], v2[8], v3[8], v4[8], o[8];
-      df_unpack8(g.cn[0][h], v1); df_unpack8(g.cn[1][h], v2); df_unpack8(g.cn[2][h], v3); df_unpack8(g.cn[3][h], v4);
+      df_unpack8(g.cn[u][0], v1); df_unpack8(g.cn[u][1], v2); df_unpack8(g.cn[u][2], v3); df_unpack8(g.cn[u][3], v4);
 #pragma unroll
       for (int e = 0; e < 8; ++e)       // (the explicit fma chain of deform_sample_fwd_kernel: identical column values)
-        o[e] = fmaf(g.wq[3], v4[e], fmaf(g.wq[2], v3[e], fmaf(g.wq[1], v2[e], g.wq[0] * v1[e])));
-      const bool keep = g.in && live;               // a select on the packed words (a branch around the blend costs more than the blend)
-      outv[h].x = keep ? pack2bf(o[0], o[1]) : 0u; outv[h].y = keep ? pack2bf(o[2], o[3]) : 0u;
-      outv[h].z = keep ? pack2bf(o[4], o[5]) : 0u; outv[h].w = keep ? pack2bf(o[6], o[7]) : 0u;
+        o[e] = fmaf(g.wq[u][3], v4[e], fmaf(g.wq[u][2], v3[e], fmaf(g.wq[u][1], v2[e], g.wq[u][0] * v1[e])));
+      const bool keep = g.in[u] && live2[u];        // a select on the packed words (a branch around the blend costs more than the blend)
+      uint4 outv;
+      outv.x = keep ? pack2bf(o[0], o[1]) : 0u; outv.y = keep ? pack2bf(o[2], o[3]) : 0u;
+      outv.z = keep ? pack2bf(o[4], o[5]) : 0u; outv.w = keep ? pack2bf(o[6], o[7]) : 0u;
+      *reinterpret_cast<uint4*>(smem + stage * ABYTES + px2[u] * 128 + ((ck ^ (px2[u] & 7)) << 4)) = outv;
+      pend[u] = outv;
     }
-    char* dst = smem + stage * ABYTES + a_dst;
-    *reinterpret_cast<uint4*>(dst + sw0) = outv[0];                     // (measured: this order is the conflict-free one; swapping the two
-    *reinterpret_cast<uint4*>(dst + sw1) = outv[1];                     //  stores for odd pixel pairs costs 50 %)
-    pend[0] = outv[0]; pend[1] = outv[1]; pend_ks = ks;                 // the column-buffer copy is stored at the start of the next step
+    pend_ks = ks;                                                       // the column-buffer copy is stored at the start of the next step
   };
   auto flush_col = [&]() __attribute__((always_inline)) {              // (there its stores are OLDER than the step's DMA in the wave's queue)
-    if (a.col && live && pend_ks >= 0) {
+    if (a.col && pend_ks >= 0) {
       const int t = pend_ks / a.dg, grp = pend_ks - t * a.dg;
-      bf16_t* cp = a.col + (m * 9 + t) * a.C + grp * 64 + q4 * 16;
-      *reinterpret_cast<uint4*>(cp) = pend[0];
-      *reinterpret_cast<uint4*>(cp + 8) = pend[1];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (live2[u]) *reinterpret_cast<uint4*>(a.col + (m2[u] * 9 + t) * a.C + grp * 64 + ck * 8) = pend[u];
     }
     pend_ks = -1;
   };
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a
   // One K-step.  The corner rows are gathered TWO steps ahead (memory latency is several K-steps of MFMA time and all eight waves of the
   // single resident workgroup move in lockstep): queue of a wave at its wait, oldest first =
   //   [rows(ks+1) | column-buffer stores of the previous blend | W(ks+1) | rows(ks+2)]
-  // so "W(ks+1) landed" = at most the 9 loads of rows(ks+2) outstanding.
+  // so "W(ks+1) landed" = at most the 10 loads of rows(ks+2) outstanding.
   auto step = [&](int ks, const Taps& nxt, Taps& refill, int st) __attribute__((always_inline)) {
     const bool more = ks + 1 < ksteps, more2 = ks + 2 < ksteps;
     flush_col();
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a
     __builtin_amdgcn_sched_barrier(0);
     if (more) blend_store(nxt, ks + 1, st ^ 1);
     if (!more2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
   for (int ks = 0; ks < ksteps; ks += 2) {
@@ -242,14 +259,14 @@ __global__ __launch_bounds__(512) void deform_fused_fwd_kernel(const FusedArgs a
   }
 }
 
-template <int BN>
+template <int BN, int BM>
 int launch_fused(const FusedArgs& a, hipStream_t s) {
-  constexpr int LDS = 2 * 128 * 128 + 2 * BN * 128;
+  constexpr int LDS = 2 * BM * 128 + 2 * BN * 128;
   static const bool attr_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fused_fwd_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fused_fwd_kernel<BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
-  const long tiles = (a.M + 127) / 128;
-  hipLaunchKernelGGL((deform_fused_fwd_kernel<BN>), dim3((unsigned)tiles), dim3(512), LDS, s, a);
+  const long tiles = (a.M + BM - 1) / BM;
+  hipLaunchKernelGGL((deform_fused_fwd_kernel<BN, BM>), dim3((unsigned)tiles), dim3(BM * 4), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -275,7 +292,7 @@ int danhip_launch_deform_fused_fwd(const uint16_t* x, const uint16_t* wf_packed,
   int tw = (a.Wo - 1) * stride + 3 - W; if (tw < 0) tw = 0;
   a.pad_t = th / 2; a.pad_l = tw / 2;
   a.M = (long)N * a.Ho * a.Wo;
-  if (Cout == 256) return launch_fused<256>(a, s);
-  if (Cout == 128) return launch_fused<128>(a, s);
-  return launch_fused<64>(a, s);
+  if (Cout == 256) return launch_fused<256, FUSED_BM>(a, s);
+  if (Cout == 128) return launch_fused<128, FUSED_BM>(a, s);
+  return launch_fused<64, FUSED_BM>(a, s);
 }
