@@ -50,6 +50,9 @@ SIGNATURES = {
     "danhip_avgpool2x2s1_same_fwd_f32": [P, P, I32, I32, I32, I32, P],
     "danhip_deform_sample_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
+    "danhip_conv2d_bwd_data_bits": [DESC, P, P, P, P, ctypes.c_int, P],
+    "danhip_relu_bits": [P, P, I64, I32, P],
+    "danhip_conv2d_fwd_relu_bits": [DESC, P, P, P, P, P, P, P, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
@@ -135,6 +138,10 @@ def lib():
         L.danhip_augment_workspace_bytes.argtypes = []
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
+        L.danhip_conv2d_fwd_emits_bits.restype = ctypes.c_int
+        L.danhip_conv2d_fwd_emits_bits.argtypes = [DESC, ctypes.c_int]
+        L.danhip_conv2d_bwd_data_takes_bits.restype = ctypes.c_int
+        L.danhip_conv2d_bwd_data_takes_bits.argtypes = [DESC]
         L.danhip_deform_conv_fused.restype = ctypes.c_int
         L.danhip_deform_conv_fused.argtypes = [I32] * 9
         L.danhip_bbox_vote_workspace_bytes.argtypes = [I32, I32]

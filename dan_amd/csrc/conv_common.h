@@ -7,8 +7,11 @@ struct ConvArgs {
   const bf16_t* w;
   const float* bias;
   const bf16_t* mask;
+  const unsigned char* mask_bits;   // data gradient: the ReLU mask as one bit per element, [M][Co/8] bytes (danhip_relu_bits), instead of `mask`
   const bf16_t* resid;
   void* y;
+  unsigned char* bits_out;        // forward conv_relu on the 128-wide halo tiles: also writes the ReLU bit mask of y ([M][Co/8] bytes) ...
+  unsigned char* pool_bits_out;   // ... and of the fused pooled output
   bf16_t* pool_y;   // optional: 2x2/stride-2 SAME max-pool of y (ReLU outputs), written by the kernels that can fuse it
   int N, H, W, C;
   int Ho, Wo, Co;
@@ -35,6 +38,8 @@ __device__ __forceinline__ unsigned pkmax_relu(unsigned a, unsigned b) {
 // Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
 // eligible (caller falls back to the flat-M kernel), negative on a launch error.
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
+bool danhip_conv_halo_takes_bits(const ConvArgs& a);
+bool danhip_conv_halo_emits_bits(const ConvArgs& a);   // the forward instance for these args writes ConvArgs::bits_out (and pool_bits_out with a fused pool)   // the data-gradient instance for these args reads ConvArgs::mask_bits
 const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);
 // 64 -> 64 channel special case with register-resident weights (conv_halo_c64.hip); same return convention.
 int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s);

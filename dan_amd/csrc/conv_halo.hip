@@ -124,6 +124,25 @@ __device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo
   return t;
 }
 
+// ReLU bit mask of 8 packed 16-bit activations (bit r = value r > 0): a 16-bit float is > 0 iff its bit pattern is in [1, 0x7fff]
+__device__ __forceinline__ unsigned pos_bits8(const u32x4& t) {
+  unsigned byte = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned lo = t[e] & 0xffffu, hi = t[e] >> 16;
+    byte |= ((lo - 1u) < 0x7fffu ? 1u : 0u) << (2 * e);
+    byte |= ((hi - 1u) < 0x7fffu ? 1u : 0u) << (2 * e + 1);
+  }
+  return byte;
+}
+// OR over the four lanes that share frow (the wave's 64 channels of one pixel): lane fq contributes bytes fq (pair 0) and 4 + fq (pair 1)
+__device__ __forceinline__ uint2 gather_bits64(unsigned b0, unsigned b1, int fq) {
+  unsigned lo = b0 << (8 * fq), hi = b1 << (8 * fq);
+  lo |= (unsigned)__shfl_xor((int)lo, 16, 64); hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
+  lo |= (unsigned)__shfl_xor((int)lo, 32, 64); hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
+  return uint2{lo, hi};
+}
+
 // 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out
 // of range (0xFFFFFFFF) writes ZEROS to its LDS slot.
 __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* lds_wave_base) {
@@ -277,6 +296,24 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   };
 
+  // ---- ReLU bit mask of the data gradient (ConvArgs::mask_bits, 128-wide tiles): the item's 256 pixels x 16 bytes (128 channels) are
+  // DMA'd by waves 0-3 during step 1 of the item's first chunk — after the barriers of step 0, i.e. after every wave's epilogue of the
+  // PREVIOUS item has read the buffer — and read from LDS in the epilogue: 4 KiB instead of the 64 KiB bf16 mask tile, off the epilogue's
+  // critical path.  The extra DMA only makes the counted waits stricter (one more young operation in the queue of those waves).
+  constexpr bool BITS_OK = DGRAD && NCU == 0 && BN == 128 && TPS == 1;
+  constexpr bool EMIT_OK = !DGRAD && NCU == 0 && BN == 128;            // forward: writes the bit mask of its own ReLU output (ConvArgs::bits_out)
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.mask_bits ? a.mask_bits : reinterpret_cast<const unsigned char*>(a.x)), 0,
+      (int)((unsigned)(a.N * a.H * a.W) * (unsigned)(a.Co / 8)), 0x00020000);
+  auto issue_bits = [&](int sp, int nb) __attribute__((always_inline)) {
+    int n, y0, x0;
+    sp_coords(sp, n, y0, x0);
+    const int t = wave * 64 + lane;                                     // (waves 0-3 only)
+    const int y = y0 + t / TW, x = x0 + t % TW;
+    const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * (unsigned)(a.Co / 8) + (unsigned)(nb * (BN / 8)) : 0xFFFFFFFFu;
+    bufdma16(rsrc_b, off, 0u, smem + SBIAS + wave * 1024);
+  };
+
   // ---- compute-side per-lane constants --------------------------------------------------------------------------
   const int frow = lane & 15, fq = lane >> 4;
   const int wrow0 = IL ? ((frow >> 2) * 8 + (frow & 3)) : frow;                   // lane's row inside the first tile (pair)
@@ -405,6 +442,23 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int r = 0; r < 8; ++r) bv[q][r] = (!DGRAD && cok[q]) ? reinterpret_cast<const float*>(smem + SBIAS)[cb + q * 32 + r] : 0.f;
       }
       [[maybe_unused]] u32x4 pk[POOL ? NPAIR : 1][POOL ? NPT : 1];      // POOL: packed outputs (zero where the pixel is outside)
+      if constexpr (BITS_OK) {
+        if (a.mask_bits) {                           // the staged bit mask: 8 bytes = this wave's 64 channels of one pixel
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const int t = wm * TP + p * 16 + frow;
+            const uint2 bb = *reinterpret_cast<const uint2*>(smem + SBIAS + t * 16 + wn * 8);
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+              const int bi = fq + q * 4;                                // byte of channels cb + q*32 .. +7
+              const unsigned byte = ((bi < 4 ? bb.x : bb.y) >> (8 * (bi & 3))) & 0xffu;
+#pragma unroll
+              for (int r = 0; r < 8; ++r)
+                if (!((byte >> r) & 1u)) acc[2 * q + (r >> 2)][p][r & 3] = 0.f;
+            }
+          }
+        }
+      }
       if constexpr (DGRAD) {
         // Data gradient: the ReLU mask / the value to accumulate into are read-modify inputs from HBM.  ALL of them are issued before the
         // first one is consumed — one exposed memory latency per item instead of one per pixel fragment (the forward epilogue only stores).
@@ -450,13 +504,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (a.resid && !a.out_f32) in0[q] = *reinterpret_cast<const uint4*>(a.resid + o0 + q * 32);
           }
         }
+        [[maybe_unused]] unsigned pb[2] = {0u, 0u};
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
           u32x4 r = {0u, 0u, 0u, 0u};
           if (ok && cok[q]) r = halo_finish8<DGRAD>(a, acc[2 * q][p], acc[2 * q + 1][p], bv[q], in0[q], in1[q], o0 + q * 32);
           if constexpr (POOL) pk[q][p] = r;
+          if constexpr (EMIT_OK) pb[q & 1] = pos_bits8(r);
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (EMIT_OK) {
+          if (a.bits_out) {                          // (uniform) the ReLU bit mask of y for the consumer's data gradient: 8 bytes per pixel and wave
+            const uint2 w8 = gather_bits64(pb[0], pb[1], fq);
+            if (ok && fq == 0)
+              *reinterpret_cast<uint2*>(a.bits_out + ((size_t)((n * a.H + y) * a.W + x)) * (a.Co / 8) + c_nb * (BN / 8) + wn * 8) = w8;
+          }
         }
       }
       }
@@ -475,6 +538,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const int y = y0 + t / TW, x = x0 + t % TW;
           const bool okp = y < a.H && x < a.W && (frow & 1) == 0;
           const size_t op = ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * a.Co + cb;
+          [[maybe_unused]] unsigned pb2[2] = {0u, 0u};
 #pragma unroll
           for (int q = 0; q < NPAIR; ++q) {
             u32x4 m;
@@ -484,6 +548,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               m[e] = pkmax_relu(v, (unsigned)__shfl_xor((int)v, 1));
             }
             if (okp) *reinterpret_cast<u32x4*>(a.pool_y + op + q * 32) = m;
+            if constexpr (EMIT_OK) pb2[q & 1] = pos_bits8(m);
+          }
+          if constexpr (EMIT_OK) {
+            if (a.pool_bits_out) {
+              const uint2 w8 = gather_bits64(pb2[0], pb2[1], fq);
+              if (okp && fq == 0)
+                *reinterpret_cast<uint2*>(a.pool_bits_out + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * (a.Co / 8) + c_nb * (BN / 8) + wn * 8) = w8;
+            }
           }
         }
       }
@@ -526,6 +598,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const bool more_w = w_ok;
         if (more_w) issue_w();
         if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        if constexpr (BITS_OK) {
+          if (STEP == 1 && cc == 0 && a.mask_bits) issue_bits(c_sp, c_nb);
+        }
         if (!more_w) wait_vmcnt<0>();              // tail of this block's work
         else if (patch_age <= D - 1) wait_vmcnt<(D - 1) * WL + PL>();
         else wait_vmcnt<(D - 1) * WL>();
@@ -662,7 +737,7 @@ template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, 
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
   constexpr int LDS0 = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
-  constexpr int LDS = LDS0 + ((!DGRAD && NCU == 0) ? 8192 : 0);     // + the bias vector (Co <= 2048 floats)
+  constexpr int LDS = LDS0 + (NCU == 0 ? 8192 : 0);     // + the bias vector (forward, Co <= 2048 floats) / the item's 4 KiB ReLU bit mask (data gradient)
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU, POOL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
@@ -717,9 +792,22 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return 1;
   const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32 && !p.head;
+  if (a.mask_bits && !(dgrad && p.bn == 128 && a.Co % 128 == 0)) return 1;
   if (!dgrad && a.accumulate) return 1;
   if (!dgrad && a.mask) return 1;
   return dgrad ? launch_halo<true>(a, p, s) : launch_halo<false>(a, p, s);
+}
+
+bool danhip_conv_halo_emits_bits(const ConvArgs& a) {
+  HaloPlan p;
+  if (!plan_halo(a, &p) || p.head || p.bn != 128 || a.Co % 128 != 0) return false;
+  return a.bias && a.relu && !a.resid && !a.out_f32 && !a.mask && !a.accumulate;      // forward conv_relu
+}
+
+bool danhip_conv_halo_takes_bits(const ConvArgs& a) {
+  HaloPlan p;
+  if (!plan_halo(a, &p) || p.head || p.bn != 128 || a.Co % 128 != 0) return false;
+  return !a.bias && !a.relu && !a.resid && !a.out_f32;                 // the data-gradient form
 }
 
 bool danhip_conv_halo_pool_fusable(const ConvArgs& a) {

@@ -598,6 +598,35 @@ extern "C" int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t*
   return danhip_maxpool2x2_fwd(y, pool_y, d->N, d->Ho, d->Wo, d->Cout, stream);
 }
 
+// conv_relu (+ the fused 2x2 max-pool when pool_y is given) that ALSO writes the ReLU bit masks of its outputs (danhip_relu_bits layout) from
+// the packed values still in registers — for the data gradient of the NEXT convolution (danhip_conv2d_bwd_data_bits).  Only the
+// 128-wide halo tiles do this: ask danhip_conv2d_fwd_emits_bits first.
+extern "C" int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_pool) {
+  if (!d || check_desc(d) != DANHIP_OK || d->Cout % 8 != 0) return 0;
+  static const float one = 1.f;
+  static bf16_t dummy = 0;
+  ConvArgs a = fwd_args(d);
+  a.bias = &one; a.relu = 1;
+  if (danhip_conv_c8_label(a) || danhip_conv_c64_eligible(a)) return 0;
+  if (!danhip_conv_halo_emits_bits(a)) return 0;
+  if (with_pool) { a.pool_y = &dummy; if (!danhip_conv_halo_pool_fusable(a)) return 0; }
+  return 1;
+}
+
+extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                           uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(x && wf_packed && bias && y && y_bits && (!pool_y == !pool_bits), DANHIP_EINVAL, "conv2d_fwd_relu_bits: null pointer");
+  DH_REQUIRE(danhip_conv2d_fwd_emits_bits(d, pool_y != nullptr), DANHIP_EINVAL,
+             "conv2d_fwd_relu_bits: this shape's forward kernel does not write bit masks (ask danhip_conv2d_fwd_emits_bits)");
+  ConvArgs a = fwd_args(d);
+  a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = nullptr; a.y = y;
+  a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
+  a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits;
+  return danhip_launch_conv_halo(a, (hipStream_t)stream);
+}
+
 namespace {
 // Direct (gather-form) data gradient for strided convolutions (only conv6_2 / conv7_2, 3x3 stride 2, tiny maps).
 // One thread per (input pixel, 8 input channels).
@@ -665,4 +694,26 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = relu_mask; a.resid = nullptr; a.y = dx;
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
   return launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d) {
+  if (!d || check_desc(d) != DANHIP_OK) return 0;
+  if (d->stride != 1) return 0;
+  ConvArgs a = bwd_args(d);
+  a.bias = nullptr; a.relu = 0; a.out_f32 = 0; a.resid = nullptr;
+  if (danhip_conv_c64_eligible(a)) return 0;
+  return danhip_conv_halo_takes_bits(a) ? 1 : 0;
+}
+
+extern "C" int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
+                                           uint16_t* dx, int accumulate, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(dy && wb_packed && dx && relu_bits, DANHIP_EINVAL, "conv2d_bwd_data_bits: null pointer");
+  DH_REQUIRE(danhip_conv2d_bwd_data_takes_bits(d), DANHIP_EINVAL, "conv2d_bwd_data_bits: the data-gradient kernel of this shape takes the 16-bit mask "
+             "(ask danhip_conv2d_bwd_data_takes_bits first)");
+  ConvArgs a = bwd_args(d);
+  a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = nullptr; a.mask_bits = relu_bits; a.resid = nullptr; a.y = dx;
+  a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
+  return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }

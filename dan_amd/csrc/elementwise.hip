@@ -369,6 +369,46 @@ extern "C" int danhip_slice_deliver(const uint16_t* dy, int32_t ldy, int32_t c0,
 }
 
 namespace {
+// ------------------------------------------------------------------ ReLU mask as bits: bits[m][j] bit i = x[m][8j + i] > 0
+// thread = 32 channels (four 16-byte loads -> one 32-bit store); C % 32 != 0: the tail groups store single bytes
+__global__ void relu_bits_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ bits, long M, int C) {
+  const int g32 = (C + 31) / 32, cb = C / 8;
+  const long total = M * g32;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / g32;
+    const int j = (int)(idx - m * g32);
+    unsigned word = 0;
+    const int nb = min(4, cb - j * 4);                 // bytes (8-channel groups) this thread owns
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + m * C + (j * 4 + b) * 8), f);
+        unsigned byte = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) byte |= (f[i] > 0.f ? 1u : 0u) << i;
+        word |= byte << (8 * b);
+      }
+    }
+    unsigned char* dst = bits + m * cb + j * 4;
+    if (nb == 4 && (cb & 3) == 0) *reinterpret_cast<unsigned*>(dst) = word;
+    else
+      for (int b = 0; b < nb; ++b) dst[b] = (unsigned char)(word >> (8 * b));
+  }
+}
+}  // namespace
+
+extern "C" int danhip_relu_bits(const uint16_t* x, uint8_t* bits, int64_t M, int32_t C, void* stream) {
+  DH_REQUIRE(x && bits && M > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "relu_bits: bad arguments (C %% 8 == 0)");
+  const long total = (long)M * ((C + 31) / 32);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, bits, (long)M, C);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+namespace {
 __global__ void zero_fill_kernel(uint4* __restrict__ p16, long n16, unsigned* __restrict__ tail, int ntail) {
   const uint4 z = make_uint4(0, 0, 0, 0);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p16[i] = z;

@@ -6,6 +6,7 @@ buffer) the backward kernels accumulate straight into it and return None to auto
 gradient tensor is returned as usual (used by the parity tests with torch.autograd.grad).
 """
 import ctypes
+import os
 
 import torch
 
@@ -255,11 +256,34 @@ def _attach_slot(t, is_relu):
     return s
 
 
+# ReLU masks as bits for the data-gradient kernels that stage them in LDS (danhip_relu_bits).  One activation may feed several convolutions:
+# every consumer's forward shares ONE holder hung on the activation tensor, the first backward that needs the bits fills it.
+USE_RELU_BITS = os.environ.get("DANHIP_RELU_BITS", "1") == "1"        # (0: A/B against the 16-bit mask reads)
+
+
+def _bits_holder(x):
+    h = getattr(x, "_dh_bits", None)
+    if h is None:
+        h = [None]
+        x._dh_bits = h
+    return h
+
+
+def relu_bits(x, holder):
+    if holder[0] is None:
+        C = x.shape[-1]
+        M = x.numel() // C
+        b = torch.empty((M, C // 8), dtype=torch.uint8, device=x.device)
+        call("danhip_relu_bits", ptr(x), ptr(b), M, C, stream())
+        holder[0] = b
+    return holder[0]
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0, xbits=None, bits_out=None):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
@@ -269,7 +293,18 @@ class _Conv2d(torch.autograd.Function):
         wf, wb = packed_weights(d, w, w_param, need_bwd)
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
         e0 = _prof_begin()
-        if pool_out is not None:                         # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
+        emit = (bits_out is not None and relu and not out_f32 and residual is None and b is not None
+                and _lib.lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d), 1 if pool_out is not None else 0))
+        if emit:                                         # conv_relu (+ fused pool) that also leaves the ReLU bit masks for the next conv's data gradient
+            ybits = torch.empty((N * d.Ho * d.Wo, cout // 8), dtype=torch.uint8, device=x.device)
+            pooled = pbits = None
+            if pool_out is not None:
+                pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
+                pbits = torch.empty((pooled.numel() // cout, cout // 8), dtype=torch.uint8, device=x.device)
+                pool_out.append(pooled)
+            call("danhip_conv2d_fwd_relu_bits", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(ybits), ptr(pooled), ptr(pbits), stream())
+            bits_out.extend([ybits, pbits])
+        elif pool_out is not None:                       # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
             assert relu and not out_f32 and residual is None and b is not None and cout % 8 == 0
             pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
             call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
@@ -279,7 +314,7 @@ class _Conv2d(torch.autograd.Function):
                  F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
         _prof_end(e0, d, 4 if pool_out is not None else 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
-        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.xslot, ctx.yslot, ctx.xbits = xslot, yslot, xbits
         ctx.set_materialize_grads(False)
         ctx.has_res = residual is not None
         ctx.w_param, ctx.b_param = w_param, b_param
@@ -324,7 +359,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 14
+            return (None,) * 16
         db_in_wgrad = need_db and need_dw                        # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -337,7 +372,11 @@ class _Conv2d(torch.autograd.Function):
             if xs is not None:                           # deliver straight into the producer's slot (+ its ReLU backward)
                 buf, acc = xs.target()
                 e0 = _prof_begin()
-                call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, stream())
+                if xs.is_relu and ctx.xbits is not None and _lib.lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d)):
+                    # the kernel keeps its tile's mask in LDS as bits: 1/16 of the bytes, and not a load in its epilogue
+                    call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(g), ptr(wb), ptr(relu_bits(x, ctx.xbits)), ptr(buf), acc, stream())
+                else:
+                    call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, stream())
                 _prof_end(e0, d, 5 if xs.is_relu else 1)
             else:
                 dx = torch.empty_like(x)
@@ -372,7 +411,7 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None and not hooked:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
 # ---- fp32 inference path (csrc/f32_infer.hip): every op below accepts fp32 NHWC activations and then runs the fp32 kernels — forward
@@ -413,7 +452,12 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     blk = 0
     if torch.is_grad_enabled():
         blk = (1 if _sink_trainable(w) else 0) | (2 if (b is not None and _sink_trainable(b)) else 0)
-    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, _slot_of(x) if track else None, yslot, pool_out, padding == "valid", blk)
+    xs = _slot_of(x) if track else None
+    xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
+    bits_out = [] if (track and relu and USE_RELU_BITS) else None
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out)
+    if bits_out:                                         # the forward kernel wrote the masks: the holders of y (and its pooled map) start filled
+        y._dh_bits = [bits_out[0]]
     if yslot is not None:
         cout = w.shape[-1]
         if cout % 8 == 0:
@@ -424,6 +468,8 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
             y._dh_pslot = yslot
     if pool_out:
         y._dh_pooled = pool_out[0]
+        if bits_out and bits_out[1] is not None:
+            y._dh_pooled_bits = bits_out[1]
     return y
 
 
@@ -479,6 +525,9 @@ def max_pool_2x2(x):
     xs = _slot_of(x) if track else None
     yslot = _new_slot(track)
     y = _MaxPool.apply(x, xs, yslot, getattr(x, "_dh_pooled", None))
+    pbits = getattr(x, "_dh_pooled_bits", None)
+    if pbits is not None and getattr(x, "_dh_pooled", None) is not None:
+        y._dh_bits = [pbits]                             # the fused conv + pool kernel also wrote the pooled map's ReLU bit mask
     if yslot is not None:
         # consumers may mask by (pooled > 0) when the source is a ReLU output
         yslot.__init__(y, xs.is_relu if xs is not None else False)

@@ -98,6 +98,19 @@ int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const u
  * that produced x).  dy bf16 [N,Ho,Wo,Cout_pad8]; dx bf16 [N,H,W,Cin]. accumulate: dx += instead of = . */
 int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed,
                            const uint16_t* relu_mask, uint16_t* dx, int accumulate, void* stream);
+/* The ReLU mask as one bit per element: bits[m][j] bit i = x[m][8j + i] > 0, rows of C/8 bytes (C % 8 == 0).  A data-gradient kernel that
+ * keeps its tile's mask in LDS reads 1/16 of the bytes, and not from its epilogue: danhip_conv2d_bwd_data_takes_bits(d) says whether the
+ * kernel chosen for descriptor d does (then call danhip_conv2d_bwd_data_bits with the bits of the conv's INPUT activation). */
+int danhip_relu_bits(const uint16_t* x, uint8_t* bits, int64_t M, int32_t C, void* stream);
+/* conv_relu (+ the block's fused 2x2 max-pool when pool_y != NULL) that also writes those bit masks for y (and pool_y) from its epilogue
+ * registers, so the next convolution's data gradient needs no pass over the activation: danhip_conv2d_fwd_emits_bits(d, with_pool) == 1
+ * where the forward kernel of descriptor d can (3x3 / stride-1 'same' on the 128-wide halo tiles, Cout % 128 == 0). */
+int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_pool);
+int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, void* stream);
+int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d);
+int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
+                                uint16_t* dx, int accumulate, void* stream);
 
 /* dw_hwio fp32 [kh,kw,Cin,Cout] += sum_pixels x (x) dy   (atomic fp32 accumulation: zero it first).
  * db (optional) fp32 [Cout] += sum_pixels dy  (bias gradient, computed by the same kernel: no extra pass over dy).

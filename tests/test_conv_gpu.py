@@ -382,3 +382,87 @@ def test_weight_packing_layouts(kh, kw, cin, cin_real, cout, dev):
     call("danhip_pack_conv_weights_batched", ptr(tab), 2, first + nb.value, stream())
     torch.cuda.synchronize()
     assert torch.equal(wf1.cpu(), want_f) and torch.equal(wb1.cpu(), want_b) and torch.equal(wf2.cpu(), want_f)
+
+
+@pytest.mark.parametrize("M,C", [(1000, 256), (77, 8), (513, 72), (64, 1024), (5, 40)])
+def test_relu_bits_kernel(M, C, dev):
+    import numpy as np
+    from dan_amd._lib import call, ptr, stream
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn((M, C), generator=g).to(torch.bfloat16)
+    x[::3] = 0
+    x[1, :] = -0.0
+    bits = torch.full((M, C // 8), 0xAA, dtype=torch.uint8, device=dev)
+    call("danhip_relu_bits", ptr(x.to(dev)), ptr(bits), M, C, stream())
+    want = np.packbits((x.float().numpy() > 0), axis=1, bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 64, 128, 128), (1, 33, 62, 64, 256), (3, 16, 16, 256, 128), (1, 80, 80, 512, 256), (2, 30, 62, 72, 128), (9, 64, 96, 128, 256)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_data_gradient_with_bit_mask_equals_the_16bit_mask_form(shape, accumulate, dev):
+    """danhip_conv2d_bwd_data_bits (the ReLU mask staged in LDS as one bit per element) against danhip_conv2d_bwd_data with the activation
+    itself as the mask: the same kernel and arithmetic, so the gradients are identical bit for bit; several items per workgroup, ragged
+    edges, 16x16 tiles, accumulate on / off, a ragged input-channel count of the forward conv's OUTPUT (dY with 72 channels)."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, lib, ptr, stream
+    N, H, W, Cout, Cin = shape                     # forward conv Cin -> Cout; its data gradient produces Cin channels
+    g = torch.Generator().manual_seed(sum(shape))
+    d = ops._desc(N, H, W, Cin, Cout, 3, 3, 1)
+    assert lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d)) == 1
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    _, wb = ops.pack_conv_weight(d, w, need_bwd=True)
+    x = torch.relu(torch.randn((N, H, W, Cin), generator=g)).to(torch.bfloat16).to(dev)
+    dy = torch.randn((N, H, W, Cout), generator=g).to(torch.bfloat16).to(dev)
+    old = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(dev)
+    bits = torch.empty((N * H * W, Cin // 8), dtype=torch.uint8, device=dev)
+    call("danhip_relu_bits", ptr(x), ptr(bits), N * H * W, Cin, stream())
+    a, b = old.clone(), old.clone()
+    call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(a), accumulate, stream())
+    call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(dy), ptr(wb), ptr(bits), ptr(b), accumulate, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert (a.float().abs().sum() > 0) and ((a == 0) | (x > 0)).all() if not accumulate else True
+    d2 = ops._desc(N, H, W, 64, 64, 3, 3, 1)       # the 64 -> 64 kernel keeps its own LDS-staged 16-bit mask
+    assert lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d2)) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 64, 64, 128), (1, 33, 62, 128, 256), (3, 16, 16, 256, 128), (9, 64, 96, 128, 128)])
+@pytest.mark.parametrize("pool", [False, True])
+def test_forward_kernel_writes_the_relu_bit_masks(shape, pool, dev):
+    """The 128-wide halo forward tiles leave the ReLU bit mask of their output (and of the fused pooled map) for the next convolution's
+    data gradient: identical to danhip_relu_bits of the tensors they wrote, ragged edges and odd sizes included; the hand-off reaches
+    the consumer (its data gradient equals the one computed with the 16-bit mask, bit for bit)."""
+    import numpy as np
+    from dan_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + pool)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(dev).requires_grad_(True)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev).requires_grad_(True)
+    b = (0.1 * torch.randn(Cout, generator=g)).to(dev).requires_grad_(True)
+    w2 = (torch.randn((3, 3, Cout, 128), generator=g) / (9 * Cout) ** 0.5).to(dev).requires_grad_(True)
+    res = {}
+    for use in (True, False):
+        ops.USE_RELU_BITS = use
+        try:
+            for t in (x, w, b, w2):
+                t.grad = None
+            y = ops.conv2d(x, w, b, relu=True, pool=pool)
+            z = ops.max_pool_2x2(y) if pool else y
+            if use:
+                for t in ((y, z) if pool else (y,)):
+                    bits = t._dh_bits[0]
+                    want = np.packbits(t.detach().float().cpu().numpy().reshape(-1, Cout) > 0, axis=1, bitorder="little")
+                    assert np.array_equal(bits.cpu().numpy(), want)
+            else:
+                assert getattr(y, "_dh_bits", None) is None
+            if z.shape[1] >= 16 and z.shape[2] >= 16:
+                out = ops.conv2d(z, w2, None, relu=False)
+                out.backward(torch.ones_like(out))
+                res[use] = (x.grad.clone(), w.grad.clone())
+        finally:
+            ops.USE_RELU_BITS = True
+    if res:
+        assert torch.equal(res[True][0], res[False][0])
+        assert (res[True][1] - res[False][1]).abs().max().item() <= 1e-4 * res[False][1].abs().max().item()      # (fp32 atomics order)

@@ -77,13 +77,22 @@ def run(shape, iters, which, check):
     def dgrad_nomask():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
 
+    bits = torch.empty((N * H * W, Cin // 8), dtype=torch.uint8, device=dev)
+
+    def relu_bits():
+        call("danhip_relu_bits", ptr(x), ptr(bits), N * H * W, Cin, stream())
+
+    def dgrad_bits():
+        call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(dy), ptr(wb), ptr(bits), ptr(dx), 0, stream())
+
     def dgrad_acc():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 1, stream())
 
     def wgrad():
         call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, stream())
 
-    fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad, "dgrad_nomask": dgrad_nomask, "dgrad_acc": dgrad_acc}
+    fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad, "dgrad_nomask": dgrad_nomask, "dgrad_acc": dgrad_acc, "dgrad_bits": dgrad_bits,
+           "relu_bits": relu_bits}
     out = []
     for wname in which:
         fn = fns[wname]
@@ -98,7 +107,7 @@ def run(shape, iters, which, check):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         label = ""
-        if wname != "wgrad":
+        if wname not in ("wgrad", "relu_bits"):
             label = lib().danhip_conv_kernel_label(ctypes.byref(d), 0 if wname == "fwd" else (1 if wname == "dgrad_nomask" else 5)).decode()
         out.append((wname, ms, flops / ms / 1e9, label))
     errs = {}
