@@ -10,9 +10,11 @@
 #ifdef DANHIP_FP16
 typedef _Float16 act16_t;
 #define DH_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define DH_POS_INF16 0x7c00u      /* bit pattern of +inf in the build's 16-bit type: patterns 1 .. +inf are the values > 0 */
 #else
 typedef __bf16 act16_t;
 #define DH_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define DH_POS_INF16 0x7f80u
 #endif
 typedef __attribute__((ext_vector_type(8))) act16_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) act16_t bf16x4;

@@ -124,14 +124,15 @@ __device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo
   return t;
 }
 
-// ReLU bit mask of 8 packed 16-bit activations (bit r = value r > 0): a 16-bit float is > 0 iff its bit pattern is in [1, 0x7fff]
+// ReLU bit mask of 8 packed 16-bit activations (bit r = value r > 0): a 16-bit float is > 0 iff its bit pattern lies in [1, +inf]
+// (DH_POS_INF16; the patterns above are NaNs, which compare false like in danhip_relu_bits)
 __device__ __forceinline__ unsigned pos_bits8(const u32x4& t) {
   unsigned byte = 0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const unsigned lo = t[e] & 0xffffu, hi = t[e] >> 16;
-    byte |= ((lo - 1u) < 0x7fffu ? 1u : 0u) << (2 * e);
-    byte |= ((hi - 1u) < 0x7fffu ? 1u : 0u) << (2 * e + 1);
+    byte |= ((lo - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e);
+    byte |= ((hi - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e + 1);
   }
   return byte;
 }
