@@ -18,15 +18,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+    process (never an exec, and before this process has imported torch or touched the GPU), forward its output and exit with its code.
+    The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle (PyTorch-CPU fp32 restatement of train_sfd.py's step; TF 1.8 is not installable offline) timed on
     the host cores on a bounded sample: batch 1 at 640x640, fwd + bwd + momentum step."""
+    import torch
     from oracle import nets as ON
     from oracle import train as OT
     torch.manual_seed(0)
@@ -100,14 +114,31 @@ def main():
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
+    global torch, dist
+    import torch
+    import torch.distributed as dist
     from dan_amd import _lib, ops, synthetic
     from dan_amd.trainer import init_distributed
     from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
 
     rank, world, local = init_distributed()
+    if os.environ.get("DANHIP_BENCH_DRY") == "1":      # tests/test_abi_cpu.py: the launch plumbing alone (no GPU): ranks rendezvous, rank 0 reports
+        n = dist.get_world_size() if dist.is_initialized() else 1
+        if dist.is_initialized():
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n = int(t.item())
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry": True, "n_gpus": world, "rccl_ranks": n}), flush=True)
+        return
     multi = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())   # DANHIP_FORCE_DIST: 1-rank group
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started inside a %d-rank job (WORLD_SIZE): launch it as `python bench.py --gpus %d` (it spawns its "
+                         "own ranks) or with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
     dev = torch.device("cuda", local)
     B, S = args.batch_per_gpu, args.size
     if args.global_batch:
@@ -304,6 +335,8 @@ def main():
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
                        "step_launch": "hipGraph replay" if args.graph else "eager",
+                       "rccl_ranks": dist.get_world_size() if multi else 1,
+                       "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if multi else None,
                        "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,

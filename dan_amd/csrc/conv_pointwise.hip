@@ -220,8 +220,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto step = [&](auto lastc, auto latec) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(lastc)::value, LATE = decltype(latec)::value;
     constexpr int LDWAIT = LATE ? 0 : DPW;            // vector-memory operations younger than the epilogue loads at their wait
-    // pieces of K-step c_idx have landed when at most the (NST - 2) younger steps + the stores of a recent epilogue are outstanding
-    const int pend = st_age <= NST - 2 ? st_cnt : 0;
+    // pieces of K-step c_idx have landed when at most the (NST - 2) younger steps + the stores of a recent epilogue are outstanding.
+    // st_age = s - 1 at the start of the s-th step after an epilogue at step i.  Early waves issued DMA(i + NST - 1) BEFORE the stores of
+    // step i, so the stores are younger than the awaited DMA(i + s) while s <= NST - 1; late waves issue that DMA AFTER their stores, so
+    // for them the stores are younger only while s <= NST - 2 (tests/test_abi_cpu.py replays both issue orders against this rule).
+    const int pend = st_age <= NST - 2 - (LATE ? 1 : 0) ? st_cnt : 0;
     pw_wait_vmcnt_dyn(pw_floor_count((NST - 2) * DPW + pend));
     __builtin_amdgcn_s_barrier();                      // ... for every wave; and every wave is done reading slot (c_idx - 1) % NST
     [[maybe_unused]] pw_u32x4 ld_m[NPT][NPAIR], ld_o[NPT][NPAIR], ld_b[NPAIR][2];

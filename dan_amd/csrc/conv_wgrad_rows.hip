@@ -40,6 +40,7 @@ struct WgRowsArgs {
   int N, H, W, C, Co8, Cout, cin_real;
   int tiles_x, total_rows, rows_per_split;
   int ci_tiles, co_tiles, xcd_grouped;
+  int ablate;          // timing experiments only (DANHIP_WGRAD_ABLATE=1): skip the epilogue's atomics
   FastDiv div_tx, div_h, div_ci, div_pairs;
 };
 
@@ -333,6 +334,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
   wr_wait_vmcnt<0>();                                 // zero-fill pieces of the steps beyond the stream are still landing
 
+  if (a.ablate) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) asm volatile("" ::"v"(acc[t][o]));
+    return;
+  }
   // ---- epilogue: lane holds dW[tap][ci = ci0 + wci*16 + g*4 + r][co = co0 + wco*NO*16 + o*16 + (lane & 15)]
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -379,6 +387,8 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   a.div_ci = make_fastdiv(a.ci_tiles);
   a.div_pairs = make_fastdiv(pairs);
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
+  static const int ablate = [] { const char* e = getenv("DANHIP_WGRAD_ABLATE"); return e ? atoi(e) : 0; }();
+  a.ablate = ablate;
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;

@@ -162,3 +162,63 @@ def test_fused_head_blocks_in_the_flat_buffer():
     vs.load_tf_named({"h/cls_0/kernel": torch.ones(3, 3, 16, 2)})        # loading by TF name writes through the view
     assert W[..., 4:].eq(1).all() and torch.equal(W[..., :4], a0)
     assert torch.equal(vs.export_tf_named()["h/loc_0/bias"], torch.zeros(4))
+
+
+def test_bench_spawns_its_own_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py starts torch.distributed.run as a child before importing torch, the two ranks
+    rendezvous on 127.0.0.1 and rank 0 prints the line (DANHIP_BENCH_DRY: the launch plumbing alone, gloo, no GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DANHIP_BENCH_DRY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+
+
+def _replay_pointwise_waits(NST, DPW, ksteps, n_items, stores_per_item, late):
+    """Host replay of conv_pointwise_kernel's issue / wait order for ONE wave under in-order vmcnt retirement (csrc/conv_pointwise.hip:
+    `step`): returns the list of (awaited DMA step, younger operations actually in the queue, count the kernel's rule allows to stay
+    outstanding).  The rule is safe iff allowed <= younger at every wait."""
+    floor = lambda n: 32 if n >= 32 else 24 if n >= 24 else 16 if n >= 16 else 12 if n >= 12 else 8 if n >= 8 else 6 if n >= 6 else 4 if n >= 4 else 2 if n >= 2 else 0
+    queue = []                                     # issue order: ("dma", step) / ("st", item)
+    d_idx = 0
+
+    def issue():
+        nonlocal d_idx
+        queue.extend([("dma", d_idx)] * DPW)
+        d_idx += 1
+    for _ in range(NST - 1):
+        issue()
+    st_age, st_cnt, out, c_idx = NST, 0, [], 0
+    for item in range(n_items):
+        for k in range(ksteps):
+            last = k == ksteps - 1
+            pend = st_cnt if st_age <= NST - 2 - (1 if late else 0) else 0
+            allowed = floor((NST - 2) * DPW + pend)
+            pos = max(i for i, op in enumerate(queue) if op == ("dma", c_idx))
+            out.append((c_idx, len(queue) - 1 - pos, allowed))
+            if not late:
+                issue()
+            c_idx += 1
+            st_age += 1
+            if last:
+                queue.extend([("st", item)] * stores_per_item)
+                st_age, st_cnt = 0, stores_per_item
+            if late:
+                issue()
+    return out
+
+
+@pytest.mark.parametrize("bn,nst", [(256, 3), (128, 4), (64, 4)])
+def test_pointwise_counted_vmcnt_never_lets_the_awaited_dma_stay_in_flight(bn, nst):
+    """the waves that issue their DMA AFTER the epilogue stores (waves 4-7) must stop counting those stores as younger
+    one K-step earlier than waves 0-3.  Replays both issue orders for every tile width and K depth the launcher uses."""
+    dpw = 2 + bn // 64
+    npt = {256: 4, 128: 2, 64: 1}[bn]
+    for late in (False, True):
+        for ksteps in (1, 2, 3, 4, 5, 9, 36):
+            for op_idx, younger, allowed in _replay_pointwise_waits(nst, dpw, ksteps, 6, 2 * npt, late):
+                assert allowed <= younger, (bn, nst, late, ksteps, op_idx, younger, allowed)

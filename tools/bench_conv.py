@@ -141,10 +141,13 @@ def main():
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--which", default="fwd,dgrad,wgrad")
     ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=0, help="override N of every shape (the per-rank shapes of the strong-scaling series)")
     args = ap.parse_args()
     shapes = {"s3fd": S3FD, "pb": PB, "small": SMALL, "big": BIG, "tail": TAIL, "dan": DANB}[args.set]
     if args.only:
         shapes = [s for s in shapes if s[0] in args.only.split(",")]
+    if args.batch:
+        shapes = [(s[0], args.batch) + tuple(s[2:]) for s in shapes]
     which = args.which.split(",")
     tot = {w: [0.0, 0.0] for w in which}
     for sh in shapes:
