@@ -54,6 +54,7 @@ SIGNATURES = {
     "danhip_relu_bits": [P, P, I64, I32, P],
     "danhip_conv2d_fwd_relu_bits": [DESC, P, P, P, P, P, P, P, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
+    "danhip_conv2d_bwd_weight_ws": [DESC, P, P, P, P, I32, P, ctypes.c_size_t, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
     "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
@@ -136,6 +137,8 @@ def lib():
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.argtypes = []
+        L.danhip_conv2d_bwd_weight_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_conv2d_bwd_weight_workspace_bytes.argtypes = [DESC]
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
         L.danhip_conv2d_fwd_emits_bits.restype = ctypes.c_int

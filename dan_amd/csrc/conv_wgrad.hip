@@ -239,8 +239,19 @@ extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d)
   return "conv_wgrad_kernel<128, 128, 2>";
 }
 
+extern "C" size_t danhip_conv2d_bwd_weight_workspace_bytes(const danhip_conv_desc* d) {
+  if (!d) return 0;
+  static const int mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();      // 0: always the atomic epilogue (A/B)
+  return mode ? danhip_wgrad_rows_workspace_bytes(d) : 0;
+}
+
 extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
                                         int32_t cin_real, void* stream) {
+  return danhip_conv2d_bwd_weight_ws(d, x, dy, dw_hwio, db, cin_real, nullptr, 0, stream);
+}
+
+extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                           int32_t cin_real, void* ws, size_t ws_bytes, void* stream) {
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
@@ -250,7 +261,7 @@ extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_
     DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
   }
   {
-    const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
+    const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
     if (hr <= 0) return hr;
     const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
     if (pr <= 0) return pr;

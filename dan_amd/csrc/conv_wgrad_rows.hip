@@ -41,6 +41,8 @@ struct WgRowsArgs {
   int tiles_x, total_rows, rows_per_split;
   int ci_tiles, co_tiles, xcd_grouped;
   int ablate;          // timing experiments only (DANHIP_WGRAD_ABLATE=1): skip the epilogue's atomics
+  float* slab;         // optional workspace: every block stores its partial tile here (plain 16-byte stores) and wg_rows_reduce_kernel combines
+  int splits;
   FastDiv div_tx, div_h, div_ci, div_pairs;
 };
 
@@ -342,6 +344,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     return;
   }
   // ---- epilogue: lane holds dW[tap][ci = ci0 + wci*16 + g*4 + r][co = co0 + wco*NO*16 + o*16 + (lane & 15)]
+  // Slab form (a.slab): the block's partial tile goes out as 9 * NO fully coalesced 1 KiB-per-wave stores in register order
+  // ([t * NO + o][wave][lane] float4) and wg_rows_reduce_kernel sums the splits and applies the HWIO permutation.  Plain stores run at
+  // ~6 TB/s; the same bytes as 256-byte float atomics at ~1.3 TB/s (MI355X_MICROARCH.md): with every block ending at the same time the
+  // atomic tail was 50 us of a 100 us launch at 2 images per GPU (profiles/r3/README.md).
+  if (a.slab) {
+    f32x4* dst = reinterpret_cast<f32x4*>(a.slab) + (size_t)blockIdx.x * (9 * NO * 512) + wave * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) __builtin_nontemporal_store(acc[t][o], dst + (t * NO + o) * 512);
+    if (do_bias) {
+      const int co = co0 + wco * NO * 16 + wci * 16 + (lane & 15);
+      if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, accb[0]);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -357,6 +375,41 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   if (do_bias) {                                      // rows 0..15 of accb are identical: lanes 0..15 (row 0) deliver
     const int co = co0 + wco * NO * 16 + wci * 16 + (lane & 15);
     if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, accb[0]);
+  }
+}
+
+// Second pass of the slab form: one thread per float4 of a (ci, co) tile sums it over the splits and adds the four values (four
+// consecutive ci of one co) into the HWIO gradient.  Slot -> element as in the kernel above: q = (t * NO + o) * 512 + wave * 64 + lane.
+template <int COT>
+__global__ __launch_bounds__(256) void wg_rows_reduce_kernel(const WgRowsArgs a) {
+  constexpr int NO = COT / 32, TILE = 9 * NO * 512;
+  const int pairs = a.ci_tiles * a.co_tiles;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= pairs * TILE) return;
+  const int pair = gid / TILE, q = gid - pair * TILE;
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.slab) + q;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  auto blk = [&](int split) -> size_t {             // the block that computed (split, pair): inverse of the kernel's mapping
+    return a.xcd_grouped ? (size_t)(((split >> 3) * pairs + pair) * 8 + (split & 7)) : (size_t)(split * pairs + pair);
+  };
+  int sp = 0;
+  for (; sp + 4 <= a.splits; sp += 4) {
+    const f32x4 v0 = __builtin_nontemporal_load(src + blk(sp) * TILE), v1 = __builtin_nontemporal_load(src + blk(sp + 1) * TILE);
+    const f32x4 v2 = __builtin_nontemporal_load(src + blk(sp + 2) * TILE), v3 = __builtin_nontemporal_load(src + blk(sp + 3) * TILE);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; sp < a.splits; ++sp) s0 += __builtin_nontemporal_load(src + blk(sp) * TILE);
+  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  const int to = q >> 9, wave = (q >> 6) & 7, lane = q & 63;
+  const int t = to / NO, o = to - t * NO;
+  const int wci = wave & 3, wco = wave >> 2, g = lane >> 4;
+  const int co_tile = pair / a.ci_tiles, ci_tile = pair - co_tile * a.ci_tiles;
+  const int co = co_tile * COT + wco * NO * 16 + o * 16 + (lane & 15);
+  if (co >= a.Cout) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ci = ci_tile * 64 + wci * 16 + g * 4 + r;
+    if (ci < a.cin_real) a.dw[(size_t)(t * a.cin_real + ci) * a.Cout + co] += sum[r];
   }
 }
 
@@ -389,8 +442,15 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
   static const int ablate = [] { const char* e = getenv("DANHIP_WGRAD_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
+  a.splits = splits;
+  if (a.slab && splits < 2) a.slab = nullptr;         // a single split: nothing to combine, straight into dw
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
+  if (a.slab) {
+    const int threads = pairs * 9 * (COT / 32) * 512;
+    hipLaunchKernelGGL((wg_rows_reduce_kernel<COT>), dim3((threads + 255) / 256), dim3(256), 0, s, a);
+    DH_LAUNCH_CHECK();
+  }
   return DANHIP_OK;
 }
 
@@ -412,8 +472,17 @@ const char* danhip_wgrad_rows_label(const danhip_conv_desc* d) {
   return wg_rows_cot(d) == 128 ? "conv_wgrad_rows_kernel<128>" : "conv_wgrad_rows_kernel<64>";
 }
 
+// Bytes of the partial-tile workspace the slab form needs for this descriptor (one register tile per workgroup, at most one workgroup
+// per CU); 0 when the row-streaming kernel does not take the shape.
+size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d) {
+  if (!wg_rows_eligible(d)) return 0;
+  const int cot = wg_rows_cot(d);
+  return (size_t)wr_cu_count() * 9 * (cot / 32) * 512 * 16;
+}
+
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
-int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s) {
+int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
+                             void* ws, size_t ws_bytes) {
   if (!wg_rows_eligible(d)) return 1;
   const int co8 = (d->Cout + 7) / 8 * 8;
   WgRowsArgs a{};
@@ -423,5 +492,6 @@ int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const b
   a.total_rows = d->N * a.tiles_x * d->H;
   a.div_tx = make_fastdiv(a.tiles_x);
   a.div_h = make_fastdiv(d->H);
+  a.slab = (ws && ws_bytes >= danhip_wgrad_rows_workspace_bytes(d)) ? reinterpret_cast<float*>(ws) : nullptr;
   return wg_rows_cot(d) == 128 ? launch_wg_rows<128>(a, s) : launch_wg_rows<64>(a, s);
 }

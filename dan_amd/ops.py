@@ -388,22 +388,26 @@ class _Conv2d(torch.autograd.Function):
         if need_dw:
             sink = _grad_sink(wp) if wp is not None else None
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
+            # split partial sums as plain stores into a scratch slab + a combine pass, where the library's kernel for this shape offers it
+            nws = _lib.lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(nws, dtype=torch.uint8, device=g.device) if nws else None
             if _WGRAD["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
                 side = _WGRAD["side"]
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 side.wait_event(ev)
                 e0 = _prof_begin(side)                  # (explicit stream handle: no stream-context switch per layer on the host)
-                call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
-                     ctypes.c_void_p(side.cuda_stream))
+                call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
+                     ptr(ws), nws, ctypes.c_void_p(side.cuda_stream))
                 _prof_end(e0, d, 2, side)
                 if GRAD_READY_HOOK is not None and wp is not None:
                     GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
-                _WGRAD["keep"].append((g, x))
+                _WGRAD["keep"].append((g, x, ws))
                 hooked = True
             else:
                 e0 = _prof_begin()
-                call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real, stream())
+                call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
+                     ptr(ws), nws, stream())
                 _prof_end(e0, d, 2)
             if sink is not None:
                 dw = None

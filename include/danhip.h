@@ -117,6 +117,12 @@ int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, c
  * cin_real: number of leading input channels that exist in dw (dw is [kh,kw,cin_real,Cout]). */
 int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
                              int32_t cin_real, void* stream);
+/* The same with a caller-provided scratch buffer: where danhip_conv2d_bwd_weight_workspace_bytes(d) > 0 and `ws` holds at least that many
+ * bytes, the split partial sums leave the kernel as plain coalesced stores and a second small kernel combines them into dw_hwio (+=),
+ * instead of fp32 atomics (4-5x the bytes per second; the atomic tail dominated the launch at <= 4 images per GPU).  ws == NULL: atomics. */
+size_t danhip_conv2d_bwd_weight_workspace_bytes(const danhip_conv_desc* d);
+int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                int32_t cin_real, void* ws, size_t ws_bytes, void* stream);
 
 /* In place: dy *= (y > 0) (ReLU backward) when y != NULL; db[c] += sum over pixels of the masked dy.
  * dy bf16 [M, C]; y bf16 [M, C] or NULL; db fp32 [C] or NULL. */

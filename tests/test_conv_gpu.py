@@ -466,3 +466,44 @@ def test_forward_kernel_writes_the_relu_bit_masks(shape, pool, dev):
     if res:
         assert torch.equal(res[True][0], res[False][0])
         assert (res[True][1] - res[False][1]).abs().max().item() <= 1e-4 * res[False][1].abs().max().item()      # (fp32 atomics order)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 128, 3, 3, 1), (3, 40, 40, 256, 256, 3, 3, 1), (2, 16, 32, 256, 8, 3, 3, 1), (2, 32, 64, 256, 72, 3, 3, 1),
+                                   (5, 56, 96, 128, 128, 3, 3, 1), (1, 33, 47, 64, 64, 3, 3, 1)])
+def test_weight_gradient_slab_form_equals_the_atomic_form(shape, dev):
+    """danhip_conv2d_bwd_weight_ws (partial tiles as plain stores + a combine pass) against danhip_conv2d_bwd_weight (fp32 atomics): same
+    += semantics on a pre-filled gradient, equal up to fp32 summation order; both against the oracle convolution's weight gradient."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, lib, ptr, stream
+    N, H, W, Cin, Cout, kh, kw, s = shape
+    x, w, b, _ = _mk(shape, 21)
+    co8 = (Cout + 7) // 8 * 8
+    g = torch.Generator().manual_seed(22)
+    dy = torch.zeros((N, H, W, co8), dtype=torch.bfloat16)
+    dy[..., :Cout] = torch.randn((N, H, W, Cout), generator=g).to(torch.bfloat16)
+    d = ops._desc(N, H, W, Cin, Cout, kh, kw, s)
+    nws = lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+    assert nws > 0, "the row-streaming kernel takes this shape"
+    xd, dyd = x.to(dev), dy.to(dev)
+    pre = torch.randn((kh, kw, Cin, Cout), generator=g).to(dev)
+    dw_a, dw_s = pre.clone(), pre.clone()
+    db_a, db_s = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    ws = torch.full((nws,), 0x7f, dtype=torch.uint8, device=dev)               # garbage in the scratch buffer must not matter
+    call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(xd), ptr(dyd), ptr(dw_a), ptr(db_a), Cin, stream())
+    call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(xd), ptr(dyd), ptr(dw_s), ptr(db_s), Cin, ptr(ws), nws, stream())
+    torch.cuda.synchronize()
+    xr = x.float()
+    wr = w.clone().requires_grad_(True)
+    ref = T.conv2d_same(xr, wr, None, stride=s)
+    ref.backward(dy[..., :Cout].float())
+    want = wr.grad + pre.cpu()
+    scale = wr.grad.abs().max().item()
+    assert (dw_s.cpu() - want).abs().max().item() <= 2.0 ** -6 * scale + 2e-3
+    assert (dw_s - dw_a).abs().max().item() <= 1e-4 * scale + 1e-5
+    assert (db_s - db_a).abs().max().item() <= 1e-4 * db_a.abs().max().item() + 1e-5
+    # a buffer that is too small is refused in favour of the atomic form, never overrun
+    dw_t = pre.clone()
+    call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(xd), ptr(dyd), ptr(dw_t), None, Cin, ptr(ws), nws // 2, stream())
+    torch.cuda.synchronize()
+    assert (dw_t - dw_a).abs().max().item() <= 1e-4 * scale + 1e-5

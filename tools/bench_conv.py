@@ -88,8 +88,11 @@ def run(shape, iters, which, check):
     def dgrad_acc():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 1, stream())
 
+    nws = lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+
     def wgrad():
-        call("danhip_conv2d_bwd_weight", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, stream())
+        call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, ptr(ws) if nws else None, nws, stream())
 
     fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad, "dgrad_nomask": dgrad_nomask, "dgrad_acc": dgrad_acc, "dgrad_bits": dgrad_bits,
            "relu_bits": relu_bits}
