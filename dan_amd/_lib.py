@@ -43,6 +43,7 @@ SIGNATURES = {
     "danhip_pack_entry_init": [ctypes.POINTER(PackEntry), DESC, P, I32, P, P, I32, ctypes.POINTER(ctypes.c_int32)],
     "danhip_pack_conv_weights_batched": [P, I32, I32, P],
     "danhip_conv2d_fwd": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P],
+    "danhip_conv2d_fwd_ws": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P, ctypes.c_size_t, P],
     "danhip_conv2d_fwd_f32": [DESC, P, P, P, P, ctypes.c_int, P, P],
     "danhip_maxpool2x2_fwd_f32": [P, P, I32, I32, I32, I32, P],
     "danhip_l2norm_fwd_f32": [P, P, P, I64, I32, P],
@@ -50,6 +51,7 @@ SIGNATURES = {
     "danhip_avgpool2x2s1_same_fwd_f32": [P, P, I32, I32, I32, I32, P],
     "danhip_deform_sample_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
+    "danhip_conv2d_bwd_data_ws": [DESC, P, P, P, P, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_conv2d_bwd_data_bits": [DESC, P, P, P, P, ctypes.c_int, P],
     "danhip_relu_bits": [P, P, I64, I32, P],
     "danhip_conv2d_fwd_relu_bits": [DESC, P, P, P, P, P, P, P, P],
@@ -137,6 +139,8 @@ def lib():
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.argtypes = []
+        L.danhip_conv2d_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_conv2d_workspace_bytes.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_weight_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_conv2d_bwd_weight_workspace_bytes.argtypes = [DESC]
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t

@@ -20,6 +20,8 @@ struct ConvArgs {
   FastDiv div_wo, div_howo, div_c, div_kw;
   int relu, out_f32, accumulate;
   int dshift;    // log2(dstride)
+  float* splitk_ws;      // split-K (conv_igemm.hip, maps too small to fill the chip): fp32 partial outputs [splits][M][Co]; null = no split
+  int splits, kt_per_split;
   int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
 };
 

@@ -14,6 +14,8 @@
 //
 // Pipeline: two LDS stages; tile k+1's DMA is issued before tile k's MFMAs (one barrier per K tile);
 // two workgroups per CU overlap each other's barrier stalls.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace {
@@ -70,6 +72,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_danhip_zero_page);
 
+  // split-K: blockIdx.z owns the K tiles [kt_lo, kt_hi) and stores raw fp32 partial sums (conv_splitk_finish_kernel applies the epilogue)
+  const int kt_lo = a.splitk_ws ? (int)blockIdx.z * a.kt_per_split : 0;
+  const int kt_hi = a.splitk_ws ? min(a.ktiles, kt_lo + a.kt_per_split) : a.ktiles;
+
   // FAST path tap walker (uniform): tile kt covers channels [c0, c0+64) of tap (ti, tj)
   int ti = 0, tj = 0, c0 = 0;
 
@@ -104,6 +110,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   }
   int tap = 0;
+  if (FAST && kt_lo > 0) {                               // (C % 64 == 0: a K tile never straddles two taps)
+    tap = (int)fdiv((unsigned)(kt_lo * 64), a.div_c);
+    c0 = kt_lo * 64 - tap * a.C;
+    ti = (int)fdiv((unsigned)tap, a.div_kw);
+    tj = tap - ti * a.kw;
+  }
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE;
@@ -175,11 +187,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
   const int frow = lane & 15, fq = lane >> 4;
 
-  stage(0, 0);
-  for (int kt = 0; kt < a.ktiles; ++kt) {
+  stage(kt_lo, kt_lo & 1);
+  for (int kt = kt_lo; kt < kt_hi; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // tile kt landed; everyone is done reading the other stage
-    if (kt + 1 < a.ktiles) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < kt_hi) stage(kt + 1, (kt + 1) & 1);
     const char* sA = smem + (kt & 1) * STAGE;
     const char* sB = sA + BM * 128;
 #pragma unroll
@@ -204,6 +216,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   // ---- epilogue: lane holds out[pixel = p*16 + (lane&15)][co = c*16 + (lane>>4)*4 + 0..3]
+  if (a.splitk_ws) {
+    float* slab = a.splitk_ws + (size_t)blockIdx.z * (size_t)a.M * a.Co;
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const int m = m0 + wm * TP + p * 16 + frow;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int co = n0 + wn * TC + c * 16 + fq * 4;
+        if (co >= a.Co) continue;
+        float* o = slab + (size_t)m * a.Co + co;
+        if ((co + 4 <= a.Co) && ((a.Co & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(o) = acc[c][p];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (co + r < a.Co) o[r] = acc[c][p][r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int p = 0; p < NPT; ++p) {
     const int m = m0 + wm * TP + p * 16 + frow;
@@ -275,6 +308,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+// Second pass of a split-K launch: one thread per 4 output channels of a pixel sums the partial outputs and applies the epilogue
+// (bias, ReLU, mask, residual, accumulate, output type) exactly as the single-pass kernels do (conv_store4).
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs a) {
+  const int cq = (a.Co + 3) >> 2;
+  const long total = (long)a.M * cq;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const long m = gid / cq;
+  const int co = (int)(gid - m * cq) * 4;
+  const size_t slab = (size_t)a.M * a.Co;
+  const float* src = a.splitk_ws + (size_t)m * a.Co + co;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((a.Co & 3) == 0) {
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int z = 0;
+    for (; z + 2 <= a.splits; z += 2) {
+      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * slab);
+      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(z + 1) * slab);
+    }
+    if (z < a.splits) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)z * slab);
+    s0 += s1;
+    v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+  } else {
+    for (int z = 0; z < a.splits; ++z)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (co + r < a.Co) v[r] += src[(size_t)z * slab + r];
+  }
+  conv_store4(a, v, (size_t)m, co);
+}
+
 // Tile selection: output-channel tile BN from the (padded) channel count.
 inline int pick_bn(int co) {
   if (co % 128 == 0) return 128;
@@ -284,9 +347,63 @@ inline int pick_bn(int co) {
   return 64;
 }
 
+int igemm_cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+// Pixel tile of the flat-M configuration launch_conv picks for these args.
+inline int igemm_bm(const ConvArgs& a) {
+  const int bn = pick_bn(a.Co);
+  if (bn == 128) return 128;
+  if (bn == 16) return a.M <= 256 * 128 ? 64 : 256;
+  return 256;
+}
+
+// Split-K plan: maps with too few output tiles to fill the chip (the 40x40 ... 5x5 levels, every level at 2-4 images per GPU) walk K
+// (up to 9 taps x 1024 channels = 144 tiles) serially in a handful of workgroups; splitting K over blockIdx.z puts ~2 workgroups on every
+// CU.  Returns the number of splits (1 = do not split) and the K tiles per split.
+int plan_splitk(const ConvArgs& a, int* kt_per_split) {
+  *kt_per_split = a.ktiles;
+  static const int mode = [] { const char* e = getenv("DANHIP_SPLITK"); return e ? atoi(e) : 1; }();        // 0: off (A/B)
+  if (!mode || a.pool_y || a.bits_out || a.mask_bits) return 1;
+  const int bm = igemm_bm(a), bn = pick_bn(a.Co);
+  const long tiles = (long)cdiv(a.M, bm) * cdiv(a.Co, bn);
+  const int cus = igemm_cu_count();
+  // thin heads (16-channel tiles): a workgroup's K tile is one or two MFMAs per wave, eight workgroups fit a CU and the serial K walk
+  // (72-144 tiles at ~0.6 us) is pure latency: aim for 8 workgroups per CU instead of 2
+  const long target = (bn == 16 ? 8l : 2l) * cus;
+  if (tiles * 2 > target || a.ktiles < 8) return 1;
+  int splits = (int)((target + tiles - 1) / tiles);
+  if (splits > a.ktiles / 4) splits = a.ktiles / 4;
+  if (splits > 36) splits = 36;
+  if (splits < 2) return 1;
+  const int per = (a.ktiles + splits - 1) / splits;
+  *kt_per_split = per;
+  return (a.ktiles + per - 1) / per;
+}
+
+// true when a split-K flat-M launch should take precedence over the streaming kernels (their 128-pixel items would not fill the chip)
+bool wants_splitk(const ConvArgs& a) {
+  int per;
+  if (plan_splitk(a, &per) < 2) return false;
+  return (long)cdiv(a.M, 128) * cdiv(a.Co, 128) * 2 <= igemm_cu_count();
+}
+bool prefer_splitk(const ConvArgs& a) { return a.splitk_ws && wants_splitk(a); }
+
 template <int BM, int BN, int WN_WAVES>
-int launch_cfg(const ConvArgs& a, bool fast, hipStream_t s) {
-  dim3 grid((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.Co, BN));
+int launch_cfg(const ConvArgs& a0, bool fast, hipStream_t s) {
+  ConvArgs a = a0;
+  int per = a.ktiles;
+  const int splits = a.splitk_ws ? plan_splitk(a, &per) : 1;
+  if (splits < 2) a.splitk_ws = nullptr;
+  a.splits = splits; a.kt_per_split = per;
+  dim3 grid((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.Co, BN), (unsigned)splits);
   const size_t lds = 2 * (size_t)(BM + BN) * 128;
   static const bool attr_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WN_WAVES, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -299,6 +416,11 @@ int launch_cfg(const ConvArgs& a, bool fast, hipStream_t s) {
   else
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WN_WAVES, false>), grid, dim3(256), lds, s, a);
   DH_LAUNCH_CHECK();
+  if (a.splitk_ws) {
+    const long threads = (long)a.M * ((a.Co + 3) / 4);
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    DH_LAUNCH_CHECK();
+  }
   return DANHIP_OK;
 }
 
@@ -307,10 +429,13 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (c8 <= 0) return c8;
   const int cr = danhip_launch_conv_c64(a, s);         // 3x3 / stride-1, 64 -> 64 channels: register-resident weights
   if (cr <= 0) return cr;
-  const int hr = danhip_launch_conv_halo(a, s);        // 3x3 / stride-1 on large maps: halo-reuse kernel
-  if (hr <= 0) return hr;
-  const int pr = danhip_launch_conv_pointwise(a, s);   // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
-  if (pr <= 0) return pr;
+  const bool sk = prefer_splitk(a);                    // too few tiles for the persistent kernels: split K over workgroups instead
+  if (!sk) {
+    const int hr = danhip_launch_conv_halo(a, s);      // 3x3 / stride-1 on large maps: halo-reuse kernel
+    if (hr <= 0) return hr;
+    const int pr = danhip_launch_conv_pointwise(a, s); // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
+    if (pr <= 0) return pr;
+  }
   const bool fast = (a.C % 64 == 0);
   switch (pick_bn(a.Co)) {
     case 128: return launch_cfg<128, 128, 2>(a, fast, s);
@@ -499,11 +624,12 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     if (which == 0 && danhip_conv_c8_label(a)) return danhip_conv_c8_label(a);
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;
-    const char* hl = danhip_conv_halo_label(a, which == 1);
+    const bool sk = wants_splitk(a);                   // (callers that pass the scratch buffer: dan_amd.ops always does)
+    const char* hl = sk ? nullptr : danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
     if (which == 1) { if (masked) a.mask = &dummy_mask; }
     else { static const float one = 1.f; a.bias = &one; }
-    const char* pl = danhip_conv_pointwise_label(a, which == 1);
+    const char* pl = sk ? nullptr : danhip_conv_pointwise_label(a, which == 1);
     if (pl) return pl;
   }
   const bool fast = cin % 64 == 0;
@@ -560,8 +686,25 @@ extern "C" int danhip_pack_conv_weights_batched(const danhip_pack_entry* table_d
   return DANHIP_OK;
 }
 
+// Scratch bytes a forward (which = 0) / data-gradient (which = 1) call of this descriptor can use (split-K partial outputs); 0 = none.
+extern "C" size_t danhip_conv2d_workspace_bytes(const danhip_conv_desc* d, int which) {
+  if (!d || check_desc(d) != DANHIP_OK) return 0;
+  if (which == 1 && d->stride != 1 && (d->stride & (d->stride - 1)) != 0) return 0;
+  ConvArgs a = which == 0 ? fwd_args(d) : bwd_args(d);
+  int per;
+  const int splits = plan_splitk(a, &per);
+  if (splits < 2) return 0;
+  // shapes the halo / 64->64 / first-layer kernels take never come here with few tiles, except at tiny batch: let them split too
+  return (size_t)splits * (size_t)a.M * (size_t)a.Co * sizeof(float);
+}
+
 extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, void* y,
                                  int out_dtype, int relu, const uint16_t* residual, void* stream) {
+  return danhip_conv2d_fwd_ws(d, x, wf_packed, bias, y, out_dtype, relu, residual, nullptr, 0, stream);
+}
+
+extern "C" int danhip_conv2d_fwd_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, void* y,
+                                    int out_dtype, int relu, const uint16_t* residual, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd: null pointer");
@@ -571,6 +714,7 @@ extern "C" int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, c
   ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
   a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
+  if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 0) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
   return launch_conv(a, (hipStream_t)stream);
 }
 
@@ -674,6 +818,11 @@ __global__ void conv_bwd_data_strided_kernel(const bf16_t* __restrict__ dy, cons
 
 extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
                                       uint16_t* dx, int accumulate, void* stream) {
+  return danhip_conv2d_bwd_data_ws(d, dy, wb_packed, relu_mask, dx, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int danhip_conv2d_bwd_data_ws(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
+                                         uint16_t* dx, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   DH_REQUIRE(dy && wb_packed && dx, DANHIP_EINVAL, "conv2d_bwd_data: null pointer");
@@ -693,6 +842,7 @@ extern "C" int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t*
   ConvArgs a = bwd_args(d);
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = relu_mask; a.resid = nullptr; a.y = dx;
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
+  if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 1) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
   return launch_conv(a, (hipStream_t)stream);
 }
 

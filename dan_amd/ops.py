@@ -279,6 +279,19 @@ def relu_bits(x, holder):
     return holder[0]
 
 
+USE_SPLITK = True           # False (tests): never pass the scratch buffer, i.e. every shape runs on its single-pass kernel
+
+
+def _conv_scratch(d, which, dev):
+    """Scratch buffer for a split-K launch of this forward (which = 0) / data-gradient (which = 1) call, or (None, 0): maps with too few
+    output tiles to fill the chip (danhip_conv2d_workspace_bytes).  Only small problems are worth asking the library about."""
+    M, co = (d.N * d.Ho * d.Wo, d.Cout) if which == 0 else (d.N * d.H * d.W, d.Cin)
+    if not USE_SPLITK or -(-M // 128) * -(-co // 128) > 160:
+        return None, 0
+    n = _lib.lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), which)
+    return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
@@ -310,8 +323,9 @@ class _Conv2d(torch.autograd.Function):
             call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
             pool_out.append(pooled)
         else:
-            call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
-                 F32 if out_f32 else BF16, int(relu), ptr(residual), stream())
+            ws, nws = _conv_scratch(d, 0, x.device)
+            call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
+                 F32 if out_f32 else BF16, int(relu), ptr(residual), ptr(ws), nws, stream())
         _prof_end(e0, d, 4 if pool_out is not None else 0)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
         ctx.xslot, ctx.yslot, ctx.xbits = xslot, yslot, xbits
@@ -376,12 +390,15 @@ class _Conv2d(torch.autograd.Function):
                     # the kernel keeps its tile's mask in LDS as bits: 1/16 of the bytes, and not a load in its epilogue
                     call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(g), ptr(wb), ptr(relu_bits(x, ctx.xbits)), ptr(buf), acc, stream())
                 else:
-                    call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, stream())
+                    ws, nws = _conv_scratch(d, 1, g.device)
+                    call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, ptr(ws), nws,
+                         stream())
                 _prof_end(e0, d, 5 if xs.is_relu else 1)
             else:
                 dx = torch.empty_like(x)
                 e0 = _prof_begin()
-                call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, stream())
+                ws, nws = _conv_scratch(d, 1, g.device)
+                call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, ptr(ws), nws, stream())
                 _prof_end(e0, d, 1)
         dw = None
         hooked = False

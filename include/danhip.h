@@ -98,6 +98,17 @@ int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const u
  * that produced x).  dy bf16 [N,Ho,Wo,Cout_pad8]; dx bf16 [N,H,W,Cin]. accumulate: dx += instead of = . */
 int danhip_conv2d_bwd_data(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed,
                            const uint16_t* relu_mask, uint16_t* dx, int accumulate, void* stream);
+
+/* The same two calls with a caller-provided scratch buffer.  Maps with too few output tiles to fill the chip (the 40x40 ... 5x5 pyramid
+ * levels; every level at 2-4 images per GPU, the per-rank shape of an 8-GPU strong-scaling run) otherwise walk K = kh*kw*Cin serially in a
+ * handful of workgroups: with >= danhip_conv2d_workspace_bytes(d, which) bytes (which: 0 forward, 1 data gradient; 0 = the shape does not
+ * split) K is split over workgroups, the fp32 partial outputs go to the scratch buffer and a second small kernel sums them and applies
+ * the epilogue.  Results equal the single-pass form up to fp32 summation order.  ws == NULL behaves as the plain call. */
+size_t danhip_conv2d_workspace_bytes(const danhip_conv_desc* d, int which);
+int danhip_conv2d_fwd_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, void* y,
+                         int out_dtype, int relu, const uint16_t* residual, void* ws, size_t ws_bytes, void* stream);
+int danhip_conv2d_bwd_data_ws(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
+                              uint16_t* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* The ReLU mask as one bit per element: bits[m][j] bit i = x[m][8j + i] > 0, rows of C/8 bytes (C % 8 == 0).  A data-gradient kernel that
  * keeps its tile's mask in LDS reads 1/16 of the bytes, and not from its epilogue: danhip_conv2d_bwd_data_takes_bits(d) says whether the
  * kernel chosen for descriptor d does (then call danhip_conv2d_bwd_data_bits with the bits of the conv's INPUT activation). */

@@ -51,9 +51,19 @@ def _tol(ref):
     return 2.0 ** -7 * ref.abs().max().item() + 1e-3
 
 
+@pytest.fixture(params=[True, False], ids=["splitk", "singlepass"])
+def splitk(request):
+    """Small maps run twice: with the scratch buffer (split-K flat-M kernel + finish pass) and without it (the halo / streaming / flat-M
+    kernel of the shape in one pass, as every larger map runs)."""
+    from dan_amd import ops
+    old, ops.USE_SPLITK = ops.USE_SPLITK, request.param
+    yield request.param
+    ops.USE_SPLITK = old
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("relu", [False, True])
-def test_conv_forward(shape, relu, dev):
+def test_conv_forward(shape, relu, dev, splitk):
     from dan_amd import ops
     x, w, b, s = _mk(shape, 1)
     ref = T.conv2d_same(x.float(), w, b, stride=s, relu=relu)
@@ -68,7 +78,7 @@ def test_conv_forward(shape, relu, dev):
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv_backward(shape, dev):
+def test_conv_backward(shape, dev, splitk):
     from dan_amd import ops
     x, w, b, s = _mk(shape, 2)
     Cout = shape[4]
@@ -507,3 +517,44 @@ def test_weight_gradient_slab_form_equals_the_atomic_form(shape, dev):
     call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(xd), ptr(dyd), ptr(dw_t), None, Cin, ptr(ws), nws // 2, stream())
     torch.cuda.synchronize()
     assert (dw_t - dw_a).abs().max().item() <= 1e-4 * scale + 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 20, 512, 1024, 3, 3, 1), (2, 20, 20, 1024, 1024, 1, 1, 1), (2, 40, 40, 512, 512, 3, 3, 1), (2, 20, 20, 256, 512, 3, 3, 2),
+                                   (2, 40, 40, 512, 6, 3, 3, 1), (2, 5, 5, 256, 6, 3, 3, 1), (1, 80, 80, 512, 256, 3, 3, 1), (2, 10, 10, 128, 256, 3, 3, 2),
+                                   (3, 37, 41, 192, 320, 3, 3, 1), (2, 24, 40, 72, 128, 3, 3, 1)])
+def test_splitk_form_equals_the_single_pass_form(shape, dev):
+    """danhip_conv2d_{fwd,bwd_data}_ws with the scratch buffer (K split over workgroups + finish pass) against the same call without it, on the
+    per-rank shapes of the strong-scaling series (2 images per GPU): forward with bias / ReLU (16-bit and fp32 outputs), data gradient with
+    mask and accumulate.  Equal up to fp32 summation order and one 16-bit rounding."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import BF16, F32, call, lib, ptr, stream
+    N, H, W, Cin, Cout, kh, kw, s = shape
+    x, w, b, _ = _mk(shape, 31)
+    d = ops._desc(N, H, W, Cin, Cout, kh, kw, s)
+    xd, bd = x.to(dev), b.to(dev)
+    wf, wb = ops.pack_conv_weight(d, w.to(dev), need_bwd=True)
+    n0, n1 = lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), 0), lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), 1)
+    assert n0 > 0 or n1 > 0, "neither direction of this shape splits"
+    ws = torch.full((max(n0, n1, 16),), 0x7f, dtype=torch.uint8, device=dev)
+    co8 = (Cout + 7) // 8 * 8
+    for out_f32 in ([False, True] if Cout % 8 == 0 else [True]):
+        y0 = torch.empty((N, d.Ho, d.Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+        y1 = torch.empty_like(y0)
+        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(xd), ptr(wf), ptr(bd), ptr(y0), F32 if out_f32 else BF16, 1, None, stream())
+        call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(xd), ptr(wf), ptr(bd), ptr(y1), F32 if out_f32 else BF16, 1, None, ptr(ws), n0, stream())
+        torch.cuda.synchronize()
+        tol = (1e-4 if out_f32 else 2.0 ** -7) * y0.float().abs().max().item() + 1e-5
+        assert (y0.float() - y1.float()).abs().max().item() <= tol, (shape, out_f32)
+    g = torch.Generator().manual_seed(32)
+    dy = torch.zeros((N, d.Ho, d.Wo, co8), dtype=torch.bfloat16)
+    dy[..., :Cout] = torch.randn((N, d.Ho, d.Wo, Cout), generator=g).to(torch.bfloat16)
+    dyd = dy.to(dev)
+    old = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).to(dev)
+    for mask, acc in ((None, 0), (xd, 0), (xd, 1)):
+        dx0, dx1 = old.clone(), old.clone()
+        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dyd), ptr(wb), ptr(mask), ptr(dx0), acc, stream())
+        call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(dyd), ptr(wb), ptr(mask), ptr(dx1), acc, ptr(ws), n1, stream())
+        torch.cuda.synchronize()
+        tol = 2.0 ** -7 * dx0.float().abs().max().item() + 1e-5
+        assert (dx0.float() - dx1.float()).abs().max().item() <= tol, (shape, mask is not None, acc)

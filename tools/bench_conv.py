@@ -68,11 +68,14 @@ def run(shape, iters, which, check):
     db = torch.zeros((Cout,), dtype=torch.float32, device=dev)
     flops = 2.0 * N * d.Ho * d.Wo * Cin * Cout * k * k
 
+    nwf, nwd = lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), 0), lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), 1)
+    wsf = torch.empty(max(nwf, nwd, 16), dtype=torch.uint8, device=dev)
+
     def fwd():
-        call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b), ptr(y), BF16, 1, None, stream())
+        call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b), ptr(y), BF16, 1, None, ptr(wsf) if nwf else None, nwf, stream())
 
     def dgrad():
-        call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 0, stream())
+        call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 0, ptr(wsf) if nwd else None, nwd, stream())
 
     def dgrad_nomask():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), None, ptr(dx), 0, stream())
