@@ -255,6 +255,9 @@ extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
+  // the kernels address both activations through raw buffer descriptors with a 32-bit byte count: 2^31 16-bit elements = 4 GiB would wrap to 0
+  DH_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * (int64_t)((d->Cout + 7) / 8 * 8) < (1ll << 31),
+             DANHIP_EINVAL, "conv2d_bwd_weight: tensor exceeds 2^31 elements (4 GiB): split the batch");
   {   // output size: TF 'same' (ceil(in / s); padding derived, more on the bottom / right) or 'valid' (floor((in - k) / s) + 1, no padding)
     const bool same = d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride;
     const bool valid = d->H >= d->kh && d->W >= d->kw && d->Ho == (d->H - d->kh) / d->stride + 1 && d->Wo == (d->W - d->kw) / d->stride + 1;

@@ -831,7 +831,11 @@ class _Concat(torch.autograd.Function):
         g = ctx.yslot.take() if ctx.yslot is not None else None
         premasked = ctx.all_relu and dy is None          # slot deliveries arrive multiplied by (y > 0) = every input's own mask
         if dy is not None:
-            g = dy.contiguous() if g is None else g.add_(dy)
+            dy = dy.contiguous()
+            if g is not None and g.shape[-1] != dy.shape[-1]:             # ragged output width: the slot carries the channel-padded layout
+                g[..., :dy.shape[-1]].add_(dy)
+            else:
+                g = dy if g is None else g.add_(dy)
         if g is None:
             return (None,) * (3 + len(ctx.widths))
         grads, c0 = [], 0
@@ -859,10 +863,11 @@ def concat(tensors):
     all_relu = all(s is not None and s.is_relu for s in slots)
     yslot = _new_slot(True)
     y = _Concat.apply(slots, yslot, all_relu, *tensors)
-    yslot.__init__(y, all_relu)
     if y.shape[-1] % 8 == 0:
+        yslot.__init__(y, all_relu)
         y._dh_slot = yslot
-    else:
+    else:                                                # ragged width: consumers deliver into the channel-padded layout (Cpad % 8 == 0)
+        yslot.__init__(y, all_relu, (y.shape[-1] + 7) // 8 * 8)
         y._dh_pslot = yslot
     return y
 

@@ -143,6 +143,9 @@ class DetectorTrainer(object):
     def train_step(self, images_u8, *targets):
         """One optimisation step on this rank's shard.  Returns the list of (name, weight, device 4-vector
         [ce_sum, n_selected, loc_sum, n_pos]) loss terms (no host sync).  After enable_graph() the step is one hipGraph launch."""
+        if self._graph is None and getattr(self, "_recapture", False):      # restore() dropped the captured step: capture again (same static buffers)
+            self._recapture = False
+            self._capture()
         if self._graph is not None:
             return self._graph_step(images_u8, *targets)
         return self._eager_step(images_u8, *targets)

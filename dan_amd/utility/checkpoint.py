@@ -471,6 +471,8 @@ def save_checkpoint(variables, prefix, model_scope, checksums=False, trainer=Non
         for n, v in _momentum_views(trainer).items():
             tensors[model_scope + "/" + n + "/Momentum"] = v.detach().cpu().contiguous().numpy()
         tensors["global_step"] = np.asarray(int(trainer.step_no), dtype=np.int64)
+        if getattr(trainer, "ls_state", None) is not None:       # fp16 build: dynamic loss scale {scale, clean steps} (not a reference variable)
+            tensors["danhip/loss_scale"] = trainer.ls_state[0:2].detach().cpu().numpy().astype(np.float32)
     write_checkpoint(prefix, tensors, checksums=checksums)
 
 
@@ -512,6 +514,13 @@ def restore_checkpoint(variables, checkpoint_path, model_scope, trainer=None, st
             restored.append("global_step")
         elif strict:
             raise CheckpointError("global_step missing in checkpoint %s" % checkpoint_path)
-        trainer._graph = None                    # a captured step holds the old learning rate: re-capture on demand
+        if getattr(trainer, "ls_state", None) is not None and reader.has_tensor("danhip/loss_scale"):      # optional: reference checkpoints lack it
+            ls = np.asarray(reader.get_tensor("danhip/loss_scale"), dtype=np.float32).reshape(-1)
+            with torch.no_grad():
+                trainer.ls_state[0:2].copy_(torch.from_numpy(ls[:2].copy()).to(trainer.ls_state.device))
+            restored.append("danhip/loss_scale")
+        if trainer._graph is not None:           # a captured step holds the old learning rate: the next train_step re-captures
+            trainer._graph = None
+            trainer._recapture = True
     _bump_weight_epoch()
     return restored

@@ -222,3 +222,19 @@ def test_pointwise_counted_vmcnt_never_lets_the_awaited_dma_stay_in_flight(bn, n
         for ksteps in (1, 2, 3, 4, 5, 9, 36):
             for op_idx, younger, allowed in _replay_pointwise_waits(nst, dpw, ksteps, 6, 2 * npt, late):
                 assert allowed <= younger, (bn, nst, late, ksteps, op_idx, younger, allowed)
+
+
+def test_four_gib_activations_are_refused_not_wrapped():
+    """The convolution kernels build raw buffer descriptors with a 32-bit byte count: a 16 x 1024 x 1024 x 128 16-bit tensor is exactly 4 GiB
+    and would wrap to a zero-length buffer.  Every entry point refuses it before any launch."""
+    from dan_amd import _lib
+    L = _lib.lib()
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.Ho, d.Wo = 16, 1024, 1024, 128, 128, 3, 3, 1, 1024, 1024
+    one = ctypes.c_void_p(16)                       # never dereferenced: the size check comes first
+    assert L.danhip_conv2d_fwd(ctypes.byref(d), one, one, None, one, 1, 0, None, None) == -1 and b"2^31" in L.danhip_last_error()
+    assert L.danhip_conv2d_bwd_data(ctypes.byref(d), one, one, None, one, 0, None) == -1 and b"2^31" in L.danhip_last_error()
+    assert L.danhip_conv2d_bwd_weight(ctypes.byref(d), one, one, one, None, 128, None) == -1 and b"2^31" in L.danhip_last_error()
+    d.N = 8                                          # the BASELINE per-GPU shard (batch 8 at 1024 x 1024) is 2 GiB: accepted by the check
+    r, c = ctypes.c_int64(), ctypes.c_int64()
+    assert L.danhip_conv_packed_dims(ctypes.byref(d), 0, ctypes.byref(r), ctypes.byref(c)) == 0

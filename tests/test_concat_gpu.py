@@ -91,3 +91,40 @@ def test_concat_add_avgpool_hand_off_equals_autograd(relu_input, dev):
         assert b.abs().max().item() > 0, k
         # the two routes sum the same bf16 terms in a different order: one bf16 rounding of the largest entry
         assert (a - b).norm().item() <= 2.0 ** -6 * b.norm().item() + 1e-6, (k, (a - b).norm().item(), b.norm().item())
+
+
+def test_ragged_concat_feeding_another_concat(dev):
+    """a concat whose width is not a multiple of 8 (16 + 11 = 27) owns a channel-padded gradient slot (32); a downstream concat
+    delivers into it and the ragged concat's backward hands its inputs their slices — same gradients as the autograd route."""
+    from dan_amd import ops
+    g = torch.Generator().manual_seed(9)
+    C = 16
+    shapes = {"a": (1, 1, C, 16), "b": (1, 1, C, 11), "c": (1, 1, C, 5), "o": (3, 3, 32, 8), "in": (3, 3, 8, C)}
+    ws = {}
+    for k, s in shapes.items():
+        ws[k] = (torch.randn(s, generator=g) * (2.0 / (s[0] * s[1] * s[2])) ** 0.5).to(dev).requires_grad_(True)
+        ws[k + "b"] = (0.1 * torch.randn(s[3], generator=g)).to(dev).requires_grad_(True)
+    x0 = _bf(torch.randn(2, 9, 13, 8, generator=g)).to(dev)
+    dy = _bf(torch.randn(2, 9, 13, 8, generator=g)).to(dev)
+    res = {}
+    for slots in (True, False):
+        ops.USE_SLOTS = slots
+        try:
+            for p in ws.values():
+                p.grad = None
+            x = ops.conv2d(x0, ws["in"], ws["inb"], relu=True)
+            a = ops.conv2d(x, ws["a"], ws["ab"], relu=True)
+            b = ops.conv2d(x, ws["b"], ws["bb"], relu=True)
+            c = ops.conv2d(x, ws["c"], ws["cb"], relu=False)
+            h = ops.concat([ops.concat([a, b]), c])                      # 27 (ragged) + 5 = 32
+            y = ops.conv2d(h, ws["o"], ws["ob"], relu=False)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res[slots] = ({k: p.grad.clone() for k, p in ws.items()}, y.detach().clone())
+        finally:
+            ops.USE_SLOTS = True
+    assert torch.equal(res[True][1], res[False][1])
+    for k in ws:
+        a_, b_ = res[True][0][k], res[False][0][k]
+        assert b_.abs().max().item() > 0, k
+        assert (a_ - b_).norm().item() <= 2.0 ** -6 * b_.norm().item() + 1e-6, (k, (a_ - b_).norm().item(), b_.norm().item())
