@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the training step (incl. the bucketed RCCL all-reduce when N > 1) in a hipGraph; off by default")
+    ap.add_argument("--eager", action="store_true", help="never capture the step (below 8 images per GPU the step is host-launch-bound and the default is "
+                    "hipGraph replay: ~180 launches of 5-30 us kernels)")
     ap.add_argument("--no-eval", action="store_true", help="skip the inference-FPS leg (the 'eval FPS' half of BASELINE.json's metric)")
     ap.add_argument("--deform-offsets", type=float, default=0.0,
                     help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
@@ -184,6 +186,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if B < 8 and not args.eager:                      # the per-rank shape of a strong-scaling run: host-bound in eager mode
+        args.graph = True
     if args.graph:                                    # (data-parallel steps are captured too: RCCL collectives are device-side)
         trainer.enable_graph(*step_args)
     for _ in range(args.warmup):

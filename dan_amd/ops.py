@@ -288,7 +288,21 @@ def _conv_scratch(d, which, dev):
     M, co = (d.N * d.Ho * d.Wo, d.Cout) if which == 0 else (d.N * d.H * d.W, d.Cin)
     if not USE_SPLITK or -(-M // 128) * -(-co // 128) > 160:
         return None, 0
-    n = _lib.lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), which)
+    key = (which, d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.Ho)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
+        n = _SCRATCH_BYTES[key] = _lib.lib().danhip_conv2d_workspace_bytes(ctypes.byref(d), which)
+    return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
+
+
+_SCRATCH_BYTES = {}          # (which, descriptor) -> bytes: one library query per shape (host time matters at 2 images per GPU)
+
+
+def _wgrad_scratch(d, dev):
+    key = (2, d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.Ho)
+    n = _SCRATCH_BYTES.get(key)
+    if n is None:
+        n = _SCRATCH_BYTES[key] = _lib.lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
     return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
 
 
@@ -320,7 +334,12 @@ class _Conv2d(torch.autograd.Function):
         elif pool_out is not None:                       # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
             assert relu and not out_f32 and residual is None and b is not None and cout % 8 == 0
             pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
-            call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
+            ws, nws = _conv_scratch(d, 0, x.device)
+            if nws:                                      # a map small enough to split K: no kernel of it fuses the pool anyway
+                call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), BF16, 1, None, ptr(ws), nws, stream())
+                call("danhip_maxpool2x2_fwd", ptr(y), ptr(pooled), N, d.Ho, d.Wo, cout, stream())
+            else:
+                call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
             pool_out.append(pooled)
         else:
             ws, nws = _conv_scratch(d, 0, x.device)
@@ -406,8 +425,7 @@ class _Conv2d(torch.autograd.Function):
             sink = _grad_sink(wp) if wp is not None else None
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
             # split partial sums as plain stores into a scratch slab + a combine pass, where the library's kernel for this shape offers it
-            nws = _lib.lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
-            ws = torch.empty(nws, dtype=torch.uint8, device=g.device) if nws else None
+            ws, nws = _wgrad_scratch(d, g.device)
             if _WGRAD["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
                 side = _WGRAD["side"]
                 ev = torch.cuda.Event()

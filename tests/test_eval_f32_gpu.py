@@ -81,18 +81,31 @@ def test_single_stage_eval_boxes_fp32(which, h, w, dev):
 @pytest.mark.parametrize("deform", [False, True])
 def test_dan_eval_boxes_fp32(deform, h, w, dev):
     """eval_dan.py:344-404 (the tensors fetched at :99): stage-1 boxes of levels 2.., routed stage-2 boxes of every level, scores."""
+    dan_eval_case(deform, h, w, dev)
+
+
+def dan_eval_case(deform, h, w, dev, logits16_tol=None):
+    """One image through the DAN evaluation graph on the fp32 path against the oracle (logits, stage-1 boxes, routed stage-2 boxes, scores);
+    logits16_tol: also compare the 16-bit path's four logit tensors at that fraction of the reference scale (tests/test_size_1024_gpu.py)."""
     from dan_amd import synthetic
     from dan_amd.train_dan import DANModel, dan_anchor_config
     imgs = synthetic.make_images(1, h, w, "cpu", seed=h + w + 1)
     x = ON.preprocess_synthetic(imgs)
     fwd = lambda P, xx: ON.dan_forward(P, xx, deform=deform)
-    P = _weights(fwd, x, 9, deform)
+    P = _weights(fwd, x[:, :64, :64], 9, deform)             # (variable shapes do not depend on the image size)
     with torch.no_grad():
         (l1r, c1r), (l2r, c2r) = fwd(ON.Params(P.t), x)
     model = DANModel(device=dev, deform=deform)
     model.vs.load_tf_named(P.t)
-    model.precision = "fp32"
     anchors = dan_anchor_config(h, w, dev)
+    if logits16_tol is not None:
+        with torch.no_grad():
+            (a1, b1), (a2, b2), _ = model.forward(imgs.to(dev))
+        for got, want, name in ((a1, l1r, "stage1/loc"), (b1, c1r, "stage1/cls"), (a2, l2r, "stage2/loc"), (b2, c2r, "stage2/cls")):
+            err = (got.float().cpu() - want).abs().max().item()
+            assert err <= logits16_tol * want.abs().max().item(), (name, err, want.abs().max().item())
+        del a1, b1, a2, b2
+    model.precision = "fp32"
     with torch.no_grad():
         (l1, c1), (l2, c2), sizes = model.forward(imgs.to(dev))
         boxes, scores = model.predict(imgs.to(dev), anchors)
