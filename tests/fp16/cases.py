@@ -136,6 +136,13 @@ def main():
         # above the typical floor)
         assert checked > 250 and not worst and len(bad) <= 0.03 * checked, (which, checked, worst[:10], bad[:10])
         n += 1
+    # BASELINE.json configs[4] at its input size: DAN-Deform on ONE 1024 x 1024 image in the fp16 build — the four 16-bit logit tensors against the
+    # fp32 oracle (fp16 storage: 2 % of scale), the fp32 path's logits / stage-1 boxes at 1e-4 and the routed stage-2 boxes
+    import test_eval_f32_gpu as TE
+    T.EMULATE_DTYPE = torch.bfloat16          # (the helper compares against the plain fp32 oracle: leave the emulation switch as it found it)
+    TE.dan_eval_case(True, 1024, 1024, dev, logits16_tol=0.02)
+    T.EMULATE_DTYPE = torch.float16
+    n += 1
     print("FP16-OK", n, "groups; DAN-Deform losses", ["%.4f" % t for t in totals])
 
 

@@ -46,6 +46,34 @@ def test_deform_conv_forward_backward(seed, N, H, W, C, Cout, dg, off_scale, dev
         assert err <= 2.0 ** -5 * scale + 2e-3, (name, err, scale)      # dS (bf16) feeds both gradients: 3 roundings
 
 
+def test_deform_conv_at_the_baseline_level_with_spread_offsets(dev):
+    """The context module's largest instance (BASELINE.json configs[4]: 160 x 160 x 256 -> 256, 4 deformable groups), one image, offsets
+    N(0, 2 px): most samples leave their cell, thousands leave the image — forward, dX, dW and dOffset against oracle/deform.py
+    (the gather path had been checked at full size only with ~zero offsets)."""
+    from dan_amd.utility import custom_op
+    N, H, W, C, Cout, dg = 1, 160, 160, 256, 256, 4
+    x, w, off = _case(160, N, H, W, C, Cout, dg, 2.0)
+    xr, wr, offr = x.float().permute(0, 3, 1, 2), w.clone(), off.float().permute(0, 3, 1, 2)
+    ref = OD.deform_conv_forward(xr, wr, offr, 1, 1, dg).permute(0, 2, 3, 1)
+    g = torch.Generator().manual_seed(161)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    dxr, dwr, doffr = OD.deform_conv_backward(xr, wr, offr, dy.float().permute(0, 3, 1, 2), 1, 1, dg)
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    od = off.to(dev).requires_grad_(True)
+    y = custom_op.deform_conv_op(xd, wd, od, [1, 1, 1, 1], "SAME", [1, 1, 1, 1], 1, dg)
+    y.backward(dy.to(dev))
+    torch.cuda.synchronize()
+    assert (y.float().cpu() - ref).abs().max().item() <= 2.0 ** -6 * ref.abs().max().item() + 1e-3
+    for name, got, want in (("dx", xd.grad.float().cpu(), dxr.permute(0, 2, 3, 1)), ("dw", wd.grad.cpu(), dwr),
+                            ("doffset", od.grad.float().cpu(), doffr.permute(0, 2, 3, 1))):
+        scale = want.abs().max().item() + 1e-6
+        err = (got - want).abs().max().item()
+        assert err <= 2.0 ** -5 * scale + 2e-3, (name, err, scale)
+        rel = (got - want).norm().item() / (want.norm().item() + 1e-12)
+        assert rel <= 0.02, (name, rel)
+
+
 @pytest.mark.parametrize("seed,N,H,W,C,Cout,dg,off_scale", [(11, 1, 6, 10, 256, 256, 4, 0.7), (12, 3, 19, 23, 128, 128, 2, 2.5), (13, 2, 16, 16, 64, 64, 1, 6.0),
                                                             (14, 1, 40, 40, 256, 256, 4, 1.0), (15, 1, 5, 5, 256, 128, 4, 0.3)])
 def test_fused_sampling_gemm_kernel(seed, N, H, W, C, Cout, dg, off_scale, dev):
