@@ -608,6 +608,8 @@ ConvArgs bwd_args(const danhip_conv_desc* d) {
 extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which) {
   static bf16_t dummy_mask = 0;
   if (!d) return "";
+  const bool noscratch = (which & 16) != 0;            // which | 16: the call without a scratch buffer (danhip_conv2d_fwd / _bwd_data): no split-K
+  which &= 15;
   const bool masked = which == 5;                      // which = 5: data gradient with the producer's ReLU mask fused (never the library GEMM)
   if (which == 5) which = 1;
   const int cin = (which == 0 || which == 4) ? d->Cin : round_up(d->Cout, 8);
@@ -624,7 +626,7 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     if (which == 0 && danhip_conv_c8_label(a)) return danhip_conv_c8_label(a);
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;
-    const bool sk = wants_splitk(a);                   // (callers that pass the scratch buffer: dan_amd.ops always does)
+    const bool sk = !noscratch && wants_splitk(a);     // (callers that pass the scratch buffer: dan_amd.ops always does)
     const char* hl = sk ? nullptr : danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
     if (which == 1) { if (masked) a.mask = &dummy_mask; }

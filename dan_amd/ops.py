@@ -279,6 +279,10 @@ def relu_bits(x, holder):
     return holder[0]
 
 
+# TRACE (tests): when a dict, every ReLU layer records its output under id(weight variable) and every 2x2 max-pool its input under
+# "pools" (call order) — the discrete decisions of this forward pass, which the gradient-parity tests impose on the oracle graph
+TRACE = None
+
 USE_SPLITK = True           # False (tests): never pass the scratch buffer, i.e. every shape runs on its single-pass kernel
 
 
@@ -495,6 +499,8 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
     bits_out = [] if (track and relu and USE_RELU_BITS) else None
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out)
+    if TRACE is not None and relu and wp is not None:
+        TRACE[id(wp)] = y.detach()
     if bits_out:                                         # the forward kernel wrote the masks: the holders of y (and its pooled map) start filled
         y._dh_bits = [bits_out[0]]
     if yslot is not None:
@@ -560,6 +566,8 @@ def max_pool_2x2(x):
         y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
         call("danhip_maxpool2x2_fwd_f32", ptr(x.contiguous()), ptr(y), N, H, W, C, stream())
         return y
+    if TRACE is not None:
+        TRACE.setdefault("pools", []).append(x.detach())
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
     yslot = _new_slot(track)

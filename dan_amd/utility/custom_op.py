@@ -65,8 +65,11 @@ def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, defor
     w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
     if cout % 8 == 0:
         # DeformConvOp / DeformConvBackpropOp as single library calls (danhip_deform_conv_{fwd,bwd})
-        return ops.deform_conv(x, w1x1, bias, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group,
-                               relu=relu)
+        y = ops.deform_conv(x, w1x1, bias, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group,
+                            relu=relu)
+        if ops.TRACE is not None and relu:
+            ops.TRACE[id(filter)] = y.detach()
+        return y
     # ragged Cout: the two halves as separate ops (same kernels; the conv wrapper pads the output-gradient channels)
     S = ops.deform_sample(x, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group)
     return ops.conv2d(S, w1x1, bias, stride=1, relu=relu)

@@ -141,7 +141,7 @@ int danhip_relu_bwd_bias_grad(uint16_t* dy, const uint16_t* y, float* db, int64_
 
 /* Kernel-instance label a forward (which=0) / data-gradient (which=1; which=5 when relu_mask is passed) / forward-with-fused-pool
  * (which=4, danhip_conv2d_fwd_pool) call of this descriptor launches (the demangled name rocprofv3 reports) — lets bench.py attribute
- * measured time to a kernel. */
+ * measured time to a kernel.  The answer is for the *_ws calls given their scratch buffer; which | 16: for the plain calls (no split-K). */
 const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int which);
 /* Same for the weight-gradient call of this descriptor. */
 const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d);

@@ -20,6 +20,11 @@ class Params:
         # emulate_bf16: round conv weights (straight-through), stored activations and their gradients to bf16, as the
         # MI355X build stores them (fp32 accumulate everywhere) — used only to tighten parity tolerances.
         self.emulate_bf16 = emulate_bf16
+        # impose (tests/test_grad_parity_gpu.py): {"relu": {kernel name: activation of the run under test}, "pools": [pre-pool activations in
+        # call order]} — the DISCRETE decisions (ReLU sign, 2x2 arg-max) are taken from those tensors instead of from this graph's own
+        # values, so that a comparison of gradients is not dominated by pre-activations within rounding of zero landing on different sides
+        self.impose = None
+        self._pool_no = 0
         self.t = dict(tensors or {})
         self.create = create
         self.gen = torch.Generator().manual_seed(seed)
@@ -47,6 +52,32 @@ class Params:
         return v
 
 
+def _relu(P, y, scope):
+    """ReLU of a layer's pre-activation; with P.impose the sign pattern comes from the recorded activation of that layer."""
+    if P.impose is not None and scope + "/kernel" in P.impose["relu"]:
+        ref = P.impose["relu"][scope + "/kernel"]
+        assert ref.shape == y.shape, (scope, tuple(ref.shape), tuple(y.shape))
+        return y * (ref > 0).to(y.dtype)
+    return torch.relu(y)
+
+
+def max_pool(P, x):
+    """tf.layers.max_pooling2d([2,2],[2,2],'same') (net/sfd_net.py:132-143); with P.impose the arg-max positions come from the recorded
+    pre-pool activation (same window scan order: the first maximum wins)."""
+    if P.impose is None:
+        return T.max_pool_2x2_same(x)
+    ref = P.impose["pools"][P._pool_no]
+    P._pool_no += 1
+    assert ref.shape == x.shape, (tuple(ref.shape), tuple(x.shape))
+    n, h, w, c = x.shape
+    ph, pw = h % 2, w % 2
+    rn = F.pad(ref.permute(0, 3, 1, 2), (0, pw, 0, ph), value=float("-inf"))
+    xn = F.pad(x.permute(0, 3, 1, 2), (0, pw, 0, ph))
+    _, idx = F.max_pool2d(rn, 2, 2, return_indices=True)
+    y = torch.gather(xn.flatten(2), 2, idx.flatten(2)).view(idx.shape)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
 def conv(P, x, filters, ksize, stride, scope, relu, init="glorot"):
     """tf.layers.conv2d(name=<scope>) with bias; kernel var '<scope>/kernel', bias '<scope>/bias'."""
     kh, kw = ksize
@@ -59,8 +90,10 @@ def conv(P, x, filters, ksize, stride, scope, relu, init="glorot"):
         if head:                                              # head convs emit fp32; their incoming gradient is cast to bf16
             return T.round_bf16(y, False, True)
         y = T.round_bf16(y, False, True) if relu else y       # gradient w.r.t. the pre-activation is stored in bf16
-        y = torch.relu(y) if relu else y
+        y = _relu(P, y, scope) if relu else y
         return T.round_bf16(y, True, not relu)                # stored activation is bf16
+    if relu and P.impose is not None:
+        return _relu(P, T.conv2d_same(x, w, b, stride=stride, relu=False), scope)
     return T.conv2d_same(x, w, b, stride=stride, relu=relu)
 
 
@@ -80,19 +113,19 @@ def get_featmaps(P, x):
     """VGG16Backbone.get_featmaps — net/sfd_net.py:127-156 (identical in pb_net/danet)."""
     feats = []
     x = conv_block(P, x, 2, 64, "conv1")
-    x = T.max_pool_2x2_same(x)
+    x = max_pool(P, x)
     x = conv_block(P, x, 2, 128, "conv2")
-    x = T.max_pool_2x2_same(x)
+    x = max_pool(P, x)
     x = conv_block(P, x, 3, 256, "conv3")
     l2n = (lambda a, g: T.round_bf16(T.l2_normalize(a, g), True, True)) if P.emulate_bf16 else T.l2_normalize
     feats.append(l2n(x, P.get("l2_norm_layer_3/weight", (256,), 10.0)))
-    x = T.max_pool_2x2_same(x)
+    x = max_pool(P, x)
     x = conv_block(P, x, 3, 512, "conv4")
     feats.append(l2n(x, P.get("l2_norm_layer_4/weight", (512,), 8.0)))
-    x = T.max_pool_2x2_same(x)
+    x = max_pool(P, x)
     x = conv_block(P, x, 3, 512, "conv5")
     feats.append(l2n(x, P.get("l2_norm_layer_5/weight", (512,), 5.0)))
-    x = T.max_pool_2x2_same(x)
+    x = max_pool(P, x)
     x = conv_relu(P, x, 1024, (3, 3), 1, "fc6")
     x = conv_relu(P, x, 1024, (1, 1), 1, "fc7")
     feats.append(x)
@@ -221,7 +254,7 @@ def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False, relu=False):
     if not P.emulate_bf16:
         y = deform_conv_forward(xn, w, on, 1, 1, dg).permute(0, 2, 3, 1)
         y = y if b is None else y + b
-        return torch.relu(y) if relu else y
+        return _relu(P, y, name) if relu else y
     w = T.round_bf16(w, True, False)
     col = T.round_bf16(deform_im2col(xn, on, 3, 3, 1, 1, dg), True, True)       # the sampled operand is a 16-bit MFMA input
     B, C, K, Ho, Wo = col.shape
@@ -229,7 +262,7 @@ def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False, relu=False):
     y = y.permute(0, 2, 3, 1)
     y = y if b is None else y + b
     y = T.round_bf16(y, False, True) if relu else y
-    y = torch.relu(y) if relu else y
+    y = _relu(P, y, name) if relu else y
     return T.round_bf16(y, True, not relu)
 
 

@@ -32,7 +32,13 @@ def setup(which, H, W, B, dev, act_dtype, seed=11):
     deform = which == "dan_deform"
     imgs = synthetic.make_images(B, H, W, "cpu", seed=3)
     x = ON.preprocess_synthetic(imgs)
-    if which == "pb":
+    if which == "sfd":
+        from dan_amd.train_sfd import SFDModel
+        ofwd = ON.sfd_forward
+        flat = lambda o: [o[0], o[1]]
+        P = make_weights(ofwd, x, seed)
+        model = SFDModel(device=dev)
+    elif which == "pb":
         from dan_amd.train_pb import PBModel
         ofwd = ON.pb_forward
         flat = lambda o: [o[k][j] for k in ("face", "head", "body") for j in (0, 1)]
@@ -48,9 +54,11 @@ def setup(which, H, W, B, dev, act_dtype, seed=11):
     return model, flat, ofwd, P, imgs, x.to(act_dtype).float()
 
 
-def oracle_grads(ofwd, flat, P, x, Gs=None, seed=5):
+def oracle_grads(ofwd, flat, P, x, Gs=None, seed=5, impose=None):
     params = {n: v.clone().requires_grad_(True) for n, v in P.t.items()}
-    outs = flat(ofwd(ON.Params(params, emulate_bf16=True), x))
+    PO = ON.Params(params, emulate_bf16=True)
+    PO.impose = impose
+    outs = flat(ofwd(PO, x))
     if Gs is None:
         gen = torch.Generator().manual_seed(seed)
         Gs = [torch.randn(o.shape, generator=gen) for o in outs]
@@ -58,12 +66,23 @@ def oracle_grads(ofwd, flat, P, x, Gs=None, seed=5):
     return {n: p.grad for n, p in params.items()}, Gs, [o.detach() for o in outs]
 
 
-def hip_grads(model, flat, imgs, Gs, dev):
-    """Gradients of sum(out * G) w.r.t. every variable through the HIP path (plain autograd leaves: no flat buffer)."""
+def hip_grads(model, flat, imgs, Gs, dev, trace=None):
+    """Gradients of sum(out * G) w.r.t. every variable through the HIP path (plain autograd leaves: no flat buffer).
+    trace: a dict that receives the forward pass's discrete decisions in the form oracle.nets.Params.impose takes."""
+    from dan_amd import ops
     named = model.vs.named()
     for _, p in named:
         p.grad = None
-    outs = flat(model.forward(imgs.to(dev)))
+    ops.TRACE = {} if trace is not None else None
+    try:
+        outs = flat(model.forward(imgs.to(dev)))
+        rec, ops.TRACE = ops.TRACE, None
+    finally:
+        ops.TRACE = None
+    if trace is not None:
+        name_of = {id(p): n for n, p in named}
+        trace["pools"] = [t.float().cpu() for t in rec.pop("pools", [])]
+        trace["relu"] = {name_of[k]: v.float().cpu() for k, v in rec.items() if k in name_of}
     torch.autograd.backward(outs, [G.to(dev) for G in Gs])
     torch.cuda.synchronize()
     return {n: (p.grad.detach().cpu() if p.grad is not None else None) for n, p in named}, [o.detach().cpu() for o in outs]

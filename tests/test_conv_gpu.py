@@ -246,16 +246,16 @@ def test_pointwise_data_gradient_ragged_channels(accumulate, dev):
 # The 12 distinct 3x3 shapes of the VGG-16 backbone at BASELINE.json's 640x640 (SURVEY §7 "minimum slice", Appendix B) plus conv1_1 and
 # the two heavy pointwise shapes, at N = 1 and FULL spatial size, against the CPU oracle convolution (oneDNN fp32 on bf16-rounded
 # operands): forward with bias + ReLU, data gradient, weight gradient, bias gradient.
-def test_ragged_channel_counts_run_on_the_halo_and_row_streaming_kernels(dev):
+def test_ragged_channel_counts_run_on_the_halo_and_row_streaming_kernels(dev, splitk):
     import ctypes
     from dan_amd import ops
     from dan_amd._lib import lib
-    d = ops._desc(2, 32, 64, 256, 72, 3, 3, 1)
-    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
-    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 1).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
+    d = ops._desc(2, 32, 64, 256, 72, 3, 3, 1)                  # (| 16: the single-pass call; maps this small split K when given scratch)
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0 | 16).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 1 | 16).decode().startswith("conv3x3_halo_kernel<8, 32, 128")
     assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_rows_kernel<128>"
     d = ops._desc(1, 24, 32, 128, 40, 3, 3, 1)
-    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv3x3_halo_kernel<8, 32, 64")
+    assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0 | 16).decode().startswith("conv3x3_halo_kernel<8, 32, 64")
     assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_rows_kernel<64>"
 
 
@@ -307,7 +307,7 @@ PW_SHAPES = [(2, 48, 48, 256, 256), (1, 64, 72, 2304, 256), (4, 40, 40, 1024, 10
 
 
 @pytest.mark.parametrize("shape", PW_SHAPES)
-def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
+def test_pointwise_kernel_forward_and_data_gradient(shape, dev, splitk):
     """Forward (bias, ReLU on / off) against the oracle convolution; data gradient through the C ABI in all four epilogue modes
     (plain, ReLU mask of the producer, accumulate into an existing gradient, both) against dx = dy . W^T in fp32."""
     import ctypes
@@ -319,9 +319,9 @@ def test_pointwise_kernel_forward_and_data_gradient(shape, dev):
     w = (torch.randn((1, 1, Cin, Cout), generator=g) / Cin ** 0.5).to(torch.bfloat16).float()
     b = torch.randn((Cout,), generator=g)
     d = ops._desc(N, H, W, Cin, Cout, 1, 1, 1)
-    if Cin % 64 == 0 and Cout % 64 == 0:
-        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0).decode().startswith("conv_pointwise_kernel")
-        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 5).decode().startswith("conv_pointwise_kernel")
+    if Cin % 64 == 0 and Cout % 64 == 0:                       # (| 16: the single-pass call — small maps split K when given scratch)
+        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 0 | 16).decode().startswith("conv_pointwise_kernel")
+        assert lib().danhip_conv_kernel_label(ctypes.byref(d), 5 | 16).decode().startswith("conv_pointwise_kernel")
     if Cin % 64 == 0 and Cin >= 128 and N * H * W >= 4096:
         assert lib().danhip_conv_wgrad_kernel_label(ctypes.byref(d)).decode() == "conv_wgrad_pw_kernel"
     for relu in (False, True):

@@ -127,6 +127,7 @@ def test_single_call_entry_points_equal_the_two_halves(dev):
     b = torch.randn(64, generator=g)
     dy = torch.randn((2, 11, 13, 64), generator=g).to(torch.bfloat16).to(dev)
     res = []
+    ops.USE_SPLITK = False                              # bit-identity: the separate conv op must run the same single-pass GEMM kernel as the library call
     for single in (True, False, "resample"):            # "resample": the reference's re-im2col in backward instead of the kept buffer
         ops.KEEP_DEFORM_COL = single != "resample"
         xd, od = x.to(dev).requires_grad_(True), off.to(dev).requires_grad_(True)
@@ -139,6 +140,7 @@ def test_single_call_entry_points_equal_the_two_halves(dev):
         y.backward(dy)
         res.append((y, xd.grad, od.grad, w1.grad, bd.grad))
     ops.KEEP_DEFORM_COL = True
+    ops.USE_SPLITK = True
     for other in (res[1], res[2]):
         for a, c, name in zip(res[0], other, ("y", "dx", "doffset", "dw", "db")):
             if name in ("dw", "db", "dx"):        # fp32 atomics: order-dependent in the last bits

@@ -30,7 +30,10 @@ def test_graph_gradients_match_the_oracle(which, H, W, dev):
     got, outs = GC.hip_grads(model, flat, imgs, Gs, dev)
     for o, r in zip(outs, outs_ref):
         assert (o - r).abs().max().item() <= 0.06 * r.abs().max().item()
-    bad, checked = GC.compare(got, want, 0.25)
+    # free-running comparison: the bound is the noise floor of 16-bit storage (docstring, angle 1); a different fp32 summation order in one
+    # layer (e.g. split-K on the small maps) moves individual variables by a few hundredths around it — the tight per-variable check is
+    # test_graph_gradients_with_the_forward_decisions_imposed_on_the_oracle (0.05)
+    bad, checked = GC.compare(got, want, 0.30)
     assert checked > 250 and not bad, (checked, bad[:10])
     # the same kernels without the direct gradient hand-off
     ops.USE_SLOTS = False
@@ -40,6 +43,28 @@ def test_graph_gradients_match_the_oracle(which, H, W, dev):
         ops.USE_SLOTS = True
     bad, checked = GC.compare(got, plain, 0.03)
     assert checked > 250 and not bad, (checked, bad[:10])
+
+
+@pytest.mark.parametrize("which,H,W", [("sfd", 96, 96)] + CASES)
+def test_graph_gradients_with_the_forward_decisions_imposed_on_the_oracle(which, H, W, dev):
+    """The same comparison with the DISCRETE decisions of the HIP forward pass (sign of every ReLU layer's output, the 2x2 max-pool arg-max
+    positions) imposed on the oracle graph (oracle.nets.Params.impose): what remains is accumulation order and 16-bit rounding of the
+    stored tensors, and the per-variable bound drops from the 0.25 noise floor of the free-running comparison to 0.05 (VERDICT r2, weak 2:
+    a 20 % scale error on one small variable passed at 0.25).  The free-running test above stays as the companion that shows the
+    decisions themselves agree up to that floor."""
+    model, flat, ofwd, P, imgs, x = GC.setup(which, H, W, 2, dev, torch.bfloat16)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        shapes = [o.shape for o in flat(model.forward(imgs.to(dev)))]
+    Gs = [torch.randn(s, generator=gen) for s in shapes]
+    trace = {}
+    got, outs = GC.hip_grads(model, flat, imgs, Gs, dev, trace=trace)
+    assert len(trace["relu"]) >= 13 and len(trace["pools"]) == 5, (len(trace["relu"]), len(trace["pools"]))
+    want, _, outs_ref = GC.oracle_grads(ofwd, flat, P, x, Gs=Gs, impose=trace)
+    for o, r in zip(outs, outs_ref):
+        assert (o - r).abs().max().item() <= 0.03 * r.abs().max().item()
+    bad, checked = GC.compare(got, want, 0.05)
+    assert checked > (30 if which == "sfd" else 250) and not bad, (checked, bad[:10])
 
 
 def _close(a, b, rel):
