@@ -18,6 +18,18 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+// bit r = packed 16-bit value r > 0 (patterns 1 .. +inf; NaNs compare false as in danhip_relu_bits)
+__device__ __forceinline__ unsigned c8_pos_bits8(const u32x4& t) {
+  unsigned byte = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned lo = t[e] & 0xffffu, hi = t[e] >> 16;
+    byte |= ((lo - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e);
+    byte |= ((hi - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e + 1);
+  }
+  return byte;
+}
+
 struct C8Geom {
   int units_x;            // ceil(W / 16)
   long units;             // N * H * units_x
@@ -89,6 +101,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
     for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][1], f1, acc[m]);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][2], f2, acc[m]);
+    unsigned pbyte[2] = {0u, 0u};
     if (t.x0 + px < a.W) {
       bf16_t* yo = reinterpret_cast<bf16_t*>(a.y) + ((size_t)(unsigned)(t.base + px)) * 64 + q * 8;
 #pragma unroll
@@ -103,7 +116,16 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
         const u32x4 o = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
         if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(yo + P * 32));
         else *reinterpret_cast<u32x4*>(yo + P * 32) = o;
+        pbyte[P] = c8_pos_bits8(o);
       }
+    }
+    // ReLU bit mask of the output for the next layer's data gradient (danhip_relu_bits layout: 8 bytes per pixel): this lane's two bytes
+    // are q and 4 + q of pixel px; the four lanes of a pixel (q = 0..3: lanes px, px + 16, px + 32, px + 48) are OR-ed by two shuffles
+    if (a.bits_out) {                               // (uniform)
+      unsigned lo = pbyte[0] << (8 * q), hi = pbyte[1] << (8 * q);
+      lo |= (unsigned)__shfl_xor((int)lo, 16, 64); hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
+      lo |= (unsigned)__shfl_xor((int)lo, 32, 64); hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
+      if (q == 0 && t.x0 + px < a.W) *reinterpret_cast<uint2*>(a.bits_out + ((size_t)(unsigned)(t.base + px)) * 8) = uint2{lo, hi};
     }
   };
 

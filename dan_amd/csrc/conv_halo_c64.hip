@@ -88,6 +88,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.mask ? a.mask : a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_o =
       __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.y), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+  // Bit-mask form (ConvArgs::mask_bits, danhip_relu_bits layout: 8 bytes per pixel): the tile's 256 pixels x 8 bytes = 2 KiB are fetched by
+  // waves 0 and 1 (one 16-byte DMA per lane = two horizontally adjacent pixels) into one of two 2 KiB buffers — the hand-off barrier that
+  // ends the tile publishes them to every wave's epilogue, and the buffer is refilled two tiles later, i.e. behind the NEXT hand-off
+  // barrier, which every wave passes only after its epilogue reads.  1/16 of the 16-bit mask's bytes (conv1_2, batch 16: 839 -> 52 MB).
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(a.mask_bits ? a.mask_bits : reinterpret_cast<const unsigned char*>(a.x)), 0, (int)((unsigned)(a.N * a.H * a.W) * 8u),
+      0x00020000);
+  auto issue_bits = [&](int sp, int bbuf) __attribute__((always_inline)) {
+    if (wave >= 2) return;                         // (uniform per wave)
+    int n, y0, x0;
+    sp_coords(sp, n, y0, x0);
+    const int t = (wave * 64 + lane) * 2;          // pixels t, t + 1 of the tile (same row: TW is even)
+    const int y = y0 + t / TW, x = x0 + t % TW;
+    const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * 8u : 0xFFFFFFFFu;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_AS void*)(smem + RWBASE + bbuf * 2048 + wave * 1024), 16, off, 0, 0, 0);
+  };
   auto issue_rw = [&](int sp) __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(sp, n, y0, x0);
@@ -147,7 +163,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (;;) {
     const int nsp = sp + G;
     const bool has_next = nsp < g.sp_items;
-    if constexpr (DGRAD) issue_rw(sp);             // this tile's mask / old value (its own reads of the region ended with its last epilogue)
+    if constexpr (DGRAD) {
+      issue_rw(sp);                                // this tile's mask / old value (its own reads of the region ended with its last epilogue)
+      if (a.mask_bits) issue_bits(sp, buf);
+    }
     if (has_next) issue_patch(nsp, buf ^ 1);       // the other buffer was released by the barrier that ended the previous tile
     // ---- 18 half-taps (tap, k-slice); pixel fragments software-pipelined TWO half-taps ahead through three rotating
     //      register sets (a ds_read_b128 under load takes longer than the 8 MFMAs of one half-tap)
@@ -188,6 +207,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // store — the compiler orders an LDS read behind everything vmcnt counts (it cannot tell a DMA from a store), so a read issued
       // after a store would wait out a full write latency.  Two passes keep the live set at one 16-byte vector per fragment.
       if constexpr (DGRAD) {
+        if (a.mask_bits) {                           // byte (wn*4 + fq) of pixel t = this lane's 8 channels
+          unsigned w4[NPT];
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) w4[p] = *reinterpret_cast<const unsigned*>(smem + RWBASE + buf * 2048 + (wm * 64 + p * 16 + frow) * 8 + wn * 4);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const unsigned byte = (w4[p] >> (8 * fq)) & 0xffu;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (!((byte >> r) & 1u)) acc[r >> 2][p][r & 3] = 0.f;
+          }
+        }
         if (a.mask) {
           uint4 m[NPT];
 #pragma unroll
@@ -314,7 +344,8 @@ int launch_c64(const ConvArgs& a, hipStream_t s) {
 int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s) {
   if (!c64_eligible(a)) return 1;
   const bool dgrad = !a.bias && !a.relu && !a.resid;
-  if (!dgrad && (a.accumulate || a.mask)) return 1;
+  if (!dgrad && (a.accumulate || a.mask || a.mask_bits)) return 1;
+  if (a.mask && a.mask_bits) return 1;              // one mask form per call (the bits share the 16-bit mask's LDS region)
   return dgrad ? launch_c64<true>(a, s) : launch_c64<false>(a, s);
 }
 

@@ -753,7 +753,8 @@ extern "C" int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_
   static bf16_t dummy = 0;
   ConvArgs a = fwd_args(d);
   a.bias = &one; a.relu = 1;
-  if (danhip_conv_c8_label(a) || danhip_conv_c64_eligible(a)) return 0;
+  if (danhip_conv_c8_label(a)) return with_pool ? 0 : 1;        // the first layer's store-bound kernel writes the mask beside its output
+  if (danhip_conv_c64_eligible(a)) return 0;
   if (!danhip_conv_halo_emits_bits(a)) return 0;
   if (with_pool) { a.pool_y = &dummy; if (!danhip_conv_halo_pool_fusable(a)) return 0; }
   return 1;
@@ -770,6 +771,7 @@ extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = nullptr; a.y = y;
   a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
   a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits;
+  if (danhip_conv_c8_label(a)) return danhip_launch_conv_c8(a, (hipStream_t)stream);
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }
 
@@ -853,7 +855,7 @@ extern "C" int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d) {
   if (d->stride != 1) return 0;
   ConvArgs a = bwd_args(d);
   a.bias = nullptr; a.relu = 0; a.out_f32 = 0; a.resid = nullptr;
-  if (danhip_conv_c64_eligible(a)) return 0;
+  if (danhip_conv_c64_eligible(a)) return (a.W % 2 == 0) ? 1 : 0;   // 64 -> 64 register-resident kernel: 2 KiB of bits per tile through LDS (pixel pairs)
   return danhip_conv_halo_takes_bits(a) ? 1 : 0;
 }
 
@@ -867,5 +869,6 @@ extern "C" int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint
   ConvArgs a = bwd_args(d);
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = nullptr; a.mask_bits = relu_bits; a.resid = nullptr; a.y = dx;
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
+  if (danhip_conv_c64_eligible(a)) return danhip_launch_conv_c64(a, (hipStream_t)stream);
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }

@@ -209,8 +209,20 @@ int launch_wgrad(WgradArgs& a, hipStream_t s) {
   a.ci_tiles = a.tapcols ? 1 : cdiv(a.C, BCI);
   const int taps = a.tapcols ? 1 : a.kh * a.kw;
   const int base_blocks = co_tiles * a.ci_tiles * taps;
-  // split the pixel reduction so that ~4 workgroups per CU exist, but keep >= 8 K tiles per split
-  int splits = (1024 + base_blocks - 1) / base_blocks;
+  // split the pixel reduction so that every CU holds as many workgroups as fit (LDS: two stages of the X and dY tiles; at most 4) in ONE
+  // wave of the grid — 1024 blocks of the 48 KB <128, 64> instance were 1.33 waves of 768 slots: the first layer's gradient ran its last
+  // third alone on a third of the chip — but keep >= 8 K tiles per split
+  const int lds_block = 2 * 64 * (BCI + BCO) * 2;
+  int per_cu = (160 * 1024) / lds_block;
+  if (per_cu > 4) per_cu = 4;
+  static const int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  const int slots = per_cu * cus;
+  int splits = slots / base_blocks;
   const int max_splits = (a.ktiles + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -434,8 +434,50 @@ def test_data_gradient_with_bit_mask_equals_the_16bit_mask_form(shape, accumulat
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert (a.float().abs().sum() > 0) and ((a == 0) | (x > 0)).all() if not accumulate else True
-    d2 = ops._desc(N, H, W, 64, 64, 3, 3, 1)       # the 64 -> 64 kernel keeps its own LDS-staged 16-bit mask
-    assert lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d2)) == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 64), (1, 30, 62), (9, 64, 128), (3, 40, 96)])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_first_layer_writes_the_bit_mask_and_the_64_channel_data_gradient_reads_it(shape, accumulate, dev):
+    """conv1_1 (3 -> 64, the store-bound kernel) writes the ReLU bit mask of its output beside it; conv1_2's data gradient (64 -> 64, register-
+    resident weights) stages 2 KiB of those bits per tile instead of the 64 KiB 16-bit mask tile: bit masks equal danhip_relu_bits of the
+    written tensor, gradients equal the 16-bit-mask form bit for bit (ragged tile edges, several tiles per workgroup, accumulate)."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, lib, ptr, stream
+    N, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    d1 = ops._desc(N, H, W, 8, 64, 3, 3, 1)
+    assert lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d1), 0) == 1 and lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d1), 1) == 0
+    x0 = torch.zeros((N, H, W, 8), dtype=torch.bfloat16)
+    x0[..., :3] = torch.randn((N, H, W, 3), generator=g).to(torch.bfloat16)
+    w1 = (torch.randn((3, 3, 3, 64), generator=g) / 27 ** 0.5).to(dev)
+    b1 = (0.2 * torch.randn(64, generator=g)).to(dev)
+    wf, _ = ops.pack_conv_weight(d1, w1, need_bwd=False)
+    y = torch.empty((N, H, W, 64), dtype=torch.bfloat16, device=dev)
+    y_ref = torch.empty_like(y)
+    bits = torch.full((N * H * W, 8), 0x55, dtype=torch.uint8, device=dev)
+    x0d = x0.to(dev)
+    call("danhip_conv2d_fwd_relu_bits", ctypes.byref(d1), ptr(x0d), ptr(wf), ptr(b1), ptr(y), ptr(bits), None, None, stream())
+    call("danhip_conv2d_fwd", ctypes.byref(d1), ptr(x0d), ptr(wf), ptr(b1), ptr(y_ref), 1, 1, None, stream())
+    want = torch.empty_like(bits)
+    call("danhip_relu_bits", ptr(y), ptr(want), N * H * W, 64, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(bits, want)
+    assert 0.2 < (y > 0).float().mean().item() < 0.8
+    d2 = ops._desc(N, H, W, 64, 64, 3, 3, 1)
+    assert lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d2)) == 1
+    w2 = (torch.randn((3, 3, 64, 64), generator=g) / 576 ** 0.5).to(dev)
+    _, wb = ops.pack_conv_weight(d2, w2, need_bwd=True)
+    dy = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).to(dev)
+    old = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).to(dev)
+    a, b = old.clone(), old.clone()
+    call("danhip_conv2d_bwd_data", ctypes.byref(d2), ptr(dy), ptr(wb), ptr(y), ptr(a), accumulate, stream())
+    call("danhip_conv2d_bwd_data_bits", ctypes.byref(d2), ptr(dy), ptr(wb), ptr(bits), ptr(b), accumulate, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    d3 = ops._desc(1, 30, 47, 64, 64, 3, 3, 1)      # odd width: pixel pairs would straddle rows, the kernel keeps the 16-bit mask
+    assert lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d3)) == 0
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 64, 64, 128), (1, 33, 62, 128, 256), (3, 16, 16, 256, 128), (9, 64, 96, 128, 128)])
