@@ -102,6 +102,7 @@ SIGNATURES = {
     "danhip_small_mining_match": [P, I32, I32, FL, FL, FL, I32, FL, P, P, P, ctypes.c_size_t, P],
     "danhip_encode_anchors": [P, P, P, P, P, P, P, P, P, I32, FL, FL, FL, FL, FL, P],
     "danhip_decode_anchors": [P, P, P, P, P, P, I32, I32, FL, FL, FL, FL, P],
+    "danhip_face_scores": [P, P, P, FL, I64, P],
     "danhip_encode_anchors_batched": [P] * 11 + [I32, I32, I32, I32, I32, FL, FL, FL, I32, FL, FL, FL, FL, FL, FL, P, P, P, P, P,
                                                  ctypes.c_size_t, P],
 }

@@ -422,6 +422,19 @@ __global__ void decode_anchors_kernel(const float* __restrict__ pred, const floa
   }
 }
 
+// tf.nn.softmax(cls_pred)[:, -1] of two-way logits (eval_dan.py:356,371, eval_sfd.py:281, train_dan.py:438): exp(x - max) / sum in fp32,
+// the order TF / Eigen evaluate it in; optionally also the "easy" mask score > thr as int32 (train_dan.py:439, eval_dan.py:386).
+__global__ void face_scores_kernel(const float* __restrict__ cls, float* __restrict__ score, int* __restrict__ mask, float thr, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float2 l = *reinterpret_cast<const float2*>(cls + i * 2);
+    const float m = fmaxf(l.x, l.y);
+    const float e0 = expf(l.x - m), e1 = expf(l.y - m);
+    const float p = e1 / (e0 + e1);
+    if (score) score[i] = p;
+    if (mask) mask[i] = p > thr ? 1 : 0;
+  }
+}
+
 __global__ void fill_int_kernel(int* p, int v, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
@@ -580,6 +593,13 @@ extern "C" int danhip_decode_anchors(const float* pred, const float* ymin, const
   DH_REQUIRE(pred && ymin && xmin && ymax && xmax && boxes && B > 0 && A > 0, DANHIP_EINVAL, "decode_anchors: bad arguments");
   hipLaunchKernelGGL(decode_anchors_kernel, dim3(grid_for((long)B * A, 256)), dim3(256), 0, (hipStream_t)stream, pred, ymin, xmin, ymax, xmax, boxes,
                      B, A, ps0, ps1, ps2, ps3);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_face_scores(const float* cls, float* score, int32_t* mask, float threshold, int64_t n, void* stream) {
+  DH_REQUIRE(cls && (score || mask) && n > 0, DANHIP_EINVAL, "face_scores: bad arguments");
+  hipLaunchKernelGGL(face_scores_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, (hipStream_t)stream, cls, score, mask, threshold, (long)n);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

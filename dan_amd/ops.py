@@ -1112,3 +1112,15 @@ def preprocess_f32(img_rgb_u8):
 
 def deform_sample(x, offsets, kh, kw, stride=1, dilation=1, deformable_group=1):
     return _DeformSample.apply(x, offsets, kh, kw, stride, dilation, deformable_group)
+
+
+def face_scores(cls, threshold=None):
+    """softmax(cls)[..., 1] of two-way fp32 logits [..., 2] (eval_dan.py:356, eval_sfd.py:281) -> scores [...]; with `threshold` also the int32
+    mask (score > threshold) (train_dan.py:438-439): -> (scores, mask).  One libdanhip launch (no torch.softmax on the product path)."""
+    assert cls.dtype == torch.float32 and cls.shape[-1] == 2
+    c = cls.contiguous()
+    n = c.numel() // 2
+    score = torch.empty(c.shape[:-1], dtype=torch.float32, device=c.device)
+    mask = torch.empty(c.shape[:-1], dtype=torch.int32, device=c.device) if threshold is not None else None
+    call("danhip_face_scores", ptr(c), ptr(score), ptr(mask), float(threshold or 0.0), n, stream())
+    return (score, mask) if threshold is not None else score

@@ -46,8 +46,8 @@ class DANModel(object):
         Returns (bboxes_pred [B,A',4], cls_pred [B,A']) exactly as fetched at eval_dan.py:99."""
         (loc1, cls1), (loc2, cls2), sizes = self.forward(images_u8)
         enc = anchors.enc
-        score1 = torch.softmax(cls1, dim=-1)[..., -1]
-        score2 = torch.softmax(cls2, dim=-1)[..., -1]
+        score1, easy = ops.face_scores(cls1, select_thres)          # eval_dan.py:356, :386
+        score2 = ops.face_scores(cls2)                                # eval_dan.py:371
         boxes1 = enc.batch_decode_anchors(loc1, *anchors.anchors[:4])
         if getattr(self, "_scale2", None) is None or self._scale2.device != loc2.device:
             self._scale2 = torch.tensor([20., 20., 10., 10.], dtype=torch.float32, device=loc2.device)   # eval_dan.py:384 (kept: no per-call upload)
@@ -58,8 +58,8 @@ class DANModel(object):
         lvl_boxes, lvl_scores = [], []
         for i, (nl, (fh, fw)) in enumerate(zip(per_level, sizes)):
             sl = slice(off, off + nl)
-            mask_in = (score1[:, sl] > select_thres).to(torch.int32)
-            mo, do = custom_op.dynamic_anchor_routing(boxes1[:, sl].contiguous(), (loc2[:, sl] / scale).contiguous(), score2[:, sl].contiguous(), mask_in,
+            mo, do = custom_op.dynamic_anchor_routing(boxes1[:, sl].contiguous(), (loc2[:, sl] / scale).contiguous(), score2[:, sl].contiguous(),
+                                                      easy[:, sl].contiguous(),
                                                       fh, fw, anchors.depth[i], ALL_LAYER_STRIDES[i], images_u8.shape[1], images_u8.shape[2], False, 0.03, 0.0)
             lvl_boxes.append(do)
             lvl_scores.append(score2[:, sl] * mo.to(torch.float32))
@@ -112,7 +112,7 @@ class DANTrainer(DetectorTrainer):
         a = self.anchors
         with torch.no_grad():
             bboxes_pred = a.enc.batch_decode_anchors(loc1.detach(), *a.anchors[:4])                       # :430
-            easy = (torch.softmax(cls1.detach(), dim=-1)[..., -1] > 0.03).to(torch.int32)                 # :438-439
+            _, easy = ops.face_scores(cls1.detach(), 0.03)                                                # :438-439
             B, A = cls_targets.shape
             final_mask, final_loc = anchor_routing(bboxes_pred, matched_gt, (cls_targets > 0).to(torch.float32), easy, sizes, ALL_LAYER_STRIDES,
                                                    a.depth, a.num_anchors_per_layer, ROUTING_THRES, ROUTING_IGNORE, images_u8.shape[1:3],

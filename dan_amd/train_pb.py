@@ -32,7 +32,7 @@ class PBModel(object):
         """eval_pb.py inference graph: decoded face boxes + face scores."""
         loc, cls = self.forward(images_u8)["face"]
         boxes = anchors.enc.batch_decode_anchors(loc, *anchors.anchors[:4])
-        return boxes, torch.softmax(cls, dim=-1)[..., 1]
+        return boxes, ops.face_scores(cls)
 
 
 class PBAnchorTargets(object):

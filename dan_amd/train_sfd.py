@@ -66,7 +66,7 @@ class SFDModel(object):
         """eval_sfd.py:262-283: (bboxes_pred [B,A,4], face scores [B,A])."""
         loc, cls = self.forward(images_u8)
         boxes = anchors.enc.batch_decode_anchors(loc, *anchors.anchors[:4])
-        return boxes, torch.softmax(cls, dim=-1)[..., 1]
+        return boxes, ops.face_scores(cls)
 
 
 def _tree_clone(t):

@@ -278,6 +278,11 @@ int danhip_encode_anchors_batched(const float* ymin, const float* xmin, const fl
 int danhip_decode_anchors(const float* pred, const float* ymin, const float* xmin, const float* ymax, const float* xmax,
                           float* boxes, int32_t B, int32_t A, float ps0, float ps1, float ps2, float ps3, void* stream);
 
+/* Face score of two-way logits: score[i] = softmax(cls[i, 0:2])[1] (tf.nn.softmax(cls_pred)[:, -1]: eval_dan.py:356,371, eval_sfd.py:281) and /
+ * or the easy-anchor mask (score > threshold) as int32 (train_dan.py:438-439, eval_dan.py:386).  cls fp32 [n, 2]; score / mask [n], either
+ * may be NULL. */
+int danhip_face_scores(const float* cls, float* score, int32_t* mask, float threshold, int64_t n, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Deformable convolution (cpp/Deform: DeformConvOp deform_conv.cc:51-167,392-535; DeformConvBackpropOp :170-189,635-771;

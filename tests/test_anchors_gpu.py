@@ -194,3 +194,23 @@ def test_encode_pa_anchors_vs_oracle(scale, mining, hw, dev):
             assert np.allclose(tg[:, 2:], t_ref[:, 2:], rtol=0, atol=4 * np.finfo(np.float32).eps * 5 * 4), (b, what)
         n_pos += int((l_ref == 1).sum())
     assert n_pos > 0
+
+
+def test_face_scores_kernel_matches_the_oracle_softmax(dev):
+    """danhip_face_scores: softmax(cls)[:, 1] of two-way logits and the easy-anchor mask (score > 0.03), against oracle.anchors.softmax_np
+    (exp(x - max) / sum in fp32) — large and tiny logits included; the mask agrees wherever the score is not within 1e-6 of the threshold."""
+    import numpy as np
+    import torch
+    from dan_amd import ops
+    from oracle import anchors as OA
+    g = torch.Generator().manual_seed(77)
+    cls = torch.randn((3, 5000, 2), generator=g) * 6.0
+    cls[0, :10] = torch.tensor([[80.0, -80.0], [-80.0, 80.0], [0.0, 0.0], [1e-8, -1e-8], [30.0, 29.999]]).repeat(2, 1)
+    score, mask = ops.face_scores(cls.to(dev), 0.03)
+    only = ops.face_scores(cls.to(dev))
+    ref = OA.softmax_np(cls.numpy())[..., 1]
+    got = score.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-6
+    assert torch.equal(only, score) and mask.dtype == torch.int32
+    sure = np.abs(ref - 0.03) > 1e-6
+    assert np.array_equal(mask.cpu().numpy()[sure], (ref > np.float32(0.03)).astype(np.int32)[sure])
