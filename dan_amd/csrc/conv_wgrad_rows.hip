@@ -378,29 +378,36 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
-// Second pass of the slab form: one thread per float4 of a (ci, co) tile sums it over the splits and adds the four values (four
+// Second pass of the slab form: a 256-thread workgroup owns 64 consecutive float4 slots of one (ci, co) tile; wave w sums the splits
+// w, w + 4, ... (eight independent 16-byte loads in flight per lane), the four partial sums meet in LDS and wave 0 adds the result (four
 // consecutive ci of one co) into the HWIO gradient.  Slot -> element as in the kernel above: q = (t * NO + o) * 512 + wave * 64 + lane.
 template <int COT>
 __global__ __launch_bounds__(256) void wg_rows_reduce_kernel(const WgRowsArgs a) {
   constexpr int NO = COT / 32, TILE = 9 * NO * 512;
+  __shared__ f32x4 part[4][64];
   const int pairs = a.ci_tiles * a.co_tiles;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= pairs * TILE) return;
-  const int pair = gid / TILE, q = gid - pair * TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int chunk = blockIdx.x;                       // 64-slot chunk; TILE % 64 == 0, so a chunk never straddles two tiles
+  const int pair = chunk / (TILE / 64), q = (chunk - pair * (TILE / 64)) * 64 + lane;
   const f32x4* src = reinterpret_cast<const f32x4*>(a.slab) + q;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   auto blk = [&](int split) -> size_t {             // the block that computed (split, pair): inverse of the kernel's mapping
     return a.xcd_grouped ? (size_t)(((split >> 3) * pairs + pair) * 8 + (split & 7)) : (size_t)(split * pairs + pair);
   };
-  int sp = 0;
-  for (; sp + 4 <= a.splits; sp += 4) {
-    const f32x4 v0 = __builtin_nontemporal_load(src + blk(sp) * TILE), v1 = __builtin_nontemporal_load(src + blk(sp + 1) * TILE);
-    const f32x4 v2 = __builtin_nontemporal_load(src + blk(sp + 2) * TILE), v3 = __builtin_nontemporal_load(src + blk(sp + 3) * TILE);
-    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int sp = w;
+  for (; sp + 28 < a.splits; sp += 32) {              // eight splits of this wave per round
+    f32x4 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_nontemporal_load(src + blk(sp + 4 * e) * TILE);
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
   }
-  for (; sp < a.splits; ++sp) s0 += __builtin_nontemporal_load(src + blk(sp) * TILE);
-  const f32x4 sum = (s0 + s1) + (s2 + s3);
-  const int to = q >> 9, wave = (q >> 6) & 7, lane = q & 63;
+  for (; sp < a.splits; sp += 4) s0 += __builtin_nontemporal_load(src + blk(sp) * TILE);
+  part[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w != 0) return;
+  const f32x4 sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const int to = q >> 9, wave = (q >> 6) & 7;
   const int t = to / NO, o = to - t * NO;
   const int wci = wave & 3, wco = wave >> 2, g = lane >> 4;
   const int co_tile = pair / a.ci_tiles, ci_tile = pair - co_tile * a.ci_tiles;
@@ -451,8 +458,8 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   if (a.slab) {
-    const int threads = pairs * 9 * (COT / 32) * 512;
-    hipLaunchKernelGGL((wg_rows_reduce_kernel<COT>), dim3((threads + 255) / 256), dim3(256), 0, s, a);
+    const int chunks = pairs * 9 * (COT / 32) * 512 / 64;
+    hipLaunchKernelGGL((wg_rows_reduce_kernel<COT>), dim3(chunks), dim3(256), 0, s, a);
     DH_LAUNCH_CHECK();
   }
   return DANHIP_OK;

@@ -131,6 +131,8 @@ class VGG16Backbone(object):
             if wf is None or bf is None:
                 wf, bf = torch.cat([wl, wc], dim=3).contiguous(), torch.cat([bl, bc])
             h = ops.conv2d(feat, wf, bf, stride=1, relu=False, out_f32=True)
+            if ops.TRACE is not None and ncls > 2:           # the max-out decision of this level (tests: imposed on the oracle graph)
+                ops.TRACE.setdefault("maxout", {})[id(wc)] = h.detach()[..., 4:]
             loc, cls = ops.head_split(h, loc, cls, neg_maxout[ind], pos_maxout[ind], off)
             off += feat.shape[1] * feat.shape[2]
         return loc, cls

@@ -61,6 +61,17 @@ def _relu(P, y, scope):
     return torch.relu(y)
 
 
+def _maxout(P, c, depth, neg_maxout, pos_maxout, scope):
+    """T.maxout_cls; with P.impose the arg-max among the background logits comes from the recorded head output (depth 1)."""
+    ref = None if P.impose is None else P.impose.get("maxout", {}).get(scope + "/kernel")
+    if ref is None or pos_maxout + neg_maxout <= 2:
+        return T.maxout_cls(c, depth, neg_maxout, pos_maxout)
+    assert depth == 1 and pos_maxout == 1 and ref.shape == c.shape, (scope, tuple(ref.shape), tuple(c.shape))
+    idx = ref[..., :neg_maxout].argmax(-1, keepdim=True)
+    neg = torch.gather(c[..., :neg_maxout], -1, idx)
+    return torch.cat([neg, c[..., -1:]], dim=-1)
+
+
 def max_pool(P, x):
     """tf.layers.max_pooling2d([2,2],[2,2],'same') (net/sfd_net.py:132-143); with P.impose the arg-max positions come from the recorded
     pre-pool activation (same window scan order: the first maximum wins)."""
@@ -147,7 +158,7 @@ def predict_module(P, feats, pos_maxout, neg_maxout, depth, name, shared_conv=Fa
             f = conv_relu(P, f, f.shape[-1], (3, 3), 1, "{}/shared_conv_{}".format(name, i))
         locs.append(conv(P, f, depth[i] * 4, (3, 3), 1, "{}/loc_{}".format(name, i), relu=False))
         c = conv(P, f, depth[i] * (pos_maxout[i] + neg_maxout[i]), (3, 3), 1, "{}/cls_{}".format(name, i), relu=False)
-        clss.append(T.maxout_cls(c, depth[i], neg_maxout[i], pos_maxout[i]))
+        clss.append(_maxout(P, c, depth[i], neg_maxout[i], pos_maxout[i], "{}/cls_{}".format(name, i)))
     return locs, clss
 
 
