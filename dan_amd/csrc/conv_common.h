@@ -60,7 +60,9 @@ const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad);
 const char* danhip_wgrad_rows_label(const danhip_conv_desc* d);
 // Pointwise (1x1 / stride 1) weight gradient, 256 x 256 gradient tile per workgroup (conv_wgrad_pw.hip); same return convention.
 const char* danhip_wgrad_pw_label(const danhip_conv_desc* d);
-int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
+int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
+                           void* ws = nullptr, size_t ws_bytes = 0);
+size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d);
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
                              void* ws = nullptr, size_t ws_bytes = 0);
 size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d);

@@ -254,7 +254,9 @@ extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d)
 extern "C" size_t danhip_conv2d_bwd_weight_workspace_bytes(const danhip_conv_desc* d) {
   if (!d) return 0;
   static const int mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();      // 0: always the atomic epilogue (A/B)
-  return mode ? danhip_wgrad_rows_workspace_bytes(d) : 0;
+  if (!mode) return 0;
+  const size_t r = danhip_wgrad_rows_workspace_bytes(d);
+  return r ? r : danhip_wgrad_pw_workspace_bytes(d);
 }
 
 extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
@@ -278,7 +280,7 @@ extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint
   {
     const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
     if (hr <= 0) return hr;
-    const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream);
+    const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
     if (pr <= 0) return pr;
   }
   WgradArgs a{};

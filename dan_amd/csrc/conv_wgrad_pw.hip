@@ -14,6 +14,7 @@
 // (wave tile 128 ci x 64 co = 32 accumulators: 24 transposing reads per 32 MFMAs) and walks its share of 32-pixel K-steps through a
 // 4-deep LDS ring (X: four [32 px][64 ci] sub-tiles, dY: two [32 px][128 co] sub-tiles per step, the swizzles of the row kernel).
 // Waves whose ci / co range lies beyond the layer's channels skip their MFMAs; partial sums are combined with fp32 atomics.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -27,6 +28,8 @@ struct WgPwArgs {
   float* db;           // [Cout] or null
   int M, C, Co8, Cout, cin_real;
   int ksteps, steps_per_split, ci_tiles, co_tiles, xcd_grouped;
+  float* slab;         // optional: partial tiles as plain stores + wg_pw_reduce_kernel (short launches; see conv_wgrad_rows.hip)
+  int splits;
   FastDiv div_ci, div_pairs;
 };
 
@@ -243,7 +246,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   wp_wait_vmcnt<0>();
 
   // ---- epilogue: lane holds dW[ci = ci0 + wci*128 + i*16 + g*4 + r][co = co0 + wco*64 + o*16 + (lane & 15)]
-  if (active)
+  if (a.slab) {                                        // slab form: register order, 1 KiB per wave-instruction, slots [i*4 + o][wave][lane]
+    if (active) {
+      f32x4* dst = reinterpret_cast<f32x4*>(a.slab) + (size_t)blockIdx.x * (32 * 512) + wave * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) __builtin_nontemporal_store(acc[i][o], dst + (i * 4 + o) * 512);
+    }
+  } else if (active)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -263,6 +274,49 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int co = co0 + wco * 64 + (wci * 2 + e) * 16 + (lane & 15);
       if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, accb[e][0]);
     }
+  }
+}
+
+// Second pass of the slab form (the combine of conv_wgrad_rows.hip for the 256 x 256 tile): a workgroup owns 64 consecutive float4 slots,
+// wave w sums the splits w, w + 4, ..., wave 0 adds the total into dW[ci][co].  Slots of waves without real channels were never written
+// and are skipped (the same test as the kernel's `active`).
+__global__ __launch_bounds__(256) void wg_pw_reduce_kernel(const WgPwArgs a) {
+  constexpr int TILE = 32 * 512;
+  __shared__ f32x4 part[4][64];
+  const int pairs = a.ci_tiles * a.co_tiles;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int chunk = blockIdx.x;
+  const int pair = chunk / (TILE / 64), q = (chunk - pair * (TILE / 64)) * 64 + lane;
+  const int io = q >> 9, wave = (q >> 6) & 7;
+  const int wci = wave >> 2, wco = wave & 3;
+  const int co_tile = pair / a.ci_tiles, ci_tile = pair - co_tile * a.ci_tiles;
+  const int ci0 = ci_tile * 256, co0 = co_tile * 256;
+  if (!(ci0 + wci * 128 < a.C && co0 + wco * 64 < a.Co8)) return;       // (uniform over the workgroup: `wave` is the same for its 64 slots)
+  const f32x4* src = reinterpret_cast<const f32x4*>(a.slab) + q;
+  auto blk = [&](int split) -> size_t {
+    return a.xcd_grouped ? (size_t)(((split >> 3) * pairs + pair) * 8 + (split & 7)) : (size_t)(split * pairs + pair);
+  };
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  int sp = w;
+  for (; sp + 28 < a.splits; sp += 32) {
+    f32x4 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_nontemporal_load(src + blk(sp + 4 * e) * TILE);
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
+  }
+  for (; sp < a.splits; sp += 4) s0 += __builtin_nontemporal_load(src + blk(sp) * TILE);
+  part[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w != 0) return;
+  const f32x4 sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const int i = io >> 2, o = io & 3, g = lane >> 4;
+  const int co = co0 + wco * 64 + o * 16 + (lane & 15);
+  if (co >= a.Cout) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ci = ci0 + wci * 128 + i * 16 + g * 4 + r;
+    if (ci < a.cin_real) a.dw[(size_t)ci * a.Cout + co] += sum[r];
   }
 }
 
@@ -290,8 +344,23 @@ static bool wg_pw_eligible(const danhip_conv_desc* d) {
 
 const char* danhip_wgrad_pw_label(const danhip_conv_desc* d) { return wg_pw_eligible(d) ? "conv_wgrad_pw_kernel" : nullptr; }
 
+size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d) {
+  if (!wg_pw_eligible(d)) return 0;
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  const int pairs = ((d->Cin + 255) / 256) * ((co8 + 255) / 256);
+  const int ksteps = (d->N * d->H * d->W + 31) / 32;
+  int splits = wp_cu_count() / pairs;
+  if (splits < 1) splits = 1;
+  if (splits > ksteps) splits = ksteps;
+  const int steps_per_split = (ksteps + splits - 1) / splits;
+  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  if (splits < 2 || (slab_mode != 2 && steps_per_split > 192)) return 0;      // long launches keep the atomic epilogue
+  return (size_t)wp_cu_count() * 32 * 512 * 16;
+}
+
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
-int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s) {
+int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
+                           void* ws, size_t ws_bytes) {
   if (!wg_pw_eligible(d)) return 1;
   constexpr int LDS = 4 * (16384 + 16384);
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
@@ -311,7 +380,16 @@ int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf1
   a.div_ci = make_fastdiv(a.ci_tiles);
   a.div_pairs = make_fastdiv(pairs);
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
+  a.splits = splits;
+  // slab form for short launches only (see conv_wgrad_rows.hip: on long ones the atomic tail hides under the other blocks' MFMAs)
+  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  a.slab = (slab_mode && ws && ws_bytes >= danhip_wgrad_pw_workspace_bytes(d) && splits >= 2 && (slab_mode == 2 || a.steps_per_split <= 192))
+               ? reinterpret_cast<float*>(ws) : nullptr;
   hipLaunchKernelGGL(conv_wgrad_pw_kernel, dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
+  if (a.slab) {
+    hipLaunchKernelGGL(wg_pw_reduce_kernel, dim3(pairs * (32 * 512 / 64)), dim3(256), 0, s, a);
+    DH_LAUNCH_CHECK();
+  }
   return DANHIP_OK;
 }

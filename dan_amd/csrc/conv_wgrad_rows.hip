@@ -488,6 +488,16 @@ const char* danhip_wgrad_rows_label(const danhip_conv_desc* d) {
 size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d) {
   if (!wg_rows_eligible(d)) return 0;
   const int cot = wg_rows_cot(d);
+  // the launch geometry of launch_wg_rows: the slab form is taken for short launches only (rows_per_split <= 192)
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  const int pairs = (d->Cin / 64) * ((co8 + cot - 1) / cot);
+  const int total_rows = d->N * ((d->W + 31) / 32) * d->H;
+  int splits = wr_cu_count() / pairs;
+  if (splits < 1) splits = 1;
+  if (splits > total_rows) splits = total_rows;
+  const int rows_per_split = (total_rows + splits - 1) / splits;
+  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  if (splits < 2 || (slab_mode != 2 && rows_per_split > 192)) return 0;
   return (size_t)wr_cu_count() * 9 * (cot / 32) * 512 * 16;
 }
 

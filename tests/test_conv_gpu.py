@@ -521,7 +521,10 @@ def test_forward_kernel_writes_the_relu_bit_masks(shape, pool, dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 64, 64, 128, 3, 3, 1), (3, 40, 40, 256, 256, 3, 3, 1), (2, 16, 32, 256, 8, 3, 3, 1), (2, 32, 64, 256, 72, 3, 3, 1),
-                                   (5, 56, 96, 128, 128, 3, 3, 1), (1, 33, 47, 64, 64, 3, 3, 1)])
+                                   (5, 56, 96, 128, 128, 3, 3, 1), (1, 33, 47, 64, 64, 3, 3, 1),
+                                   # pointwise (conv_wgrad_pw.hip): whole tile, ragged ci / co tiles (inactive waves), K = 2304, several tiles
+                                   (2, 48, 48, 256, 256, 1, 1, 1), (1, 64, 72, 2304, 256, 1, 1, 1), (2, 80, 80, 512, 64, 1, 1, 1), (3, 40, 40, 320, 192, 1, 1, 1),
+                                   (2, 50, 50, 128, 512, 1, 1, 1)])
 def test_weight_gradient_slab_form_equals_the_atomic_form(shape, dev):
     """danhip_conv2d_bwd_weight_ws (partial tiles as plain stores + a combine pass) against danhip_conv2d_bwd_weight (fp32 atomics): same
     += semantics on a pre-filled gradient, equal up to fp32 summation order; both against the oracle convolution's weight gradient."""
