@@ -37,6 +37,18 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (the stamp tools/pmc_traffic.py writes into the PMC traffic file)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = (glob.glob(os.path.join(ROOT, "dan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dan_amd", "csrc", "*.h")) +
+             glob.glob(os.path.join(ROOT, "dan_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "include", "danhip.h")])
+    for f in sorted(files):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle (PyTorch-CPU fp32 restatement of train_sfd.py's step; TF 1.8 is not installable offline) timed on
     the host cores on a bounded sample: batch 1 at 640x640, fwd + bwd + momentum step."""
@@ -292,12 +304,21 @@ def main():
         stats.sort(reverse=True)
         ms, label, n, fl = stats[0]
         achieved = fl / (ms * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_bench.sh), if present
-        tj = os.path.join(ROOT, "profiles", "r2", "pmc_bench_traffic.json")      # regenerated for this round's binary (tools/pmc_bench.sh)
+        # HBM bytes per launch from the committed PMC passes (tools/pmc_bench.sh; PMC collection needs its own rocprofv3 runs, so it cannot
+        # happen inside this process).  The file is stamped with the hash of the kernel sources it was measured on: with other sources
+        # the numbers describe another binary and `traffic` is null (the stale figure is reported beside it, flagged).
+        traffic, traffic_stale, pmc = None, None, {}
+        tj = os.path.join(ROOT, "profiles", "r3", "pmc_bench_traffic.json")
         if os.path.exists(tj):
-            t = json.load(open(tj)).get(label)
-            if t:
+            pmc = json.load(open(tj))
+            t = pmc.get(label)
+            same = pmc.get("_meta", {}).get("csrc_sha256") == csrc_hash()
+            if t and same:
                 traffic = round(t["hbm_bytes_per_launch"])
+            elif t:
+                traffic_stale = {"bytes": round(t["hbm_bytes_per_launch"]), "why": "profiles/r3/pmc_bench_traffic.json was measured on other kernel sources"}
+            if not same:
+                pmc = {}
         calib = None        # library-GEMM peak measured on a box of this pool (tools/calibrate_peaks.py), next to the datasheet peak
         cj = os.path.join(ROOT, "profiles", "r1", "calibration.json")
         if os.path.exists(cj):
@@ -312,7 +333,10 @@ def main():
             serial = {"achieved": round(sach, 2), "frac": round(sach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(sms / len(prof_serial[label]), 4),
                       "what": "same kernel with the weight-gradient stream off, 2 steps after the timed region"}
         roof = {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "launches_per_step": n // prof_steps,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_stale": traffic_stale,
+                "traffic_over_algorithmic": (round(traffic / (sum(prof_bytes.get(label, [])) / max(1, len(prof_bytes.get(label, [])))), 3)
+                                             if traffic and prof_bytes and prof_bytes.get(label) else None),
+                "launches_per_step": n // prof_steps,
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
                 "share_of_step_time": round(ms / prof_steps / (dt / args.steps * 1e3), 4), "calibrated": calib,
                 "whole_step": {"what": "all convolution launches of the timed region (forward, data and weight gradients): algorithmic FLOP / wall time",
@@ -330,7 +354,8 @@ def main():
                 if nb > 0 and f_ / nb < 310.0:                      # below the MFMA / HBM ridge (2.5 PFLOP/s / 8 TB/s)
                     hbm.append({"kernel": l_, "launches_per_step": n_ // prof_steps, "ms_per_step": round(m_ / prof_steps, 3),
                                 "achieved": round(nb / (m_ * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(nb / (m_ * 1e-3) / 8e12, 4),
-                                "flop_per_byte": round(f_ / nb, 1)})
+                                "flop_per_byte": round(f_ / nb, 1), "algorithmic_bytes_per_launch": round(nb / n_),
+                                "traffic": (round(pmc[l_]["hbm_bytes_per_launch"]) if l_ in pmc else None)})
         roof["hbm_bound_convs"] = hbm[:8]
         out = {
             "metric": "640x640 images/sec/node (train fwd+bwd)", "value": round(world * B * args.steps / dt, 3), "unit": "images/sec",

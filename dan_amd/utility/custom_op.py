@@ -88,6 +88,8 @@ def deform_conv_2d(inputs, num_outputs, kernel_size_h=3, kernel_size_w=3, stride
     ow = variables.get(name + "/conv2d/kernel", (kernel_size_h, kernel_size_w, cin, noff), "zeros")
     ob = variables.get(name + "/conv2d/bias", (noff,), "zeros")
     offset = ops.conv2d(inputs, ow, ob, stride=stride, relu=False)
+    if ops.TRACE is not None:                          # tests: the sampling positions of this pass (imposed on the oracle graph)
+        ops.TRACE.setdefault("offsets", {})[id(ow)] = offset.detach()
     kernel = variables.get(name + "/kernel", (num_outputs, cin, kernel_size_h, kernel_size_w), kernel_initializer)
     bias = None if no_bias else variables.get(name + "/bias", (num_outputs,), "zeros")
     return deform_conv_op(inputs, kernel, offset, [1, 1, dilate_rate, dilate_rate], "SAME", [1, 1, stride, stride], 1, deformable_group, bias=bias, relu=relu)

@@ -66,10 +66,11 @@ def _maxout(P, c, depth, neg_maxout, pos_maxout, scope):
     ref = None if P.impose is None else P.impose.get("maxout", {}).get(scope + "/kernel")
     if ref is None or pos_maxout + neg_maxout <= 2:
         return T.maxout_cls(c, depth, neg_maxout, pos_maxout)
-    assert depth == 1 and pos_maxout == 1 and ref.shape == c.shape, (scope, tuple(ref.shape), tuple(c.shape))
-    idx = ref[..., :neg_maxout].argmax(-1, keepdim=True)
-    neg = torch.gather(c[..., :neg_maxout], -1, idx)
-    return torch.cat([neg, c[..., -1:]], dim=-1)
+    assert depth == 1 and ref.shape == c.shape, (scope, tuple(ref.shape), tuple(c.shape))
+    pick = lambda lo, hi: torch.gather(c[..., lo:hi], -1, ref[..., lo:hi].argmax(-1, keepdim=True))
+    neg = pick(0, neg_maxout) if neg_maxout > 1 else c[..., :1]
+    pos = pick(neg_maxout, neg_maxout + pos_maxout) if pos_maxout > 1 else c[..., -1:]
+    return torch.cat([neg, pos], dim=-1)
 
 
 def max_pool(P, x):
@@ -259,6 +260,12 @@ def deform_conv_2d(P, x, num_outputs, name, dg=4, no_bias=False, relu=False):
     relu: the activation the graphs apply right after (net/danet_deform.py:281), folded in here so that the bf16-storage
     emulation can round where the MI355X build stores (sampled columns, the activated output, their gradients)."""
     off = conv(P, x, 2 * dg * 9, (3, 3), 1, name + "/conv2d", relu=False, init="zeros")
+    if P.impose is not None and name + "/conv2d/kernel" in P.impose.get("offsets", {}):
+        # the sampling cell floor(position) is a discrete decision too: take the offsets' VALUES from the recorded run (straight-through:
+        # the gradient still flows into this graph's offset convolution)
+        ref = P.impose["offsets"][name + "/conv2d/kernel"]
+        assert ref.shape == off.shape, (name, tuple(ref.shape), tuple(off.shape))
+        off = off + (ref - off).detach()
     w = P.get(name + "/kernel", (num_outputs, x.shape[-1], 3, 3), "glorot_oihw")
     b = None if no_bias else P.get(name + "/bias", (num_outputs,), "zeros")
     xn, on = x.permute(0, 3, 1, 2), off.permute(0, 3, 1, 2)

@@ -83,6 +83,7 @@ def hip_grads(model, flat, imgs, Gs, dev, trace=None):
         name_of = {id(p): n for n, p in named}
         trace["pools"] = [t.float().cpu() for t in rec.pop("pools", [])]
         trace["maxout"] = {name_of[k]: v.float().cpu() for k, v in rec.pop("maxout", {}).items() if k in name_of}
+        trace["offsets"] = {name_of[k]: v.float().cpu() for k, v in rec.pop("offsets", {}).items() if k in name_of}
         trace["relu"] = {name_of[k]: v.float().cpu() for k, v in rec.items() if k in name_of}
     torch.autograd.backward(outs, [G.to(dev) for G in Gs])
     torch.cuda.synchronize()

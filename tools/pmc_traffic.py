@@ -18,6 +18,16 @@ for k, c in acc.items():
     fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024.0 * 2.0
     write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024.0
     res[label] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "launches": len(c["FETCH_SIZE"])}
+# stamp: hash of the kernel sources the measured library was built from — bench.py reports the traffic only for the same sources
+import hashlib
+root_repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root_repo, "dan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root_repo, "dan_amd", "csrc", "*.h")) +
+                glob.glob(os.path.join(root_repo, "dan_amd", "csrc", "*.cpp")) + [os.path.join(root_repo, "include", "danhip.h")]):
+    h.update(open(f, "rb").read())
+res["_meta"] = {"csrc_sha256": h.hexdigest(), "what": "HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; gfx950 fetch correction), "
+                "two separate rocprofv3 --pmc passes over `bench.py --steps 2 --warmup 1` (tools/pmc_bench.sh)"}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+res.pop("_meta")
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
     print("%-60s %8.1f MB/launch  x%d" % (k, v["hbm_bytes_per_launch"] / 1e6, v["launches"]))
