@@ -22,6 +22,7 @@
 // output channels of one pixel (8-byte bf16 / 16-byte fp32 stores into NHWC).
 // LDS swizzles (16-byte chunks, applied on the DMA source side and on the read side): weight rows by (row & 7), patch rows
 // by the patch COLUMN (hx & 7) so that a tap's row shift is a pure immediate offset; both conflict-free for ds_read_b128.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -738,7 +739,8 @@ template <int TH, int TW, int BN, int WM, int WN, int TPS, int NSW, bool DGRAD, 
 int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int PPIECES = ((TH + 2) * (TW + 2) + 7) / 8;
   constexpr int LDS0 = 2 * PPIECES * 1024 + NSW * TPS * BN * 128;
-  constexpr int LDS = LDS0 + (NCU == 0 ? 8192 : 0);     // + the bias vector (forward, Co <= 2048 floats) / the item's 4 KiB ReLU bit mask (data gradient)
+  // + the bias vector (forward, Co <= 2048 floats; <= 512 in the 3-taps-per-phase 64-wide form, which fills the LDS) / the item's 4 KiB ReLU bit mask
+  constexpr int LDS = LDS0 + (NCU == 0 ? (TPS == 3 ? 2048 : 8192) : 0);
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, WM, WN, TPS, NSW, DGRAD, NCU, POOL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
@@ -779,6 +781,8 @@ int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
       return p.th == 8 ? launch_halo_cfg<8, 32, 128, 4, 2, 1, 4, false, 0, true>(a, s) : launch_halo_cfg<16, 16, 128, 4, 2, 1, 4, false, 0, true>(a, s);
   }
   if (p.th == 8) {
+    static const int exp3 = [] { const char* e = getenv("DANHIP_HALO_TPS3"); return e ? atoi(e) : 0; }();      // experiment: 64-wide tiles, 3 taps per phase
+    if (exp3 && !a.mask_bits && !a.bits_out && !a.pool_y && a.Co <= 512) return launch_halo_cfg<8, 32, 64, 8, 1, 3, 3, DGRAD>(a, s);
     if (p.bn == 128) return launch_halo_cfg<8, 32, 128, 4, 2, 1, 4, DGRAD>(a, s);
     return launch_halo_cfg<8, 32, 64, 8, 1, 1, 4, DGRAD>(a, s);
   }
