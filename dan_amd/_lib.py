@@ -140,6 +140,10 @@ def lib():
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.argtypes = []
+        L.danhip_set_option.restype = ctypes.c_int
+        L.danhip_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.danhip_get_option.restype = ctypes.c_int
+        L.danhip_get_option.argtypes = [ctypes.c_char_p]
         L.danhip_conv2d_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_conv2d_workspace_bytes.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_weight_workspace_bytes.restype = ctypes.c_size_t

@@ -1,6 +1,8 @@
 // Error plumbing of the C ABI: thread-local message, never throws.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "../../include/danhip.h"
 
@@ -21,4 +23,35 @@ extern "C" int danhip_act_dtype(void) {
 #else
   return DANHIP_BF16;
 #endif
+}
+
+// ---- kernel-selection switches (process-wide; initial values from the environment): danhip_set_option / danhip_get_option.
+//   "halo2"      DANHIP_HALO2       0 (default) / 1: 3x3 convolutions that fill 16 x 32 pixel tiles run on conv_halo2.hip instead of conv_halo.hip
+//   "splitk"     DANHIP_SPLITK      1 (default) / 0: split-K for maps with too few output tiles (when the caller passes scratch)
+//   "wgrad_slab" DANHIP_WGRAD_SLAB  1 (default: short launches) / 0 (never) / 2 (always): weight-gradient partials as stores + combine pass
+namespace {
+struct Opt { const char* name; const char* env; int def; int value; bool init; };
+Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, 0, false}, {"splitk", "DANHIP_SPLITK", 1, 0, false}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, 0, false},
+                {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, 0, false}};
+Opt* find_opt(const char* name) {
+  if (!name) return nullptr;
+  for (Opt& o : g_opts)
+    if (strcmp(o.name, name) == 0) {
+      if (!o.init) { const char* e = getenv(o.env); o.value = e ? atoi(e) : o.def; o.init = true; }
+      return &o;
+    }
+  return nullptr;
+}
+}  // namespace
+
+int danhip_option(const char* name) {
+  Opt* o = find_opt(name);
+  return o ? o->value : 0;
+}
+extern "C" int danhip_get_option(const char* name) { return danhip_option(name); }
+extern "C" int danhip_set_option(const char* name, int value) {
+  Opt* o = find_opt(name);
+  if (!o) { danhip_set_error("set_option: unknown option '%s'", name ? name : "(null)"); return DANHIP_EINVAL; }
+  o->value = value;
+  return DANHIP_OK;
 }

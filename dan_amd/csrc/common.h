@@ -31,6 +31,9 @@ typedef unsigned short bf16_t;  // raw bf16 storage
 // route_train_cell_kernel reading unset bucket counts), kernel nodes do.  ptr 16-byte aligned, bytes a multiple of 4.
 int danhip_zero_async(void* ptr, size_t bytes, hipStream_t stream);
 
+// kernel-selection switch by name (capi.cpp: danhip_set_option / environment default)
+int danhip_option(const char* name);
+
 // ---------------------------------------------------------------- error plumbing (never throws across the ABI)
 void danhip_set_error(const char* fmt, ...);
 #define DH_REQUIRE(cond, code, ...)                  \

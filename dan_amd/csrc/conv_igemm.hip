@@ -370,8 +370,7 @@ inline int igemm_bm(const ConvArgs& a) {
 // CU.  Returns the number of splits (1 = do not split) and the K tiles per split.
 int plan_splitk(const ConvArgs& a, int* kt_per_split) {
   *kt_per_split = a.ktiles;
-  static const int mode = [] { const char* e = getenv("DANHIP_SPLITK"); return e ? atoi(e) : 1; }();        // 0: off (A/B)
-  if (!mode || a.pool_y || a.bits_out || a.mask_bits) return 1;
+  if (!danhip_option("splitk") || a.pool_y || a.bits_out || a.mask_bits) return 1;        // (DANHIP_SPLITK=0 / danhip_set_option: A/B)
   const int bm = igemm_bm(a), bn = pick_bn(a.Co);
   const long tiles = (long)cdiv(a.M, bm) * cdiv(a.Co, bn);
   const int cus = igemm_cu_count();
@@ -431,6 +430,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (cr <= 0) return cr;
   const bool sk = prefer_splitk(a);                    // too few tiles for the persistent kernels: split K over workgroups instead
   if (!sk) {
+    const int h2 = danhip_launch_conv_halo2(a, s);     // 3x3 / stride-1, Cout % 128 == 0, maps that fill 16 x 32 tiles: 512-pixel halo tiles
+    if (h2 <= 0) return h2;
     const int hr = danhip_launch_conv_halo(a, s);      // 3x3 / stride-1 on large maps: halo-reuse kernel
     if (hr <= 0) return hr;
     const int pr = danhip_launch_conv_pointwise(a, s); // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
@@ -627,6 +628,13 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;
     const bool sk = !noscratch && wants_splitk(a);     // (callers that pass the scratch buffer: dan_amd.ops always does)
+    if (!sk) {
+      ConvArgs a2 = a;
+      if (which == 1) { if (masked) a2.mask = &dummy_mask; }
+      else { static const float one1 = 1.f; a2.bias = &one1; a2.relu = 1; }
+      const char* h2 = danhip_conv_halo2_label(a2, which == 1);
+      if (h2 && danhip_conv_halo_label(a, which == 1)) return h2;
+    }
     const char* hl = sk ? nullptr : danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
     if (which == 1) { if (masked) a.mask = &dummy_mask; }
@@ -755,7 +763,7 @@ extern "C" int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_
   a.bias = &one; a.relu = 1;
   if (danhip_conv_c8_label(a)) return with_pool ? 0 : 1;        // the first layer's store-bound kernel writes the mask beside its output
   if (danhip_conv_c64_eligible(a)) return 0;
-  if (!danhip_conv_halo_emits_bits(a)) return 0;
+  if (!danhip_conv_halo_emits_bits(a)) return 0;       // (every shape conv_halo2.hip takes passes this test too: Cout % 128 == 0)
   if (with_pool) { a.pool_y = &dummy; if (!danhip_conv_halo_pool_fusable(a)) return 0; }
   return 1;
 }
@@ -772,6 +780,7 @@ extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint
   a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
   a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits;
   if (danhip_conv_c8_label(a)) return danhip_launch_conv_c8(a, (hipStream_t)stream);
+  { const int h2 = danhip_launch_conv_halo2(a, (hipStream_t)stream); if (h2 <= 0) return h2; }
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }
 
@@ -870,5 +879,6 @@ extern "C" int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = nullptr; a.mask_bits = relu_bits; a.resid = nullptr; a.y = dx;
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
   if (danhip_conv_c64_eligible(a)) return danhip_launch_conv_c64(a, (hipStream_t)stream);
+  { const int h2 = danhip_launch_conv_halo2(a, (hipStream_t)stream); if (h2 <= 0) return h2; }
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }

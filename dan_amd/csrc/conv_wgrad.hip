@@ -253,7 +253,7 @@ extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d)
 
 extern "C" size_t danhip_conv2d_bwd_weight_workspace_bytes(const danhip_conv_desc* d) {
   if (!d) return 0;
-  static const int mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();      // 0: always the atomic epilogue (A/B)
+  const int mode = danhip_option("wgrad_slab");
   if (!mode) return 0;
   const size_t r = danhip_wgrad_rows_workspace_bytes(d);
   return r ? r : danhip_wgrad_pw_workspace_bytes(d);

@@ -353,7 +353,7 @@ size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d) {
   if (splits < 1) splits = 1;
   if (splits > ksteps) splits = ksteps;
   const int steps_per_split = (ksteps + splits - 1) / splits;
-  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  const int slab_mode = danhip_option("wgrad_slab");
   if (splits < 2 || (slab_mode != 2 && steps_per_split > 192)) return 0;      // long launches keep the atomic epilogue
   return (size_t)wp_cu_count() * 32 * 512 * 16;
 }
@@ -382,7 +382,7 @@ int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf1
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
   a.splits = splits;
   // slab form for short launches only (see conv_wgrad_rows.hip: on long ones the atomic tail hides under the other blocks' MFMAs)
-  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  const int slab_mode = danhip_option("wgrad_slab");
   a.slab = (slab_mode && ws && ws_bytes >= danhip_wgrad_pw_workspace_bytes(d) && splits >= 2 && (slab_mode == 2 || a.steps_per_split <= 192))
                ? reinterpret_cast<float*>(ws) : nullptr;
   hipLaunchKernelGGL(conv_wgrad_pw_kernel, dim3(pairs * splits), dim3(512), LDS, s, a);

@@ -453,7 +453,7 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   // The slab form pays when the launch is short (every block reaches its epilogue together and nothing hides the tail: 2-4 images per
   // GPU, the 40x40 / 20x20 levels); on long launches the blocks drift apart, the atomic tail hides under other blocks' MFMAs and the
   // extra pass costs more than it saves (batch 16: conv3_2 0.426 against 0.428 ms, conv2_2 0.479 against 0.455; profiles/r3).
-  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();      // 2: always (A/B)
+  const int slab_mode = danhip_option("wgrad_slab");
   if (a.slab && (splits < 2 || (slab_mode != 2 && a.rows_per_split > 192))) a.slab = nullptr;
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
@@ -496,7 +496,7 @@ size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d) {
   if (splits < 1) splits = 1;
   if (splits > total_rows) splits = total_rows;
   const int rows_per_split = (total_rows + splits - 1) / splits;
-  static const int slab_mode = [] { const char* e = getenv("DANHIP_WGRAD_SLAB"); return e ? atoi(e) : 1; }();
+  const int slab_mode = danhip_option("wgrad_slab");
   if (splits < 2 || (slab_mode != 2 && rows_per_split > 192)) return 0;
   return (size_t)wr_cu_count() * 9 * (cot / 32) * 512 * 16;
 }

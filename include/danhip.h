@@ -42,6 +42,14 @@ extern "C" {
 
 const char* danhip_last_error(void);
 int danhip_version(void);
+/* Process-wide kernel-selection switches (defaults from the environment variables in brackets):
+ *   "halo2"      [DANHIP_HALO2, 0]       1: 3x3 / stride-1 convolutions with Cout % 128 == 0 on maps that fill 16 x 32 pixel tiles run on the 512-pixel-tile
+ *                                           kernel (csrc/conv_halo2.hip) instead of csrc/conv_halo.hip
+ *   "splitk"     [DANHIP_SPLITK, 1]      0: never split K (danhip_conv2d_workspace_bytes answers 0)
+ *   "wgrad_slab" [DANHIP_WGRAD_SLAB, 1]  0: weight-gradient partial sums always by fp32 atomics; 2: always stores + combine pass; 1: by launch length
+ * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
+int danhip_set_option(const char* name, int value);
+int danhip_get_option(const char* name);
 int danhip_act_dtype(void);   /* DANHIP_BF16 or DANHIP_F16 */
 
 /* ------------------------------------------------------------------------------------------------

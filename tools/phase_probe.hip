@@ -31,7 +31,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // MODE 3: all eight waves run the same stream (reads of the next step interleaved with the MFMAs, one barrier per phase)
 template <int NM, int NR, int ND, int MODE>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const unsigned short* __restrict__ src, float* __restrict__ out,
-                                                                                          int phases, unsigned src_bytes) {
+                                                                                          int phases, unsigned src_bytes, unsigned window) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const unsigned long long a = (unsigned long long)src;
   const u32x4 rsrc = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, src_bytes, 0x00020000u};
   // fill the first 64 KiB of LDS once (so that the fragments are not all zeros: DVFS)
-  for (int i = 0; i < 8; ++i) dma16(rsrc, (unsigned)((blockIdx.x * 64 + wave * 8 + i) * 1024 + lane * 16) % (src_bytes - 16), lds0 + (wave * 8 + i) * 1024);
+  for (int i = 0; i < 8; ++i) dma16(rsrc, (unsigned)((blockIdx.x * 64 + wave * 8 + i) * 1024 + lane * 16) & (src_bytes - 1u), lds0 + (wave * 8 + i) * 1024);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     fa[i] = *reinterpret_cast<const bf16x8*>(smem + (i * 1024 + lane * 16));
     fb[i] = *reinterpret_cast<const bf16x8*>(smem + ((8 + i) * 1024 + lane * 16));
   }
-  unsigned doff = (unsigned)(blockIdx.x * 8 + wave) * 65536u + (unsigned)lane * 16u;      // this wave's DMA cursor in the source buffer
+  unsigned doff = (unsigned)(wave) * 65536u + (unsigned)lane * 16u;      // every workgroup walks the same window (the packed weights of a layer)      // this wave's DMA cursor in the source buffer
   const unsigned ring = 65536;                                                              // DMA lands in the second 64 KiB of LDS (never read: pure traffic)
 
   auto reads = [&](int first, int count, int ph) __attribute__((always_inline)) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto dmas = [&](int ph) __attribute__((always_inline)) {
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-      dma16(rsrc, doff % (src_bytes - 16), lds0 + ring + (unsigned)(((ph * ND + d) & 7) * 8 + wave) * 1024);
+      dma16(rsrc, doff & (window - 1u), lds0 + ring + (unsigned)(((ph * ND + d) & 7) * 8 + wave) * 1024);      // (src_bytes is a power of two)
       doff += 1024;
     }
   };
@@ -142,6 +142,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   out[(size_t)blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
 }
 
+static unsigned g_window = 2u << 20;
+
 template <int NM, int NR, int ND, int MODE>
 static void run(const char* name, const unsigned short* src, float* out, unsigned src_bytes, double mfma_only_tf) {
   const int lds = 128 * 1024;
@@ -149,11 +151,11 @@ static void run(const char* name, const unsigned short* src, float* out, unsigne
   const int phases = 400000 / NM;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes, g_window);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   const int reps = 5;
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes, g_window);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0;
@@ -172,10 +174,10 @@ static double rate(const unsigned short* src, float* out, unsigned src_bytes) {
   const int phases = 400000 / NM;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes, g_window);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((probe<NM, NR, ND, MODE>), dim3(256), dim3(512), lds, 0, src, out, phases, src_bytes, g_window);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0;
@@ -183,7 +185,9 @@ static double rate(const unsigned short* src, float* out, unsigned src_bytes) {
   return 256.0 * 8 * (double)phases * NM * 16384.0 / (ms / 5 * 1e-3) / 1e12;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) g_window = (unsigned)atoi(argv[1]) << 20;       // DMA source window in MiB (power of two): 2 = L2-resident weights, 512 = an HBM stream
+  printf("DMA source window: %u MiB\n", g_window >> 20);
   const unsigned src_bytes = 512u << 20;
   unsigned short* src;
   float* out;
@@ -212,5 +216,11 @@ int main() {
   run<96, 0, 0, 0>("barriers only, 96 MFMAs per phase", src, out, src_bytes, peak);
   run<32, 16, 0, 0>("reads, no DMA, 32", src, out, src_bytes, peak);
   run<32, 0, 3, 0>("DMA, no reads, 32", src, out, src_bytes, peak);
+  run<32, 16, 1, 0>("32 MFMA, 16 reads, 1 DMA", src, out, src_bytes, peak);
+  run<32, 16, 2, 0>("32 MFMA, 16 reads, 2 DMA", src, out, src_bytes, peak);
+  run<32, 12, 2, 0>("32 MFMA, 12 reads, 2 DMA (64px x 128co wave tile)", src, out, src_bytes, peak);
+  run<64, 24, 3, 0>("64 MFMA, 24 reads, 3 DMA, two groups", src, out, src_bytes, peak);
+  run<96, 36, 3, 0>("96 MFMA, 36 reads, 3 DMA", src, out, src_bytes, peak);
+  run<36, 7, 1, 0>("wgrad ratio, 1 DMA", src, out, src_bytes, peak);
   return 0;
 }
