@@ -18,17 +18,8 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-// bit r = packed 16-bit value r > 0 (patterns 1 .. +inf; NaNs compare false as in danhip_relu_bits)
-__device__ __forceinline__ unsigned c8_pos_bits8(const u32x4& t) {
-  unsigned byte = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned lo = t[e] & 0xffffu, hi = t[e] >> 16;
-    byte |= ((lo - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e);
-    byte |= ((hi - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e + 1);
-  }
-  return byte;
-}
+// bit r = packed 16-bit ReLU output r > 0 (conv_common.h)
+__device__ __forceinline__ unsigned c8_pos_bits8(const u32x4& t) { return dh_pos_bits8_acc<0>(t, 0u); }
 
 struct C8Geom {
   int units_x;            // ceil(W / 16)
@@ -110,8 +101,8 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
         lo[0] += bias[P][0]; lo[1] += bias[P][1]; lo[2] += bias[P][2]; lo[3] += bias[P][3];
         hi[0] += bias[P][4]; hi[1] += bias[P][5]; hi[2] += bias[P][6]; hi[3] += bias[P][7];
         if (a.relu) {
-          lo[0] = fmaxf(lo[0], 0.f); lo[1] = fmaxf(lo[1], 0.f); lo[2] = fmaxf(lo[2], 0.f); lo[3] = fmaxf(lo[3], 0.f);
-          hi[0] = fmaxf(hi[0], 0.f); hi[1] = fmaxf(hi[1], 0.f); hi[2] = fmaxf(hi[2], 0.f); hi[3] = fmaxf(hi[3], 0.f);
+          lo[0] = dh_relu(lo[0]); lo[1] = dh_relu(lo[1]); lo[2] = dh_relu(lo[2]); lo[3] = dh_relu(lo[3]);
+          hi[0] = dh_relu(hi[0]); hi[1] = dh_relu(hi[1]); hi[2] = dh_relu(hi[2]); hi[3] = dh_relu(hi[3]);
         }
         const u32x4 o = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
         if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(yo + P * 32));
@@ -120,11 +111,9 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
       }
     }
     // ReLU bit mask of the output for the next layer's data gradient (danhip_relu_bits layout: 8 bytes per pixel): this lane's two bytes
-    // are q and 4 + q of pixel px; the four lanes of a pixel (q = 0..3: lanes px, px + 16, px + 32, px + 48) are OR-ed by two shuffles
+    // are q and 4 + q of pixel px; the four lanes of a pixel (q = 0..3: lanes px, px + 16, px + 32, px + 48) are OR-ed by two row swaps
     if (a.bits_out) {                               // (uniform)
-      unsigned lo = pbyte[0] << (8 * q), hi = pbyte[1] << (8 * q);
-      lo |= (unsigned)__shfl_xor((int)lo, 16, 64); hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
-      lo |= (unsigned)__shfl_xor((int)lo, 32, 64); hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
+      const unsigned lo = dh_or_rows(pbyte[0] << (8 * q)), hi = dh_or_rows(pbyte[1] << (8 * q));
       if (q == 0 && t.x0 + px < a.W) *reinterpret_cast<uint2*>(a.bits_out + ((size_t)(unsigned)(t.base + px)) * 8) = uint2{lo, hi};
     }
   };

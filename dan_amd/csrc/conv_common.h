@@ -37,6 +37,45 @@ __device__ __forceinline__ unsigned pkmax_relu(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
+// ---- epilogue arithmetic shared by the tile kernels (measured with tools/halo2_trace.hip: the epilogues, not the waits around them, were
+// the longest stretch without MFMAs).
+// ReLU in ONE instruction (fmaxf compiles to a canonicalising v_max_f32 plus the max); max(NaN, 0) = 0 like fmaxf.
+__device__ __forceinline__ float dh_relu(float v) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// Two packed 16-bit ReLU OUTPUTS (>= +0 and never NaN after dh_relu) -> 1 per half that is > 0: min(x, 1) as unsigned 16-bit integers
+// (clang lowers the generic vector min to compares and selects, hence the asm).
+typedef __attribute__((ext_vector_type(2))) unsigned short dh_u16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned dh_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned dh_u32x4;
+__device__ __forceinline__ dh_u16x2 dh_pos2(unsigned packed) {
+  unsigned r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(packed), "s"(0x00010001u));
+  return __builtin_bit_cast(dh_u16x2, r);
+}
+// bits | (value r of the 8 packed ReLU outputs > 0) << (SHIFT + r): one v_pk_min_u16 + one v_dot2_u32_u16 per register (danhip_relu_bits
+// layout: bit r of the byte = channel 8 k + r)
+template <int SHIFT>
+__device__ __forceinline__ unsigned dh_pos_bits8_acc(const dh_u32x4& t, unsigned bits) {
+  static_assert(SHIFT == 0 || SHIFT == 8, "16-bit weights");
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    bits = __builtin_amdgcn_udot2(dh_pos2(t[e]), dh_u16x2{(unsigned short)(1u << (SHIFT + 2 * e)), (unsigned short)(2u << (SHIFT + 2 * e))}, bits, false);
+  return bits;
+}
+// x | x(lane ^ 16) | x(lane ^ 32) | x(lane ^ 48) with the gfx950 row swaps (VALU) instead of two ds_bpermute round trips:
+//   v_permlane16_swap(x, x) -> {rows [0,0,2,2], rows [1,1,3,3]};  v_permlane32_swap(y, y) -> {lower half twice, upper half twice}
+__device__ __forceinline__ unsigned dh_or_rows(unsigned x) {
+  const dh_u32x2 a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const unsigned y = a[0] | a[1];
+  const dh_u32x2 b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+  return b[0] | b[1];
+}
+// value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ unsigned dh_lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+
 // Halo-reuse 3x3/stride-1 kernel (conv_halo.hip).  Returns DANHIP_OK when it launched, 1 when the shape is not
 // eligible (caller falls back to the flat-M kernel), negative on a launch error.
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);

@@ -54,7 +54,7 @@ __device__ __forceinline__ void halo_finish4(const ConvArgs& a, const f32x4& acc
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     if (a.relu) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      for (int r = 0; r < 4; ++r) v[r] = dh_relu(v[r]);
     }
     if (a.out_f32) {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -95,7 +95,7 @@ __device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo
     for (int r = 0; r < 8; ++r) v[r] += b[r];
     if (a.relu) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+      for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
     }
     if (a.out_f32) {
       float* y = reinterpret_cast<float*>(a.y) + o;
@@ -125,24 +125,11 @@ __device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo
   return t;
 }
 
-// ReLU bit mask of 8 packed 16-bit activations (bit r = value r > 0): a 16-bit float is > 0 iff its bit pattern lies in [1, +inf]
-// (DH_POS_INF16; the patterns above are NaNs, which compare false like in danhip_relu_bits)
-__device__ __forceinline__ unsigned pos_bits8(const u32x4& t) {
-  unsigned byte = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const unsigned lo = t[e] & 0xffffu, hi = t[e] >> 16;
-    byte |= ((lo - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e);
-    byte |= ((hi - 1u) < DH_POS_INF16 ? 1u : 0u) << (2 * e + 1);
-  }
-  return byte;
-}
+// ReLU bit mask of 8 packed 16-bit ReLU OUTPUTS (bit r = value r > 0; conv_common.h: dh_pos_bits8_acc)
+__device__ __forceinline__ unsigned pos_bits8(const u32x4& t) { return dh_pos_bits8_acc<0>(t, 0u); }
 // OR over the four lanes that share frow (the wave's 64 channels of one pixel): lane fq contributes bytes fq (pair 0) and 4 + fq (pair 1)
 __device__ __forceinline__ uint2 gather_bits64(unsigned b0, unsigned b1, int fq) {
-  unsigned lo = b0 << (8 * fq), hi = b1 << (8 * fq);
-  lo |= (unsigned)__shfl_xor((int)lo, 16, 64); hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
-  lo |= (unsigned)__shfl_xor((int)lo, 32, 64); hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
-  return uint2{lo, hi};
+  return uint2{dh_or_rows(b0 << (8 * fq)), dh_or_rows(b1 << (8 * fq))};
 }
 
 // 16-byte LDS-DMA through a buffer descriptor: address = base + voff (per lane) + soff (uniform); a lane whose voff is out
@@ -423,7 +410,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int co = wn * TC + c * 16 + fq * 4 + r;
             if (ok && co < a.Co) {
               float v = acc[c][p][r] + (a.bias ? a.bias[co] : 0.f);
-              if (a.relu) v = fmaxf(v, 0.f);
+              if (a.relu) v = dh_relu(v);
               if (a.out_f32) reinterpret_cast<float*>(a.y)[m * a.Co + co] = v;
               else reinterpret_cast<bf16_t*>(a.y)[m * a.Co + co] = f2bf(v);
             }
@@ -453,10 +440,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
               const int bi = fq + q * 4;                                // byte of channels cb + q*32 .. +7
-              const unsigned byte = ((bi < 4 ? bb.x : bb.y) >> (8 * (bi & 3))) & 0xffu;
+              const int byte = (int)((bi < 4 ? bb.x : bb.y) >> (8 * (bi & 3)));
 #pragma unroll
-              for (int r = 0; r < 8; ++r)
-                if (!((byte >> r) & 1u)) acc[2 * q + (r >> 2)][p][r & 3] = 0.f;
+              for (int r = 0; r < 8; ++r) {                             // value & (bit ? ~0 : 0): v_bfe_i32 + v_and_b32
+                const float v = acc[2 * q + (r >> 2)][p][r & 3];
+                acc[2 * q + (r >> 2)][p][r & 3] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(byte, r, 1));
+              }
             }
           }
         }
@@ -547,7 +536,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const unsigned v = pkmax_relu(pk[q][p][e], pk[q][p + PV][e]);
-              m[e] = pkmax_relu(v, (unsigned)__shfl_xor((int)v, 1));
+              m[e] = pkmax_relu(v, dh_lane_xor1(v));
             }
             if (okp) *reinterpret_cast<u32x4*>(a.pool_y + op + q * 32) = m;
             if constexpr (EMIT_OK) pb2[q & 1] = pos_bits8(m);

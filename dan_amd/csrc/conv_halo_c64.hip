@@ -213,9 +213,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           for (int p = 0; p < NPT; ++p) w4[p] = *reinterpret_cast<const unsigned*>(smem + RWBASE + buf * 2048 + (wm * 64 + p * 16 + frow) * 8 + wn * 4);
 #pragma unroll
           for (int p = 0; p < NPT; ++p) {
-            const unsigned byte = (w4[p] >> (8 * fq)) & 0xffu;
+            const int byte = (int)(w4[p] >> (8 * fq));
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (!((byte >> r) & 1u)) acc[r >> 2][p][r & 3] = 0.f;
+            for (int r = 0; r < 8; ++r) {            // value & (bit ? ~0 : 0): v_bfe_i32 + v_and_b32
+              const float v = acc[r >> 2][p][r & 3];
+              acc[r >> 2][p][r & 3] = __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe(byte, r, 1));
+            }
           }
         }
         if (a.mask) {
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int r = 0; r < 8; ++r) v[r] += bv[r];
             if (a.relu) {
 #pragma unroll
-              for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+              for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
             }
             if (a.resid) {
               const uint4 in = *reinterpret_cast<const uint4*>(a.resid + o0);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned v = pkmax_relu(pk[p][e], pk[p + 2][e]);
-            m[e] = pkmax_relu(v, (unsigned)__shfl_xor((int)v, 1));
+            m[e] = pkmax_relu(v, dh_lane_xor1(v));
           }
           if (y < a.H && x < a.W && (frow & 1) == 0)
             *reinterpret_cast<u32x4*>(a.pool_y + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * 64 + cbase) = m;

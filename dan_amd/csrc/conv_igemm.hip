@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       }
       if (a.relu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = dh_relu(v[r]);
       }
       if (a.out_f32) {
         float* y = reinterpret_cast<float*>(a.y) + o;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int r = 0; r < 8; ++r) v[r] += bv[q][r];
             if (a.relu) {
 #pragma unroll
-              for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+              for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
             }
           } else {
             if (LD && a.mask) {
