@@ -36,6 +36,7 @@ struct HaloGeom {
   int cch;                  // 64-channel chunks of the input (C / 64)
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
   int crem;                 // C % 64 != 0: 16-byte pieces of the LAST input chunk that exist ((C % 64) / 8); 0 = whole chunks only
+  int b2;                   // 1: second barrier per step (option "halo_b2"); see the main loop's hand-off notes
   FastDiv div_tx, div_txy, div_nb;
 };
 
@@ -561,6 +562,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   //   * every wave has waited for its own pieces of weight tile c+1 (both groups issue tile c+D during cycle c);
   //   * stage (c+D) % NSW == (c-1) % NSW was last read by A in mem(c-1) and by B in the mem phase of cycle c-2;
   //   * the patch of chunk q+1 is issued at step 0 of chunk q and retired by the counted waits long before its first use.
+  // ONE barrier per cycle carries every hand-off (b1).  The second one (b2, after A's MFMA phase / B's memory phase; option "halo_b2") only
+  // forced the two groups' phases to alternate strictly, and cost 5-7 % (same-box A/B, profiles/r3/README.md): the alternation survives
+  // without it because each group's own program order is mem -> MFMA -> mem ..., re-aligned at every b1.  Why b1 alone is enough:
+  //   * slot (c+D) % NSW is written from cycle c on (A: in mem(c), i.e. after passing b1(c-1); B: after b1(c)).  Its last readers read
+  //     tile c-1: A in mem(c-1), complete (lgkmcnt(0)) before A arrives at b1(c-1); B in its memory phase of cycle c-2, complete before
+  //     B's MFMA phase of cycle c-1, i.e. before B arrives at b1(c-1).  A wave that has PASSED b1(c-1) knows every wave has arrived there.
+  //   * the same argument with chunks for the two patch buffers (written from step 0 of chunk q, last read for the last step of chunk
+  //     q-1) and for the ReLU-bit staging area (written in step 1 of an item, last read by the previous item's epilogues: A's in
+  //     mem(0), B's before its MFMA phase of step 0 -- both before b1 of step 0).
   // DMA queue of a wave, oldest first: A at its wait in cycle c: [W(c+1)] ... [W(c+D)] -> (D-1)*WL may stay in flight, plus
   // a patch if it was issued within the last D-1 cycles; B (which has issued up to cycle c-1): (D-2)*WL, patch age <= D-2.
   int chunk = 0, cc = 0;                           // running chunk number: patch buffer = chunk & 1
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __builtin_amdgcn_sched_barrier(0);
         mma(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();              // b2
+        if (g.b2) __builtin_amdgcn_s_barrier();    // b2
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
@@ -665,7 +675,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         w_prev = more_w;
         ++patch_age;
         if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
-        __builtin_amdgcn_s_barrier();              // b2
+        if (g.b2) __builtin_amdgcn_s_barrier();    // b2
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
@@ -741,6 +751,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.NB = NCU ? 1 : (a.Co + BN - 1) / BN;
   g.cch = (a.C + 63) / 64;
   g.crem = (a.C % 64) / 8;
+  g.b2 = danhip_option("halo_b2");
   g.div_tx = make_fastdiv(g.tiles_x);
   g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
   g.div_nb = make_fastdiv(g.NB);

@@ -28,7 +28,7 @@ namespace {
 
 struct Halo2Geom {
   int tiles_x, tiles_y, sp_items, NB, cch, grouped;      // cch = C / 32
-  int ablate;      // timing experiments (danhip_set_option("halo2_ablate")): 1 no patch DMA, 2 no weight DMA, 4 no output stores, 8 no fragment reads
+  int ablate;      // timing experiments (danhip_set_option("halo2_ablate")): 1 no patch DMA, 2 no weight DMA, 4 no output stores, 8 no fragment reads, 16 second barrier per step
   FastDiv div_tx, div_txy, div_nb;
 #ifdef H2_TRACE
   unsigned* trace;   // tools/halo2_trace.hip: [2 groups][128 steps][4 stamps] shader-clock values of workgroup 0, waves 0 and 4
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // The item's epilogue right after its last MFMAs, BEFORE b2: group B runs its own in the memory phase that is in progress, so the two
         // (~1000 instructions each, the only stretch without MFMAs) overlap instead of following each other in two steps.
         if (decltype(tapc)::value == 8 && cc + 1 == g.cch) epilogue();
-        __builtin_amdgcn_s_barrier();                // b2
+        if (g.ablate & 16) __builtin_amdgcn_s_barrier();         // b2: timing experiment only (see conv_halo.hip's hand-off notes)
         ++step_idx;
       };
       cycle(std::integral_constant<int, 0>{}); cycle(std::integral_constant<int, 1>{}); cycle(std::integral_constant<int, 2>{});
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (more_w) issue_w();
         w_prev = more_w;
         H2_STAMP(3);
-        __builtin_amdgcn_s_barrier();                // b2
+        if (g.ablate & 16) __builtin_amdgcn_s_barrier();         // b2: timing experiment only (see conv_halo.hip's hand-off notes)
         ++step_idx;
       };
       cycle(std::integral_constant<int, 0>{}); cycle(std::integral_constant<int, 1>{}); cycle(std::integral_constant<int, 2>{});

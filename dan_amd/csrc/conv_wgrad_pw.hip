@@ -30,6 +30,7 @@ struct WgPwArgs {
   int ksteps, steps_per_split, ci_tiles, co_tiles, xcd_grouped;
   float* slab;         // optional: partial tiles as plain stores + wg_pw_reduce_kernel (short launches; see conv_wgrad_rows.hip)
   int splits;
+  int b2;              // 1: second barrier per K-step (option "wgrad_b2")
   FastDiv div_ci, div_pairs;
 };
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __builtin_amdgcn_sched_barrier(0);
         if (k_begin + v + U < k_end) mma();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                // b2
+        if (a.b2) __builtin_amdgcn_s_barrier();      // b2
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
       step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mem(std::integral_constant<int, (U + 1) % DEPTH>{});
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                // b2
+        if (a.b2) __builtin_amdgcn_s_barrier();      // b2
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
       step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
@@ -381,6 +382,7 @@ int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf1
   a.div_pairs = make_fastdiv(pairs);
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
   a.splits = splits;
+  a.b2 = danhip_option("wgrad_b2");
   // slab form for short launches only (see conv_wgrad_rows.hip: on long ones the atomic tail hides under the other blocks' MFMAs)
   const int slab_mode = danhip_option("wgrad_slab");
   a.slab = (slab_mode && ws && ws_bytes >= danhip_wgrad_pw_workspace_bytes(d) && splits >= 2 && (slab_mode == 2 || a.steps_per_split <= 192))

@@ -41,6 +41,7 @@ struct WgRowsArgs {
   int tiles_x, total_rows, rows_per_split;
   int ci_tiles, co_tiles, xcd_grouped;
   int ablate;          // timing experiments only (DANHIP_WGRAD_ABLATE=1): skip the epilogue's atomics
+  int b2;              // 1: second barrier per K-step (option "wgrad_b2")
   float* slab;         // optional workspace: every block stores its partial tile here (plain 16-byte stores) and wg_rows_reduce_kernel combines
   int splits;
   FastDiv div_tx, div_h, div_ci, div_pairs;
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   // K-step v (ring slot U = v % 6):   A:  mem(v) + DMA(v+P) | b1 | MFMA(v) | b2        B:  MFMA(v) | b1 | mem(v+1) + DMA(v+1+P) | b2
   // A wave's pieces of K-step u are waited for (vmcnt(2(P-1)): the P-1 younger steps stay in flight) before b1 of cycle u-1; B reads
-  // them in the phase after that barrier, A one phase later.
+  // them in the phase after that barrier, A one phase later.  b2 is off by default (option "wgrad_b2"; -2.5 % on the layer set): a slot is
+  // rewritten only by waves that have passed the b1 after its last readers' reads completed (argument in conv_halo.hip's main loop).
   RowStep nxt;
   if (grp == 0) {
     gen_next(nxt, P);
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (flags & 1ull) mma(uc);
         flags >>= 1;
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                // b2
+        if (a.b2) __builtin_amdgcn_s_barrier();      // b2
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __builtin_amdgcn_sched_barrier(0);
         gen_next(nxt, P + 1);
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                // b2
+        if (a.b2) __builtin_amdgcn_s_barrier();      // b2
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
@@ -449,6 +451,7 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   a.xcd_grouped = (splits % 8 == 0 && pairs > 1) ? 1 : 0;
   static const int ablate = [] { const char* e = getenv("DANHIP_WGRAD_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
+  a.b2 = danhip_option("wgrad_b2");
   a.splits = splits;
   // The slab form pays when the launch is short (every block reaches its epilogue together and nothing hides the tail: 2-4 images per
   // GPU, the 40x40 / 20x20 levels); on long launches the blocks drift apart, the atomic tail hides under other blocks' MFMAs and the
