@@ -38,7 +38,28 @@ struct HaloGeom {
   int crem;                 // C % 64 != 0: 16-byte pieces of the LAST input chunk that exist ((C % 64) / 8); 0 = whole chunks only
   int b2;                   // 1: second barrier per step (option "halo_b2"); see the main loop's hand-off notes
   FastDiv div_tx, div_txy, div_nb;
+#ifdef H_TRACE
+  unsigned* trace;          // tools/halo2_trace.hip -DTRACE_HALO1: [2 groups][128 steps][4 stamps] shader clocks of workgroup 0, waves 0 and 4
+#endif
 };
+
+#ifdef H_TRACE
+// All-scalar time stamp into the upper half of the bias / bit staging area (forward with Co <= 1024 and the bit-mask data gradient of
+// 256-pixel tiles use only its lower 4 KiB); the dynamic LDS segment starts at LDS address 0.
+#define H_STAMP(slot)                                                                                               \
+  do {                                                                                                              \
+    if (blockIdx.x == 0 && (wave & 3) == 0 && tr_step < 128) {                                                       \
+      const unsigned t_ = (unsigned)__builtin_readcyclecounter();                                                   \
+      const unsigned sa_ = (unsigned)(SBIAS + 4096 + (((wave >> 2) * 128 + tr_step) * 4 + (slot)) * 4);             \
+      unsigned va_, vd_;                                                                                            \
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\tds_write_b32 %0, %1" : "=&v"(va_), "=&v"(vd_) : "s"(sa_), "s"(t_) : "memory"); \
+    }                                                                                                               \
+  } while (0)
+#define H_STEP_DONE() (++tr_step)
+#else
+#define H_STAMP(slot) do { } while (0)
+#define H_STEP_DONE() do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -574,6 +595,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // DMA queue of a wave, oldest first: A at its wait in cycle c: [W(c+1)] ... [W(c+D)] -> (D-1)*WL may stay in flight, plus
   // a patch if it was issued within the last D-1 cycles; B (which has issued up to cycle c-1): (D-2)*WL, patch age <= D-2.
   int chunk = 0, cc = 0;                           // running chunk number: patch buffer = chunk & 1
+  [[maybe_unused]] int tr_step = 0;
   int patch_age = 16;                              // cycles since this wave last issued a patch (large: outside every window)
   auto stage_of = [&](int step) __attribute__((always_inline)) -> int {
     return TPS == 3 ? step : (chunk + step) & (NSW - 1);      // TPS == 3: SPC == NSW; TPS == 1: SPC = 9 = 1 (mod 4)
@@ -589,6 +611,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int STEP = decltype(stepc)::value;
         // ---- mem phase: fragment reads first (their LDS latency runs under the epilogue / DMA issue below)
         const int wbase = offW + stage_of(STEP) * WBYTES;
+        H_STAMP(0);
         if constexpr (DGRAD) {                       // its HBM reads first: the fragment registers are not live across them
           if (pending) { epilogue(); pending = false; }
           __builtin_amdgcn_sched_barrier(0);
@@ -607,12 +630,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         else wait_vmcnt<(D - 1) * WL>();
         ++patch_age;
         __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): fragments are in registers before the MFMA phase starts
+        H_STAMP(1);
         __builtin_amdgcn_s_barrier();              // b1
+        H_STAMP(2);
         // ---- MFMA phase
         __builtin_amdgcn_sched_barrier(0);
         mma(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
+        H_STAMP(3);
         if (g.b2) __builtin_amdgcn_s_barrier();    // b2
+        H_STEP_DONE();
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
@@ -644,13 +671,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int STEP = decltype(stepc)::value;
         // ---- MFMA phase (step c)
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        H_STAMP(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(offW + stage_of(STEP) * WBYTES, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
+        H_STAMP(1);
         if (!w_prev) wait_vmcnt<0>();
         else if (patch_age <= D - 2) wait_vmcnt<(D - 2) * WL + PL>();
         else wait_vmcnt<(D - 2) * WL>();
         __builtin_amdgcn_s_barrier();              // b1
+        H_STAMP(2);
         // ---- mem phase (for step c+1): reads first
         constexpr int NSTEP = (STEP + 1) % SPC;
         const int nstage = TPS == 3 ? NSTEP : (chunk + STEP + 1) & (NSW - 1);
@@ -675,7 +705,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         w_prev = more_w;
         ++patch_age;
         if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        H_STAMP(3);
         if (g.b2) __builtin_amdgcn_s_barrier();    // b2
+        H_STEP_DONE();
       };
       cycle(std::integral_constant<int, 0>{});
       cycle(std::integral_constant<int, 1>{});
@@ -693,7 +725,20 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (last) break;
     }
   }
+#ifdef H_TRACE
+  wait_vmcnt<0>();
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = tid; i < 1024; i += 512) g.trace[i] = reinterpret_cast<const unsigned*>(smem + SBIAS + 4096)[i];
+#endif
 }
+
+#ifdef H_TRACE
+unsigned* h_trace_buffer() {
+  static unsigned* p = [] { void* q = nullptr; (void)hipMalloc(&q, 4096 + 64); (void)hipMemset(q, 0, 4096 + 64); return (unsigned*)q; }();
+  return p;
+}
+#endif
 
 struct HaloPlan {
   int th, tw, bn;
@@ -752,6 +797,9 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.cch = (a.C + 63) / 64;
   g.crem = (a.C % 64) / 8;
   g.b2 = danhip_option("halo_b2");
+#ifdef H_TRACE
+  g.trace = h_trace_buffer();
+#endif
   g.div_tx = make_fastdiv(g.tiles_x);
   g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
   g.div_nb = make_fastdiv(g.NB);

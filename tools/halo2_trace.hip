@@ -4,6 +4,7 @@
 //   group B:  0 step start   1 MFMAs issued   2 past barrier b1 (counted wait before it)             3 memory phase done
 // Build (the kernel source is compiled INTO this program with -DH2_TRACE; the library build has no stamps):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DH2_TRACE -I dan_amd/csrc -o tools/halo2_trace tools/halo2_trace.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRACE_HALO1 -I dan_amd/csrc -o tools/halo1_trace tools/halo2_trace.hip     (conv_halo.hip)
 // Run:  tools/halo2_trace [fwd|dgrad] [N H W C Co]       (default: conv3_2 of the benchmark, 16 x 160 x 160 x 256 -> 256)
 #include <hip/hip_runtime.h>
 
@@ -12,7 +13,17 @@
 #include <cstring>
 #include <vector>
 
+#ifdef TRACE_HALO1      // the production kernel (conv_halo.hip, 8 x 32 pixel tiles, 64-channel chunks) instead of conv_halo2.hip
+#define H_TRACE 1
+#include "../dan_amd/csrc/conv_halo.hip"
+#define TRACE_LAUNCH danhip_launch_conv_halo
+#define TRACE_BUFFER h_trace_buffer
+bool danhip_conv_halo2_eligible(const ConvArgs&) { return false; }
+#else
 #include "../dan_amd/csrc/conv_halo2.hip"
+#define TRACE_LAUNCH danhip_launch_conv_halo2
+#define TRACE_BUFFER h2_trace_buffer
+#endif
 
 #include <cstdarg>
 void danhip_set_error(const char* fmt, ...) {
@@ -25,6 +36,7 @@ void danhip_set_error(const char* fmt, ...) {
 
 int danhip_option(const char* name) {
   if (!strcmp(name, "halo2")) return 1;
+  if (!strcmp(name, "halo_b2")) { const char* e = getenv("DANHIP_HALO_B2"); return e ? atoi(e) : 0; }
   if (!strcmp(name, "halo2_ablate")) { const char* e = getenv("DANHIP_HALO2_ABLATE"); return e ? atoi(e) : 0; }
   return 0;
 }
@@ -65,10 +77,10 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i)
-    if (danhip_launch_conv_halo2(a, s) != 0) { fprintf(stderr, "not eligible / launch failed\n"); return 1; }
+    if (TRACE_LAUNCH(a, s) != 0) { fprintf(stderr, "not eligible / launch failed\n"); return 1; }
   hipEventRecord(e0, s);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) danhip_launch_conv_halo2(a, s);
+  for (int i = 0; i < reps; ++i) TRACE_LAUNCH(a, s);
   hipEventRecord(e1, s);
   hipStreamSynchronize(s);
   float ms = 0;
@@ -76,7 +88,7 @@ int main(int argc, char** argv) {
   ms /= reps;
   printf("%s %dx%dx%dx%d->%d  %.3f ms  %.1f TFLOP/s\n", dgrad ? "dgrad" : "fwd", N, H, W, C, Co, ms, 2.0 * N * H * W * 9.0 * C * Co / ms * 1e-9);
   std::vector<unsigned> tr(1024 + 16);
-  hipMemcpy(tr.data(), h2_trace_buffer(), 4096 + 64, hipMemcpyDeviceToHost);
+  hipMemcpy(tr.data(), TRACE_BUFFER(), 4096 + 64, hipMemcpyDeviceToHost);
   // steady state: steps 18 .. 125 (past the first item's prologue); a chunk is 9 steps
   const char* namesA[4] = {"memory phase (reads, DMA issue, counted wait)", "wait at b1", "MFMA phase", "wait at b2"};
   const char* namesB[4] = {"MFMA phase", "counted wait + b1", "memory phase (epilogue, reads, DMA issue)", "wait at b2"};
