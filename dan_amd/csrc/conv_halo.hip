@@ -272,6 +272,34 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (p_ok) patch_item_setup();
     }
   };
+  // One-tap-per-step configurations issue ONE piece per step (piece k in step k of the chunk before the one that reads it) instead of all PL
+  // in step 0: that step's memory phase was 1230-1350 clocks against ~550 for the others (tools/halo2_trace.hip -DTRACE_HALO1), i.e. one
+  // MFMA phase of the partner group lost per chunk.  Piece k is issued AFTER the step's weight pieces, so it is younger than W(c+D) and
+  // complete before b1 of step k + D <= 8 -- the barrier after which group B reads the next chunk's first fragments.
+  static_assert(SPC != 9 || PL - 1 + D <= SPC - 1, "the last patch piece must have landed before b1 of the chunk's last step");
+  auto issue_patch_piece = [&](auto kc) __attribute__((always_inline)) {
+    constexpr int K = decltype(kc)::value;
+    char* dst = smem + (p_idx & 1) * PBYTES;
+    const bool ragged_chunk = g.crem != 0 && p_cc == g.cch - 1;
+    int piece = K * 8 + wave;
+    if (piece > PPIECES - 1) piece = PPIECES - 1;
+    unsigned voff = psrc[K];
+    if (ragged_chunk && ((lane & 7) ^ (pgeo[K] & 7)) >= g.crem) voff = 0xFFFFFFFFu;
+    bufdma16(rsrc_x, voff, (unsigned)(p_cc * 128), dst + piece * 1024);
+    if (K == PL - 1) {
+      ++p_idx;
+      if (++p_cc == g.cch) {
+        p_cc = 0;
+        p_v += G;
+        p_ok = decode(p_v, p_sp, p_nb);
+        if (p_ok) patch_item_setup();
+      }
+    }
+  };
+  // patch pieces of this chunk that may still be in flight at the counted wait of step s: group A has issued steps s-(D-1) .. s after the
+  // weight tile it waits for, group B steps s-(D-1) .. s-1
+  auto np_a = [](int s) constexpr -> int { int n = 0; for (int k = 0; k < PL; ++k) n += (k >= s - (D - 1) && k <= s) ? 1 : 0; return n; };
+  auto np_b = [](int s) constexpr -> int { int n = 0; for (int k = 0; k < PL; ++k) n += (k >= s - (D - 1) && k <= s - 1) ? 1 : 0; return n; };
   if (p_ok) patch_item_setup();
 
   // ---- weight DMA cursor: step (w_v, w_cc, w_step) to be loaded next; a stage holds TPS taps x BN rows x 128 bytes ---------
@@ -597,6 +625,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   int chunk = 0, cc = 0;                           // running chunk number: patch buffer = chunk & 1
   [[maybe_unused]] int tr_step = 0;
   int patch_age = 16;                              // cycles since this wave last issued a patch (large: outside every window)
+  bool p_live = false;                             // one-tap-per-step form: this chunk issues patch pieces (set in its step 0)
   auto stage_of = [&](int step) __attribute__((always_inline)) -> int {
     return TPS == 3 ? step : (chunk + step) & (NSW - 1);      // TPS == 3: SPC == NSW; TPS == 1: SPC = 9 = 1 (mod 4)
   };
@@ -621,13 +650,25 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (pending) { epilogue(); pending = false; }
         const bool more_w = w_ok;
         if (more_w) issue_w();
-        if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        if constexpr (SPC == 9) {
+          if (STEP == 0) p_live = p_ok;
+          if constexpr (STEP < PL) {
+            if (p_live) issue_patch_piece(stepc);
+          }
+        } else {
+          if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        }
         if constexpr (BITS_OK) {
           if (STEP == 1 && cc == 0 && a.mask_bits) issue_bits(c_sp, c_nb);
         }
         if (!more_w) wait_vmcnt<0>();              // tail of this block's work
-        else if (patch_age <= D - 1) wait_vmcnt<(D - 1) * WL + PL>();
-        else wait_vmcnt<(D - 1) * WL>();
+        else if constexpr (SPC == 9) {
+          if (p_live) wait_vmcnt<(D - 1) * WL + np_a(STEP)>();
+          else wait_vmcnt<(D - 1) * WL>();
+        } else {
+          if (patch_age <= D - 1) wait_vmcnt<(D - 1) * WL + PL>();
+          else wait_vmcnt<(D - 1) * WL>();
+        }
         ++patch_age;
         __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): fragments are in registers before the MFMA phase starts
         H_STAMP(1);
@@ -677,8 +718,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         __builtin_amdgcn_sched_barrier(0);
         H_STAMP(1);
         if (!w_prev) wait_vmcnt<0>();
-        else if (patch_age <= D - 2) wait_vmcnt<(D - 2) * WL + PL>();
-        else wait_vmcnt<(D - 2) * WL>();
+        else if constexpr (SPC == 9) {
+          if (p_live) wait_vmcnt<(D - 2) * WL + np_b(STEP)>();
+          else wait_vmcnt<(D - 2) * WL>();
+        } else {
+          if (patch_age <= D - 2) wait_vmcnt<(D - 2) * WL + PL>();
+          else wait_vmcnt<(D - 2) * WL>();
+        }
         __builtin_amdgcn_s_barrier();              // b1
         H_STAMP(2);
         // ---- mem phase (for step c+1): reads first
@@ -704,7 +750,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (more_w) issue_w();
         w_prev = more_w;
         ++patch_age;
-        if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        if constexpr (SPC == 9) {
+          if (STEP == 0) p_live = p_ok;
+          if constexpr (STEP < PL) {
+            if (p_live) issue_patch_piece(stepc);
+          }
+        } else {
+          if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
+        }
         H_STAMP(3);
         if (g.b2) __builtin_amdgcn_s_barrier();    // b2
         H_STEP_DONE();
