@@ -31,12 +31,13 @@ extern "C" int danhip_act_dtype(void) {
 //   "wgrad_slab" DANHIP_WGRAD_SLAB  1 (default: short launches) / 0 (never) / 2 (always): weight-gradient partials as stores + combine pass
 //   "halo_b2"    DANHIP_HALO_B2     0 (default) / 1: second workgroup barrier per step in conv_halo.hip (the round-2 form; A/B switch)
 //   "wgrad_b2"   DANHIP_WGRAD_B2    0 (default) / 1: the same for conv_wgrad_rows.hip / conv_wgrad_pw.hip
+//   "halo_general_epilogue" DANHIP_HALO_GENERAL_EPILOGUE  0 (default) / 1: conv_halo.hip always takes its general epilogue (A/B of the lean one)
 //   "halo2_ablate" DANHIP_HALO2_ABLATE  timing experiments of conv_halo2.hip (bit mask; 16 = second barrier per step)
 namespace {
 struct Opt { const char* name; const char* env; int def; int value; bool init; };
 Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, 0, false}, {"splitk", "DANHIP_SPLITK", 1, 0, false}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, 0, false},
                 {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, 0, false}, {"halo_b2", "DANHIP_HALO_B2", 0, 0, false},
-                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, 0, false}};
+                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, 0, false}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, 0, false}};
 Opt* find_opt(const char* name) {
   if (!name) return nullptr;
   for (Opt& o : g_opts)

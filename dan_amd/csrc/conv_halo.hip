@@ -37,6 +37,7 @@ struct HaloGeom {
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
   int crem;                 // C % 64 != 0: 16-byte pieces of the LAST input chunk that exist ((C % 64) / 8); 0 = whole chunks only
   int b2;                   // 1: second barrier per step (option "halo_b2"); see the main loop's hand-off notes
+  int fast;                 // 1: the lean epilogue (16-bit output, no residual / 16-bit mask / accumulate, output <= 2^31 bytes)
   FastDiv div_tx, div_txy, div_nb;
 #ifdef H_TRACE
   unsigned* trace;          // tools/halo2_trace.hip -DTRACE_HALO1: [2 groups][128 steps][4 stamps] shader clocks of workgroup 0, waves 0 and 4
@@ -500,6 +501,106 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
         }
       }
+      if (g.fast) {
+        // The common case (every conv of the training step except residual adds / accumulating data gradients / fp32 heads): stores through
+        // a buffer descriptor with 32-bit offsets (2^31 = out of range = dropped: no exec-mask branch, no 64-bit address arithmetic per
+        // store) and no mode branches per fragment.  The epilogue is instruction-issue bound -- both waves of a SIMD run theirs at the
+        // same time -- so its length is its instruction count (tools/halo2_trace.hip -DTRACE_HALO1).
+        constexpr unsigned OOB = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rsrc_y =
+            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co * 2u), 0x00020000);
+        unsigned pix[NPT];
+        bool okp[NPT];
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const int t = wm * TP + p * 16 + frow;
+          const int y = y0 + t / TW, x = x0 + t % TW;
+          okp[p] = y < a.H && x < a.W;
+          pix[p] = (unsigned)((n * a.H + y) * a.W + x);
+        }
+        [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrc_bits;
+        if constexpr (EMIT_OK) {
+          if (a.bits_out)
+            rsrc_bits = __builtin_amdgcn_make_buffer_rsrc(a.bits_out, 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)(a.Co / 8)), 0x00020000);
+        }
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          const unsigned yo = okp[p] ? (pix[p] * (unsigned)a.Co + (unsigned)cb) * 2u : OOB;
+          [[maybe_unused]] unsigned pb[2] = {0u, 0u};
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q) {
+            float v[8] = {acc[2 * q][p][0], acc[2 * q][p][1], acc[2 * q][p][2], acc[2 * q][p][3],
+                          acc[2 * q + 1][p][0], acc[2 * q + 1][p][1], acc[2 * q + 1][p][2], acc[2 * q + 1][p][3]};
+            acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!DGRAD) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bv[q][r];
+              if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
+              }
+            }
+            u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
+            if constexpr (POOL) {
+              if (!(okp[p] && cok[q])) tt = u32x4{0u, 0u, 0u, 0u};
+              pk[q][p] = tt;
+            }
+            if constexpr (EMIT_OK) {
+              if (a.bits_out) pb[q & 1] = pos_bits8(tt);
+            }
+          }
+          if constexpr (EMIT_OK) {
+            if (a.bits_out) {                        // (uniform) 8 bytes per pixel and wave, stored by the fq == 0 lane
+              const uint2 w8 = gather_bits64(pb[0], pb[1], fq);
+              const unsigned bo = (okp[p] && fq == 0) ? pix[p] * (unsigned)(a.Co / 8) + (unsigned)(c_nb * (BN / 8) + wn * 8) : OOB;
+              __builtin_amdgcn_raw_buffer_store_b64(dh_u32x2{w8.x, w8.y}, rsrc_bits, (int)bo, 0, 0);
+            }
+          }
+        }
+        if constexpr (POOL) {
+          constexpr int FPR = TW / 16, PV = FPR;
+          const int Hp = (a.H + 1) >> 1, Wp = (a.W + 1) >> 1;
+          const __amdgpu_buffer_rsrc_t rsrc_p =
+              __builtin_amdgcn_make_buffer_rsrc(a.pool_y, 0, (int)((unsigned)(a.N * Hp * Wp) * (unsigned)a.Co * 2u), 0x00020000);
+          [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrc_pb;
+          if constexpr (EMIT_OK) {
+            if (a.pool_bits_out)
+              rsrc_pb = __builtin_amdgcn_make_buffer_rsrc(a.pool_bits_out, 0, (int)((unsigned)(a.N * Hp * Wp) * (unsigned)(a.Co / 8)), 0x00020000);
+          }
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            if (((p / FPR) & 1) != 0) continue;      // top rows of the pairs only
+            const int t = wm * TP + p * 16 + frow;
+            const int y = y0 + t / TW, x = x0 + t % TW;
+            const bool pok = okp[p] && (frow & 1) == 0;
+            const unsigned ppix = (unsigned)((n * Hp + (y >> 1)) * Wp + (x >> 1));
+            const unsigned po = pok ? (ppix * (unsigned)a.Co + (unsigned)cb) * 2u : OOB;
+            [[maybe_unused]] unsigned pb2[2] = {0u, 0u};
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+              u32x4 m;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned v = pkmax_relu(pk[q][p][e], pk[q][p + PV][e]);
+                m[e] = pkmax_relu(v, dh_lane_xor1(v));
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(m, rsrc_p, (int)((cok[q] ? po : OOB) + q * 64), 0, 0);
+              if constexpr (EMIT_OK) {
+                if (a.pool_bits_out) pb2[q & 1] = pos_bits8(m);
+              }
+            }
+            if constexpr (EMIT_OK) {
+              if (a.pool_bits_out) {
+                const uint2 w8 = gather_bits64(pb2[0], pb2[1], fq);
+                const unsigned bo = (pok && fq == 0) ? ppix * (unsigned)(a.Co / 8) + (unsigned)(c_nb * (BN / 8) + wn * 8) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(dh_u32x2{w8.x, w8.y}, rsrc_pb, (int)bo, 0, 0);
+              }
+            }
+          }
+        }
+      } else {
       if constexpr (DGRAD) {
         // Data gradient: the ReLU mask / the value to accumulate into are read-modify inputs from HBM.  ALL of them are issued before the
         // first one is consumed — one exposed memory latency per item instead of one per pixel fragment (the forward epilogue only stores).
@@ -600,6 +701,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
         }
       }
+      }                                              // (the general epilogue)
     }
     c_v += G;
     c_ok = decode(c_v, c_sp, c_nb);
@@ -633,21 +735,24 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
   if (wave < 4) {
     // ================================================= group A =================================================
-    bool pending = false;                          // an item finished in the previous cycle: its epilogue runs in this mem phase
+    // An item that finished in the previous cycle has its epilogue at the top of the loop: ONE inlined copy for both the "next item follows"
+    // and the "last item of this block" case (the epilogue is ~700-1600 instructions and the kernel must stay inside the 64 KB I-cache).
+    bool pending = false, done = false;
     for (;;) {
+      if (pending) {
+        epilogue();
+        pending = false;
+        if (done) break;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const int pofs = (chunk & 1) * PBYTES;
       auto cycle = [&](auto stepc) __attribute__((always_inline)) {
         constexpr int STEP = decltype(stepc)::value;
         // ---- mem phase: fragment reads first (their LDS latency runs under the epilogue / DMA issue below)
         const int wbase = offW + stage_of(STEP) * WBYTES;
         H_STAMP(0);
-        if constexpr (DGRAD) {                       // its HBM reads first: the fragment registers are not live across them
-          if (pending) { epilogue(); pending = false; }
-          __builtin_amdgcn_sched_barrier(0);
-        }
         load_frags(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
-        if (pending) { epilogue(); pending = false; }
         const bool more_w = w_ok;
         if (more_w) issue_w();
         if constexpr (SPC == 9) {
@@ -697,8 +802,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if (++cc == g.cch) {
         cc = 0;
         int nsp, nnb;
-        if (!decode(c_v + G, nsp, nnb)) { epilogue(); break; }     // the block's last item
         pending = true;
+        done = !decode(c_v + G, nsp, nnb);         // the block's last item
       }
     }
   } else {
@@ -731,20 +836,20 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int NSTEP = (STEP + 1) % SPC;
         const int nstage = TPS == 3 ? NSTEP : (chunk + STEP + 1) & (NSW - 1);
         const int npofs = STEP == SPC - 1 ? (PBYTES - pofs) : pofs;
-        bool ep_done = false;
         if constexpr (DGRAD) {
           if (STEP == SPC - 1 && cc + 1 == g.cch) {
             epilogue();
             if (!c_ok) last = true;
-            ep_done = true;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
         load_frags(offW + nstage * WBYTES, npofs, std::integral_constant<int, NSTEP>{});
         __builtin_amdgcn_sched_barrier(0);
-        if (!ep_done && STEP == SPC - 1 && cc + 1 == g.cch) {  // the item ended with this step
-          epilogue();
-          if (!c_ok) last = true;
+        if constexpr (!DGRAD) {
+          if (STEP == SPC - 1 && cc + 1 == g.cch) {  // the item ended with this step
+            epilogue();
+            if (!c_ok) last = true;
+          }
         }
         const bool more_w = w_ok;
         if (more_w) issue_w();
@@ -850,6 +955,8 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.cch = (a.C + 63) / 64;
   g.crem = (a.C % 64) / 8;
   g.b2 = danhip_option("halo_b2");
+  g.fast = (NCU == 0 && !a.out_f32 && !a.resid && !a.mask && !a.accumulate && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
+            !danhip_option("halo_general_epilogue")) ? 1 : 0;
 #ifdef H_TRACE
   g.trace = h_trace_buffer();
 #endif
