@@ -37,7 +37,7 @@ struct HaloGeom {
   int grouped;              // 1: XCD-grouped item mapping (the NB blocks of one spatial tile run on one XCD)
   int crem;                 // C % 64 != 0: 16-byte pieces of the LAST input chunk that exist ((C % 64) / 8); 0 = whole chunks only
   int b2;                   // 1: second barrier per step (option "halo_b2"); see the main loop's hand-off notes
-  int fast;                 // 1: the lean epilogue (16-bit output, no residual / 16-bit mask / accumulate, output <= 2^31 bytes)
+  int fast;                 // 1: the lean epilogue (16-bit output of <= 2^31 bytes, no 16-bit ReLU mask, no residual)
   FastDiv div_tx, div_txy, div_nb;
 #ifdef H_TRACE
   unsigned* trace;          // tools/halo2_trace.hip -DTRACE_HALO1: [2 groups][128 steps][4 stamps] shader clocks of workgroup 0, waves 0 and 4
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
       }
       if (g.fast) {
-        // The common case (every conv of the training step except residual adds / accumulating data gradients / fp32 heads): stores through
+        // The common case (everything but fp32 outputs, 16-bit ReLU masks and residual adds): loads / stores through
         // a buffer descriptor with 32-bit offsets (2^31 = out of range = dropped: no exec-mask branch, no 64-bit address arithmetic per
         // store) and no mode branches per fragment.  The epilogue is instruction-issue bound -- both waves of a SIMD run theirs at the
         // same time -- so its length is its instruction count (tools/halo2_trace.hip -DTRACE_HALO1).
@@ -523,6 +523,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           if (a.bits_out)
             rsrc_bits = __builtin_amdgcn_make_buffer_rsrc(a.bits_out, 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)(a.Co / 8)), 0x00020000);
         }
+        // ONE optional read-modify input: the gradient an accumulating data gradient adds to.  All 8 loads are requested before the first
+        // is used; a lane outside the map or beyond Cout reads zeros (out-of-range offset).  (The 16-bit ReLU mask and the forward's
+        // residual take the general epilogue: with a second array live, or this one in the forward instances, the allocator spilled
+        // 60-75 registers.)
+        const bf16_t* extra = (DGRAD && a.accumulate) ? reinterpret_cast<const bf16_t*>(a.y) : nullptr;      // (uniform)
+        [[maybe_unused]] u32x4 inx[NPT][NPAIR];
+        if (extra) {
+          const __amdgpu_buffer_rsrc_t rsrc_e =
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(extra), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co * 2u), 0x00020000);
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const unsigned yo = okp[p] ? (pix[p] * (unsigned)a.Co + (unsigned)cb) * 2u : OOB;
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) inx[p][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_e, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
+          }
+        }
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
           const unsigned yo = okp[p] ? (pix[p] * (unsigned)a.Co + (unsigned)cb) * 2u : OOB;
@@ -540,6 +556,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
               }
+            }
+            if (extra) {
+              const bf16_t* xp = reinterpret_cast<const bf16_t*>(&inx[p][q]);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bf2f(xp[r]);
             }
             u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
             __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
@@ -955,7 +976,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.cch = (a.C + 63) / 64;
   g.crem = (a.C % 64) / 8;
   g.b2 = danhip_option("halo_b2");
-  g.fast = (NCU == 0 && !a.out_f32 && !a.resid && !a.mask && !a.accumulate && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
+  g.fast = (NCU == 0 && !a.out_f32 && !a.mask && !a.resid && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
             !danhip_option("halo_general_epilogue")) ? 1 : 0;
 #ifdef H_TRACE
   g.trace = h_trace_buffer();
