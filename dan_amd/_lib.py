@@ -75,6 +75,7 @@ SIGNATURES = {
     "danhip_dynamic_anchor_routing_train": [P, P, P, P, I64, I32, I32, I32, I32, I32, FL, FL, ctypes.c_uint64, ctypes.c_uint64, P, P, P, P,
                                             ctypes.c_size_t, P],
     "danhip_nms": [P, I32, I32, I32, FL, P, P, P],
+    "danhip_argsort_desc_f32": [P, I64, I32, P, P, ctypes.c_size_t, P],
     "danhip_augment_preprocess": [P, I32, I32, I32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float), I32, I32, I32, I32, I32, P, I32, I32,
                                   P, ctypes.c_size_t, P],
     "danhip_deform_psroi_pool_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, FL, FL, I32, I32, P],
@@ -139,6 +140,8 @@ def lib():
         L.danhip_routing_workspace_bytes.argtypes = [I64, I32, ctypes.c_int]
         L.danhip_bbox_vote_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_argsort_workspace_bytes.argtypes = [I64]
+        L.danhip_argsort_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_augment_workspace_bytes.argtypes = []
         L.danhip_set_option.restype = ctypes.c_int
         L.danhip_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]

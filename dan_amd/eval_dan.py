@@ -6,6 +6,7 @@ reference) are libdanhip kernels; everything stays on the device until write_to_
 import numpy as np
 import torch
 
+from . import ops
 from ._lib import call, lib, ptr, stream
 
 NMS_THRESHOLD = 0.3          # eval_dan.py:69-70
@@ -53,9 +54,16 @@ def resize_image(image, fx, fy):
 
 
 def _order_desc(scores):
-    """argsort()[::-1]; ties resolved as a stable ascending sort read backwards (numpy's default sort leaves it open)."""
-    n = scores.shape[0]
-    return (n - 1) - torch.sort(scores.flip(0), descending=True, stable=True).indices
+    """argsort()[::-1]; ties resolved as a stable ascending sort read backwards (numpy's default sort leaves it open): libdanhip's
+    arg-sort with ties_high_index_first.  The detections are fp32 (or fp32 values held in float64: bbox_vote's input); a caller that
+    passes scores an fp32 cannot hold keeps torch's sort."""
+    if scores.dtype != torch.float32:
+        s32 = scores.to(torch.float32)
+        if not bool((s32.to(scores.dtype) == scores).all()):
+            n = scores.shape[0]
+            return (n - 1) - torch.sort(scores.flip(0), descending=True, stable=True).indices
+        scores = s32
+    return ops.argsort_desc(scores.contiguous(), ties_high_index_first=True)
 
 
 def detect_face(net, image, shrink, max_per_image=MAX_PER_IMAGE):

@@ -1124,3 +1124,19 @@ def face_scores(cls, threshold=None):
     mask = torch.empty(c.shape[:-1], dtype=torch.int32, device=c.device) if threshold is not None else None
     call("danhip_face_scores", ptr(c), ptr(score), ptr(mask), float(threshold or 0.0), n, stream())
     return (score, mask) if threshold is not None else score
+
+
+def argsort_desc(scores, ties_high_index_first=False):
+    """Positions of a 1-D fp32 vector by descending value, equal values by ascending index — torch.sort(descending=True, stable=True).indices,
+    i.e. tf.nn.top_k's / tf.image.non_max_suppression's candidate order (utility/bbox_util.py:61-91); ties_high_index_first: numpy's
+    argsort()[::-1] (eval_dan.py:255).  -> int64 indices.  libdanhip's bitonic arg-sort (csrc/sort.hip): no torch.sort on the product path."""
+    assert scores.dim() == 1 and scores.dtype == torch.float32
+    n = scores.shape[0]
+    idx = torch.empty((n,), dtype=torch.int32, device=scores.device)
+    if n == 0:
+        return idx.long()
+    s = scores.contiguous()
+    nbytes = int(_lib.lib().danhip_argsort_workspace_bytes(n))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
+    call("danhip_argsort_desc_f32", ptr(s), n, 1 if ties_high_index_first else 0, ptr(idx), ptr(ws), nbytes, stream())
+    return idx.long()

@@ -1,9 +1,15 @@
 """Host-side mirror of the reference's utility/bbox_util.py on device tensors: select / clip / filter / sort are exact
-fp32 elementwise steps (torch plumbing), NMS is the libdanhip kernel replacing tf.image.non_max_suppression.
+fp32 elementwise steps (torch plumbing), the candidate ordering and NMS are libdanhip kernels (tf.nn.top_k / tf.image.non_max_suppression).
 Function names, argument order and return structure follow bbox_util.py:24-119."""
 import torch
 
 from .._lib import call, ptr, stream
+
+
+def _order(scores):
+    """tf.nn.top_k / non_max_suppression candidate order: descending score, ties -> lower index first (libdanhip arg-sort)."""
+    from .. import ops
+    return ops.argsort_desc(scores.to(torch.float32))
 
 
 def select_bboxes(scores_pred, bboxes_pred, num_classes, select_threshold, name=None):
@@ -38,14 +44,14 @@ def sort_bboxes(scores_pred, ymin, xmin, ymax, xmax, keep_topk, name=None):
     """bbox_util.py:61-73: tf.nn.top_k (ties -> lower index first) then zero padding up to keep_topk."""
     n = scores_pred.shape[0]
     k = min(int(keep_topk), n)
-    order = torch.sort(scores_pred, descending=True, stable=True).indices[:k]
+    order = _order(scores_pred)[:k]
     pad = max(int(keep_topk) - n, 0)
     f = lambda t: torch.nn.functional.pad(t[order], (0, pad))
     return f(scores_pred), f(ymin), f(xmin), f(ymax), f(xmax)
 
 
 def _nms_indices(scores_pred, bboxes_pred, nms_topk, nms_threshold):
-    order = torch.sort(scores_pred, descending=True, stable=True).indices          # TF orders candidates by score
+    order = _order(scores_pred)                                                    # TF orders candidates by score
     b = bboxes_pred[order].to(torch.float32).contiguous()
     K = b.shape[0]
     keep = torch.empty((1, int(nms_topk)), dtype=torch.int32, device=b.device)
@@ -82,7 +88,12 @@ def bbox_center2point(bboxes, name=None):
 
 def parse_by_class(image_shape, cls_pred, bboxes_pred, num_classes, select_threshold, min_size, keep_topk, nms_topk, nms_threshold):
     """bbox_util.py:103-119 -> ({class: boxes [nms_topk,4]}, {class: scores [nms_topk]})."""
-    scores_pred = torch.softmax(cls_pred.to(torch.float32), dim=-1)
+    if cls_pred.shape[-1] == 2:                      # every graph here: background / face -> one libdanhip launch for the face column
+        from .. import ops
+        p = ops.face_scores(cls_pred.to(torch.float32))
+        scores_pred = torch.stack([1. - p, p], dim=-1)        # (class 0 is never selected: the loop below starts at 1)
+    else:
+        scores_pred = torch.softmax(cls_pred.to(torch.float32), dim=-1)
     selected_bboxes, selected_scores = select_bboxes(scores_pred, bboxes_pred.to(torch.float32), num_classes, select_threshold)
     for c in range(1, num_classes):
         ymin, xmin, ymax, xmax = selected_bboxes[c].unbind(-1)

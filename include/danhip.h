@@ -371,6 +371,14 @@ int danhip_dynamic_anchor_routing_train(const float* anchors, const float* gt_ta
 int danhip_nms(const float* boxes_sorted, int32_t B, int32_t K, int32_t max_out, float iou_threshold, int32_t* keep_idx,
                int32_t* num_keep, void* stream);
 
+/* Stable descending arg-sort of one fp32 vector (the ordering step of utility/bbox_util.py:61-73 tf.nn.top_k and :75-91 ahead of
+ * tf.image.non_max_suppression; eval_dan.py:255 `argsort()[::-1]` with ties_high_index_first = 1): idx_out int32 [n] = positions by
+ * descending score, equal scores (+0 == -0) by ascending index (descending with ties_high_index_first).  Bitonic network on unique
+ * 64-bit (score, index) keys; workspace = danhip_argsort_workspace_bytes(n) bytes (8 per element of the next power of two >= 8192). */
+size_t danhip_argsort_workspace_bytes(int64_t n);
+int danhip_argsort_desc_f32(const float* scores, int64_t n, int32_t ties_high_index_first, int32_t* idx_out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* DeformPSROIPool / DeformPSROIPoolGrad (cpp/Deform/deform_psroi_pooling_op.cc:37-97; utility/custom_op.py:93-126):
  * the TF op's tensors and attributes as they are — data fp32 NCHW [B,C,H,W], rois fp32 [R,5] (batch index, x1, y1, x2, y2), trans fp32
  * [R,2*num_classes,part_size,part_size] (NULL allowed when no_trans) -> top_data, mapping_channel (sample count) fp32
