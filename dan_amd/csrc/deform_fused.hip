@@ -3,7 +3,7 @@
 //
 // For the shape the context modules use (C / deformable_group == 64) a 64-channel K-step of the GEMM is exactly one (tap, deformable
 // group) pair, so every pixel of the tile has ONE sampling position per K-step:
-//   * a 512-thread workgroup owns 128 output pixels x all Cout (<= 256) channels; per K-step thread (pixel = tid / 4, quarter = tid % 4)
+//   * a workgroup of 4 x FUSED_BM / 64 waves owns FUSED_BM output pixels x all Cout (<= 256) channels; per K-step a thread
 //     reads the tap's offset pair, gathers 16 channels of the four bilinear corners (eight 16-byte loads, issued one K-step ahead),
 //     blends them in fp32, rounds to the 16-bit activation type — the same values the column buffer would hold — and writes them into the
 //     [128 px][64 ch] A tile in LDS (XOR-swizzled 16-byte pieces);
@@ -15,8 +15,10 @@
 // (dan_amd/ops.py KEEP_DEFORM_COL); inference passes NULL and the 9x activation-sized buffer never exists.
 #include "common.h"
 
+// 64 pixels per workgroup (256 threads, 80 KB of LDS at Cout = 256): TWO workgroups per CU, so one gathers while the other multiplies --
+// 1.105 -> 1.045 ms at 160 x 160 x 256, offsets N(0, 2 px), against the 128-pixel / 512-thread form (one resident workgroup, 96 KB).
 #ifndef FUSED_BM
-#define FUSED_BM 128
+#define FUSED_BM 64
 #endif
 
 namespace {
