@@ -37,7 +37,8 @@ namespace {
 struct Opt { const char* name; const char* env; int def; int value; bool init; };
 Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, 0, false}, {"splitk", "DANHIP_SPLITK", 1, 0, false}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, 0, false},
                 {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, 0, false}, {"halo_b2", "DANHIP_HALO_B2", 0, 0, false},
-                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, 0, false}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, 0, false}};
+                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, 0, false}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, 0, false},
+                {"deform_bwd_form", "DANHIP_DEFORM_BWD_FORM", 0, 0, false}};
 Opt* find_opt(const char* name) {
   if (!name) return nullptr;
   for (Opt& o : g_opts)

@@ -187,11 +187,27 @@ __global__ void deform_sample_bwd_kernel(const bf16_t* __restrict__ x, const bf1
 }
 
 
+// ---- which backward form runs is decided ON THE DEVICE (no host synchronisation, capturable): the gather form below enumerates source
+// taps within +-DEFORM_R of an input pixel and hands every corner outside that window to fp32 atomics one by one ("far" corners) — 3.2 ms
+// at 160 x 160 x 256 with offsets of N(0, 0.5 px), but 43 ms at N(0, 2 px), where 85 % of the taps have a far corner; the all-atomics
+// scatter form costs 12 ms whatever the offsets are.  deform_far_stat_kernel counts the (dh, dw) pairs outside [-(R-1), R-1) into
+// stat[0] (zeroed with the scatter buffer); every backward kernel reads it and returns at once when it belongs to the other form.
+struct BwdGate {
+  const unsigned* stat;   // stat[0] = number of offset pairs with a component outside [-(R-1), R-1)
+  unsigned thresh;        // scatter form when stat[0] > thresh
+  int force;              // option "deform_bwd_form": 0 by the statistic, 1 always gather, 2 always scatter
+};
+__device__ __forceinline__ bool gate_runs(const BwdGate& q, bool scatter_form) {
+  const bool scatter = q.force ? q.force == 2 : q.stat[0] > q.thresh;
+  return scatter == scatter_form;
+}
+
 // Fast path for C / deformable_group == 64: one WAVE per (output pixel, tap, deformable group), lane = channel.  Every
 // atomic wave-instruction then adds 64 consecutive floats (256 contiguous bytes — the full-rate shape of the memory-side
 // float atomics), and the offset gradient is a plain 64-lane reduction.
 __global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
-                                             float* __restrict__ dx, bf16_t* __restrict__ doffs, DeformGeom g) {
+                                             float* __restrict__ dx, bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
+  if (gate.stat && !gate_runs(gate, true)) return;
   const int taps = g.kh * g.kw;
   const int offc = g.dg * 2 * taps;
   const int lane = threadIdx.x & 63;
@@ -323,7 +339,8 @@ __device__ __forceinline__ float corner_weight_at(float inv_h, float inv_w, int 
 // butterfly (14 + 6 shuffles) after which lane l8 holds the (dh, dw) pair of tap (4*b0 + 2*b1 + b2) and stores it as one 32-bit word.
 __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
                                                                    const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
-                                                                   bf16_t* __restrict__ doffs, DeformGeom g) {
+                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
+  if (!gate_runs(gate, false)) return;
   const int offc = g.dg * 18;
   const int lane = threadIdx.x & 63, l8 = lane & 7;
   const unsigned nwork = (unsigned)g.N * g.Ho * g.Wo * g.dg;            // (< 2^31: checked by the launcher)
@@ -432,7 +449,8 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
 // dX: one wave per (input pixel, group), lane = candidate during the enumeration, lane = channel during the accumulation
 __global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                         const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                        int accumulate) {
+                                                                        int accumulate, BwdGate gate) {
+  if (!gate_runs(gate, false)) return;
   constexpr int R = DEFORM_R, D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 63) / 64;
   const int offc = g.dg * 18;
   const int lane = threadIdx.x & 63;
@@ -498,7 +516,8 @@ __global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf
   }
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate) {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate, BwdGate gate) {
+  if (gate.stat && !gate_runs(gate, true)) return;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
     float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -510,6 +529,19 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __rest
     }
     *reinterpret_cast<uint4*>(dst + i * 8) = pack8(f);
   }
+}
+
+// offsets bf16 [pairs][2] -> stat[0] += number of pairs with dh or dw outside [-lim, lim)
+__global__ __launch_bounds__(256) void deform_far_stat_kernel(const bf16_t* __restrict__ offs, long pairs, float lim, unsigned* __restrict__ stat) {
+  unsigned cnt = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
+    const unsigned w = reinterpret_cast<const unsigned*>(offs)[i];
+    const float dh = bf2f((bf16_t)(w & 0xffffu)), dw = bf2f((bf16_t)(w >> 16));
+    cnt += (!(dh >= -lim && dh < lim) || !(dw >= -lim && dw < lim)) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(stat, cnt);
 }
 
 int make_geom(DeformGeom* g, int N, int H, int W, int C, int kh, int kw, int stride, int dil, int dg, const char* what) {
@@ -555,7 +587,7 @@ extern "C" int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offse
 }
 
 /* dS [N*Ho*Wo, kh*kw*C] -> d_offsets bf16 [N,Ho,Wo,dg*2*kh*kw] (overwritten) and dx bf16 [N,H,W,C] (=|+= if accumulate).
- * workspace: N*H*W*C floats (fp32 scatter target), zeroed inside. */
+ * workspace: N*H*W*C + 64 floats (fp32 scatter target + the far-corner statistic), zeroed inside. */
 extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
                                         int32_t deformable_group, int accumulate, float* workspace, void* stream) {
@@ -565,24 +597,39 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
-  { const int zrc = danhip_zero_async(workspace, sizeof(float) * nx, s); if (zrc) return zrc; }
+  // fp32 scatter target + 64 words of statistics behind it, zeroed together
+  { const int zrc = danhip_zero_async(workspace, sizeof(float) * (nx + 64), s); if (zrc) return zrc; }
+  unsigned* stat = reinterpret_cast<unsigned*>(workspace + nx);
   if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9) {
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
-    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 31) / 32 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+    const long pairs = (long)N * g.Ho * g.Wo * deformable_group * 9;
+    // gather form while at most 5/8 of the taps have a far corner (160 x 160 x 256, batch 16, offsets N(0, s): s = 0.3 / 0.5 / 1.0 px
+    // -> far fraction 0.00 / 0.09 / 0.53 -> 3.2 / 3.4 / 7.7 ms against 12.0 ms for the scatter form; s = 2.0 -> 0.85 -> 43 ms)
+    BwdGate gate{stat, (unsigned)(pairs / 8 * 5), danhip_option("deform_bwd_form")};
+    hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs,
+                       (float)(DEFORM_R - 1), stat);
+    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 31) / 32 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
+                       gate);
     hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, dim3(grid_for((ng + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, offsets, dS, workspace, dx, g,
-                       accumulate);
+                       accumulate, gate);
+    const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
+    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
+                       gate);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, gate);
     DH_LAUNCH_CHECK();
     return DANHIP_OK;
   }
+  const BwdGate none{nullptr, 0u, 0};
   if (C / deformable_group == 64) {
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
-    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
+    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
+                       none);
   } else {
     const long total = (long)N * g.Ho * g.Wo * kh * kw * (C / 8);
     hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
   }
   DH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, none);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -599,7 +646,7 @@ extern "C" size_t danhip_deform_conv_workspace_bytes(int32_t N, int32_t H, int32
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0) return 0;
   const size_t Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   const size_t col = align256((size_t)N * Ho * Wo * kh * kw * C * sizeof(uint16_t));
-  return backward ? 2 * col + align256((size_t)N * H * W * C * sizeof(float)) : col;
+  return backward ? 2 * col + align256(((size_t)N * H * W * C + 64) * sizeof(float)) : col;
 }
 
 static int deform_gemm_desc(danhip_conv_desc* d, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride) {

@@ -1009,7 +1009,7 @@ class _DeformSample(torch.autograd.Function):
         N, H, W, C = x.shape
         dx = torch.empty_like(x)
         doff = torch.empty_like(offsets)
-        ws = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+        ws = torch.empty(x.numel() + 64, dtype=torch.float32, device=x.device)      # scatter target + the far-corner statistic
         call("danhip_deform_sample_bwd", ptr(x), ptr(offsets), ptr(dS.contiguous()), ptr(dx), ptr(doff), N, H, W, C, kh, kw, stride, dilation, dg, 0,
              ptr(ws), stream())
         return dx, doff, None, None, None, None, None

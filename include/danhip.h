@@ -49,6 +49,8 @@ int danhip_version(void);
  *   "wgrad_slab" [DANHIP_WGRAD_SLAB, 1]  0: weight-gradient partial sums always by fp32 atomics; 2: always stores + combine pass; 1: by launch length
  *   "halo_b2"    [DANHIP_HALO_B2, 0]     1: a second workgroup barrier per step in csrc/conv_halo.hip (the round-2 form; timing A/B only)
  *   "wgrad_b2"   [DANHIP_WGRAD_B2, 0]    1: the same for csrc/conv_wgrad_rows.hip and csrc/conv_wgrad_pw.hip
+ *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 gather or scatter form by the offsets' statistic (on the device),
+ *                                           1 always the gather form, 2 always the fp32-atomics scatter form
  *   "halo2_ablate" [DANHIP_HALO2_ABLATE, 0]  timing experiments of csrc/conv_halo2.hip (bit mask; results are WRONG with bits 1, 2, 4, 8 set)
  * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
 int danhip_set_option(const char* name, int value);
@@ -307,7 +309,7 @@ int danhip_face_scores(const float* cls, float* score, int32_t* mask, float thre
  * ------------------------------------------------------------------------------------------------ */
 int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offsets, uint16_t* S, int32_t N, int32_t H, int32_t W, int32_t C,
                              int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, void* stream);
-/* workspace: N*H*W*C floats */
+/* workspace: N*H*W*C + 64 floats (fp32 scatter target + the far-corner statistic that selects the gather or the scatter form on the device) */
 int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
                              int32_t deformable_group, int accumulate, float* workspace, void* stream);
