@@ -190,10 +190,10 @@ __global__ void deform_sample_bwd_kernel(const bf16_t* __restrict__ x, const bf1
 // ---- which backward form runs is decided ON THE DEVICE (no host synchronisation, capturable): the gather form below enumerates source
 // taps within +-DEFORM_R of an input pixel and hands every corner outside that window to fp32 atomics one by one ("far" corners) — 3.2 ms
 // at 160 x 160 x 256 with offsets of N(0, 0.5 px), but 43 ms at N(0, 2 px), where 85 % of the taps have a far corner; the all-atomics
-// scatter form costs 12 ms whatever the offsets are.  deform_far_stat_kernel counts the (dh, dw) pairs outside [-(R-1), R-1) into
+// scatter form costs 12 ms whatever the offsets are.  deform_far_stat_kernel counts the (dh, dw) pairs outside [-R, R) into
 // stat[0] (zeroed with the scatter buffer); every backward kernel reads it and returns at once when it belongs to the other form.
 struct BwdGate {
-  const unsigned* stat;   // stat[0] = number of offset pairs with a component outside [-(R-1), R-1)
+  const unsigned* stat;   // stat[0] = number of offset pairs with a component outside [-R, R)
   unsigned thresh;        // scatter form when stat[0] > thresh
   int force;              // option "deform_bwd_form": 0 by the statistic, 1 always gather, 2 always scatter
 };
@@ -603,11 +603,12 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
   if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9) {
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
     const long pairs = (long)N * g.Ho * g.Wo * deformable_group * 9;
-    // gather form while at most 5/8 of the taps have a far corner (160 x 160 x 256, batch 16, offsets N(0, s): s = 0.3 / 0.5 / 1.0 px
-    // -> far fraction 0.00 / 0.09 / 0.53 -> 3.2 / 3.4 / 7.7 ms against 12.0 ms for the scatter form; s = 2.0 -> 0.85 -> 43 ms)
-    BwdGate gate{stat, (unsigned)(pairs / 8 * 5), danhip_option("deform_bwd_form")};
+    // A corner lies floor(o) or floor(o) + 1 from the tap's nominal position, so it is outside the +-R window iff o is outside [-R, R).
+    // Gather form while at most 15 % of the taps have such an offset (160 x 160 x 256, batch 16, offsets N(0, s): s = 0.5 / 1.0 px ->
+    // 0 % / 9 % -> 3.4 / 7.7 ms; s = 2.0 -> 53 % -> 43 ms; the scatter form: 12.0 ms whatever the offsets)
+    BwdGate gate{stat, (unsigned)(pairs / 20 * 3), danhip_option("deform_bwd_form")};
     hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs,
-                       (float)(DEFORM_R - 1), stat);
+                       (float)DEFORM_R, stat);
     hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 31) / 32 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
                        gate);
     hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, dim3(grid_for((ng + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, offsets, dS, workspace, dx, g,

@@ -32,7 +32,7 @@ def test_gather_and_scatter_forms_of_the_deformable_backward_agree(sigma, dev):
     finally:
         _lib.lib().danhip_set_option(b"deform_bwd_form", 0)
     pairs = N * H * W * dg * 9
-    assert far == far_a and ((far > pairs // 8 * 5) == (sigma > 1.0)), (far, pairs)
+    assert far == far_a and ((far > pairs // 20 * 3) == (sigma > 1.0)), (far, pairs)
     # dX: fp32 sums in different orders, rounded once to 16 bits; dOffset: the same 64-channel reductions
     scale = gx.abs().max().item()
     assert (gx - sx).abs().max().item() <= 2e-2 * scale
