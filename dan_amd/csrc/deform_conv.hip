@@ -190,24 +190,28 @@ __global__ void deform_sample_bwd_kernel(const bf16_t* __restrict__ x, const bf1
 // ---- which backward form runs is decided ON THE DEVICE (no host synchronisation, capturable): the gather form below enumerates source
 // taps within +-DEFORM_R of an input pixel and hands every corner outside that window to fp32 atomics one by one ("far" corners) — 3.2 ms
 // at 160 x 160 x 256 with offsets of N(0, 0.5 px), but 43 ms at N(0, 2 px), where 85 % of the taps have a far corner; the all-atomics
-// scatter form costs 12 ms whatever the offsets are.  deform_far_stat_kernel counts the (dh, dw) pairs outside [-R, R) into
-// stat[0] (zeroed with the scatter buffer); every backward kernel reads it and returns at once when it belongs to the other form.
+// scatter form costs 12 ms whatever the offsets are.  deform_far_stat_kernel counts the (dh, dw) pairs outside [-2, 2) and [-1, 1) into
+// stat[0..1] (zeroed with the scatter buffer); every backward kernel reads them and returns at once when it belongs to another form.
 struct BwdGate {
-  const unsigned* stat;   // stat[0] = number of offset pairs with a component outside [-R, R)
-  unsigned thresh;        // scatter form when stat[0] > thresh
-  int force;              // option "deform_bwd_form": 0 by the statistic, 1 always gather, 2 always scatter
+  const unsigned* stat;   // stat[0] / stat[1] = number of offset pairs with a component outside [-2, 2) / [-1, 1)
+  unsigned thresh2;       // scatter form when stat[0] > thresh2
+  unsigned thresh1;       // gather window +-1 (81 candidates instead of 225) when stat[1] <= thresh1
+  int force;              // option "deform_bwd_form": 0 by the statistics, 1 gather +-2, 2 scatter, 3 gather +-1
 };
-__device__ __forceinline__ bool gate_runs(const BwdGate& q, bool scatter_form) {
-  const bool scatter = q.force ? q.force == 2 : q.stat[0] > q.thresh;
-  return scatter == scatter_form;
+// form: 0 = gather with a +-1 window, 1 = gather with a +-2 window, 2 = scatter
+__device__ __forceinline__ int gate_form(const BwdGate& q) {
+  if (q.force) return q.force == 3 ? 0 : q.force;
+  if (q.stat[0] > q.thresh2) return 2;
+  return q.stat[1] <= q.thresh1 ? 0 : 1;
 }
+__device__ __forceinline__ bool gate_runs(const BwdGate& q, int form) { return gate_form(q) == form; }
 
 // Fast path for C / deformable_group == 64: one WAVE per (output pixel, tap, deformable group), lane = channel.  Every
 // atomic wave-instruction then adds 64 consecutive floats (256 contiguous bytes — the full-rate shape of the memory-side
 // float atomics), and the offset gradient is a plain 64-lane reduction.
 __global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                              float* __restrict__ dx, bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
-  if (gate.stat && !gate_runs(gate, true)) return;
+  if (gate.stat && !gate_runs(gate, 2)) return;
   const int taps = g.kh * g.kw;
   const int offc = g.dg * 2 * taps;
   const int lane = threadIdx.x & 63;
@@ -281,7 +285,7 @@ __global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const
 // deterministic gather.  Corners further than R from their nominal position (offsets beyond ~R-1 px) keep the memory atomic
 // (`far` below); the two sets are complementary by construction.  dOffset needs no atomics at all: one wave per (output pixel, group)
 // has all nine taps' loads in flight and reduces the 18 sums with a transposing butterfly (29 shuffles instead of 108).
-constexpr int DEFORM_R = 2;
+constexpr int DEFORM_R = 2;      // the widest gather window (the kernels are instantiated for 1 and 2)
 
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -337,15 +341,15 @@ __device__ __forceinline__ float corner_weight_at(float inv_h, float inv_w, int 
 // wave-per-item form issued them as 2-byte ones: eight times the load instructions for the same bytes).  The sampling geometry is
 // recomputed by each of the 8 lanes (cheaper than handing it around); the 18 sums are reduced over the 8 lanes with a transposing
 // butterfly (14 + 6 shuffles) after which lane l8 holds the (dh, dw) pair of tap (4*b0 + 2*b1 + b2) and stores it as one 32-bit word.
-__global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
-                                                                   const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
-                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
-  if (!gate_runs(gate, false)) return;
+template <int R>
+__device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                          const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                          bf16_t* __restrict__ doffs, const DeformGeom& g) {
   const int offc = g.dg * 18;
   const int lane = threadIdx.x & 63, l8 = lane & 7;
   const unsigned nwork = (unsigned)g.N * g.Ho * g.Wo * g.dg;            // (< 2^31: checked by the launcher)
   const float Hf = (float)g.H, Wf = (float)g.W;
-  const float lim = (float)(DEFORM_R - 1);
+  const float lim = (float)R;
   const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
   for (unsigned wbase = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8u; wbase < nwork; wbase += gridDim.x * (blockDim.x >> 6) * 8u) {
     const unsigned item = wbase + (lane >> 3);
@@ -417,8 +421,9 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
       *reinterpret_cast<unsigned*>(dp + (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0)) = pack2bf(r2[0], r2[1]);
       if (l8 == 0) *reinterpret_cast<unsigned*>(dp + 16) = pack2bf(e0, e1);
     }
-    // ---- far corners: not reachable by the gather kernel's +-R enumeration.  A corner sits floor(o) or floor(o)+1 from the nominal
-    // position (one less under the high-edge clamp), so offsets in [-(R-1), R-1) cannot produce one: skip the whole search then
+    // ---- far corners: not reachable by the gather kernel's +-R enumeration.  A corner that corner_set() accepts sits floor(o) or
+    // floor(o) + 1 from the nominal position (under the high-edge clamp the only candidate one further away, H - 1 for a position of
+    // exactly H, fails the |position - corner| < 1 guard), so offsets in [-R, R) cannot produce one: skip the whole search then
     if (!__any(live && farm != 0)) continue;
     if (!live) farm = 0;
     while (farm) {                                                      // (uniform inside an 8-lane item; rare)
@@ -429,13 +434,13 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
       const CornerSet cs = corner_set((float)nh + bf2f((bf16_t)(oraw & 0xffffu)), (float)nw + bf2f((bf16_t)(oraw >> 16)), g.H, g.W);
       bool any_far = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) any_far = any_far || (cs.ok[k] && (abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R));
+      for (int k = 0; k < 4; ++k) any_far = any_far || (cs.ok[k] && (abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R));
       if (!any_far) continue;
       float cg[8];
       unpack8(*reinterpret_cast<const uint4*>(ud + t * g.C), cg);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool far = abs(cs.rh[k] - nh) > DEFORM_R || abs(cs.rw[k] - nw) > DEFORM_R;
+        const bool far = abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R;
         if (cs.ok[k] && far) {
           float* dst = far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + grp * 64 + l8 * 8;
 #pragma unroll
@@ -447,11 +452,21 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
 }
 
 // dX: one wave per (input pixel, group), lane = candidate during the enumeration, lane = channel during the accumulation
-__global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
-                                                                        const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                        int accumulate, BwdGate gate) {
-  if (!gate_runs(gate, false)) return;
-  constexpr int R = DEFORM_R, D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 63) / 64;
+// ONE launch for both gather windows (the window is picked from the statistics at run time): a form that does not run must not cost a
+// launch of its own on a 65536-block grid (~150 us to retire empty; DAN-Deform has 12 of these calls per step).
+__global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                                   const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
+  const int form = gate_form(gate);
+  if (form == 0) deform_bwd_doff9_c64_body<1>(x, offs, dS, far_dx, doffs, g);
+  else if (form == 1) deform_bwd_doff9_c64_body<2>(x, offs, dS, far_dx, doffs, g);
+}
+
+template <int R>
+__device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                               const float* __restrict__ far_dx, bf16_t* __restrict__ dx, const DeformGeom& g,
+                                                               int accumulate) {
+  constexpr int D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 63) / 64;
   const int offc = g.dg * 18;
   const int lane = threadIdx.x & 63;
   const long nwork = (long)g.N * g.H * g.W * g.dg;
@@ -516,8 +531,16 @@ __global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf
   }
 }
 
+__global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                                        const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
+                                                                        int accumulate, BwdGate gate) {
+  const int form = gate_form(gate);
+  if (form == 0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate);
+  else if (form == 1) deform_bwd_dx_gather9_c64_body<2>(offs, dS, far_dx, dx, g, accumulate);
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate, BwdGate gate) {
-  if (gate.stat && !gate_runs(gate, true)) return;
+  if (gate.stat && !gate_runs(gate, 2)) return;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
     float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -531,17 +554,21 @@ __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __rest
   }
 }
 
-// offsets bf16 [pairs][2] -> stat[0] += number of pairs with dh or dw outside [-lim, lim)
-__global__ __launch_bounds__(256) void deform_far_stat_kernel(const bf16_t* __restrict__ offs, long pairs, float lim, unsigned* __restrict__ stat) {
-  unsigned cnt = 0;
+// offsets bf16 [pairs][2] -> stat[0] / stat[1] += number of pairs with dh or dw outside [-2, 2) / [-1, 1)
+__global__ __launch_bounds__(256) void deform_far_stat_kernel(const bf16_t* __restrict__ offs, long pairs, unsigned* __restrict__ stat) {
+  unsigned c2 = 0, c1 = 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (long)gridDim.x * blockDim.x) {
     const unsigned w = reinterpret_cast<const unsigned*>(offs)[i];
     const float dh = bf2f((bf16_t)(w & 0xffffu)), dw = bf2f((bf16_t)(w >> 16));
-    cnt += (!(dh >= -lim && dh < lim) || !(dw >= -lim && dw < lim)) ? 1u : 0u;
+    c2 += (!(dh >= -2.f && dh < 2.f) || !(dw >= -2.f && dw < 2.f)) ? 1u : 0u;
+    c1 += (!(dh >= -1.f && dh < 1.f) || !(dw >= -1.f && dw < 1.f)) ? 1u : 0u;
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(stat, cnt);
+  for (int o = 32; o >= 1; o >>= 1) { c2 += __shfl_xor(c2, o, 64); c1 += __shfl_xor(c1, o, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (c2) atomicAdd(stat, c2);
+    if (c1) atomicAdd(stat + 1, c1);
+  }
 }
 
 int make_geom(DeformGeom* g, int N, int H, int W, int C, int kh, int kw, int stride, int dil, int dg, const char* what) {
@@ -604,23 +631,23 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
     const long pairs = (long)N * g.Ho * g.Wo * deformable_group * 9;
     // A corner lies floor(o) or floor(o) + 1 from the tap's nominal position, so it is outside the +-R window iff o is outside [-R, R).
-    // Gather form while at most 15 % of the taps have such an offset (160 x 160 x 256, batch 16, offsets N(0, s): s = 0.5 / 1.0 px ->
-    // 0 % / 9 % -> 3.4 / 7.7 ms; s = 2.0 -> 53 % -> 43 ms; the scatter form: 12.0 ms whatever the offsets)
-    BwdGate gate{stat, (unsigned)(pairs / 20 * 3), danhip_option("deform_bwd_form")};
-    hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs,
-                       (float)DEFORM_R, stat);
-    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, dim3(grid_for((nd + 31) / 32 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
-                       gate);
-    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, dim3(grid_for((ng + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, offsets, dS, workspace, dx, g,
-                       accumulate, gate);
+    // Scatter form beyond 15 % of the taps outside [-2, 2) (160 x 160 x 256, batch 16, offsets N(0, s): s = 0.5 / 1.0 px -> 0 % / 9 % ->
+    // 3.4 / 7.7 ms in the +-2 gather form; s = 2.0 -> 53 % -> 43 ms; the scatter form: 12.0 ms whatever the offsets); the +-1 window
+    // (81 candidates per input pixel and group instead of 225) while fewer than 1 / 128 of the taps lie outside [-1, 1).
+    BwdGate gate{stat, (unsigned)(pairs / 20 * 3), (unsigned)(pairs / 128), danhip_option("deform_bwd_form")};
+    hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs, stat);
+    const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, 65536));
+    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate);
+    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate);
+    // the scatter form's two kernels on small grids (grid-stride loops): empty ~10 us each when a gather form runs
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
-    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
+    hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 2048)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
                        gate);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, gate);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8, 256, 2048)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, gate);
     DH_LAUNCH_CHECK();
     return DANHIP_OK;
   }
-  const BwdGate none{nullptr, 0u, 0};
+  const BwdGate none{nullptr, 0u, 0u, 0};
   if (C / deformable_group == 64) {
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 65536)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,

@@ -49,8 +49,8 @@ int danhip_version(void);
  *   "wgrad_slab" [DANHIP_WGRAD_SLAB, 1]  0: weight-gradient partial sums always by fp32 atomics; 2: always stores + combine pass; 1: by launch length
  *   "halo_b2"    [DANHIP_HALO_B2, 0]     1: a second workgroup barrier per step in csrc/conv_halo.hip (the round-2 form; timing A/B only)
  *   "wgrad_b2"   [DANHIP_WGRAD_B2, 0]    1: the same for csrc/conv_wgrad_rows.hip and csrc/conv_wgrad_pw.hip
- *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 gather or scatter form by the offsets' statistic (on the device),
- *                                           1 always the gather form, 2 always the fp32-atomics scatter form
+ *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 form by the offsets' statistics (on the device), 1 always the
+ *                                           gather form with a +-2 px window, 2 always the fp32-atomics scatter form, 3 gather form, +-1 px
  *   "halo2_ablate" [DANHIP_HALO2_ABLATE, 0]  timing experiments of csrc/conv_halo2.hip (bit mask; results are WRONG with bits 1, 2, 4, 8 set)
  * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
 int danhip_set_option(const char* name, int value);

@@ -26,16 +26,43 @@ def test_gather_and_scatter_forms_of_the_deformable_backward_agree(sigma, dev):
         return dx.float(), doff.float(), int(ws[-64:].view(torch.int32)[0].item())
 
     try:
-        gx, go, far = run(1)
-        sx, so, _ = run(2)
-        ax, ao, far_a = run(0)
+        gx, go, far = run(1)              # gather, +-2 px window
+        sx, so, _ = run(2)                # fp32-atomics scatter
+        nx, no, _ = run(3)                # gather, +-1 px window (everything beyond it through the far-corner atomics)
+        ax, ao, far_a = run(0)            # chosen on the device
     finally:
         _lib.lib().danhip_set_option(b"deform_bwd_form", 0)
     pairs = N * H * W * dg * 9
     assert far == far_a and ((far > pairs // 20 * 3) == (sigma > 1.0)), (far, pairs)
     # dX: fp32 sums in different orders, rounded once to 16 bits; dOffset: the same 64-channel reductions
     scale = gx.abs().max().item()
-    assert (gx - sx).abs().max().item() <= 2e-2 * scale
-    assert (go - so).abs().max().item() <= 2e-2 * go.abs().max().item()
-    want_x, want_o = (sx, so) if sigma > 1.0 else (gx, go)
+    for other_x, other_o in ((sx, so), (nx, no)):
+        assert (gx - other_x).abs().max().item() <= 2e-2 * scale
+        assert (go - other_o).abs().max().item() <= 2e-2 * go.abs().max().item()
+    want_x, want_o = (sx, so) if sigma > 1.0 else (gx, go)           # sigma = 0.4: 1.2 % of the pairs leave [-1, 1) -> the +-2 window
     assert torch.equal(ao, want_o) and (ax - want_x).abs().max().item() <= 2e-2 * scale
+
+
+def test_small_offsets_take_the_narrow_gather_window(dev):
+    """Offsets inside [-1, 1) (the zero-initialised offset convolution of the reference and the first training steps): the +-1 window."""
+    from dan_amd import _lib, ops
+    N, H, W, C, dg = 1, 24, 28, 64, 1
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, H, W, C), generator=g).to(ops.ACT).to(dev)
+    off = ((torch.rand((N, H, W, dg * 18), generator=g) - 0.5) * 1.9).to(ops.ACT).to(dev)
+    dS = torch.randn((N * H * W, 9 * C), generator=g).to(ops.ACT).to(dev)
+    outs = []
+    try:
+        for form in (0, 3, 1):
+            _lib.lib().danhip_set_option(b"deform_bwd_form", form)
+            dx, doff = torch.empty_like(x), torch.empty_like(off)
+            ws = torch.empty((x.numel() + 64,), dtype=torch.float32, device=dev)
+            _lib.call("danhip_deform_sample_bwd", _lib.ptr(x), _lib.ptr(off), _lib.ptr(dS), _lib.ptr(dx), _lib.ptr(doff), N, H, W, C, 3, 3, 1, 1, dg, 0,
+                      _lib.ptr(ws), _lib.stream())
+            torch.cuda.synchronize()
+            outs.append((dx.clone(), doff.clone(), ws[-64:].view(torch.int32)[:2].tolist()))
+    finally:
+        _lib.lib().danhip_set_option(b"deform_bwd_form", 0)
+    assert outs[0][2] == [0, 0]                                       # nothing outside [-2, 2) nor [-1, 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # automatic = the narrow window, bit for bit
+    assert (outs[0][0].float() - outs[2][0].float()).abs().max().item() <= 2e-2 * outs[2][0].float().abs().max().item()
