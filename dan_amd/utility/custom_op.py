@@ -42,26 +42,69 @@ def dynamic_anchor_routing(anchors, gt_targets, labels, mask_in, feat_height, fe
     return mo, do
 
 
-def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, deformable_group, bias=None, relu=False):
+def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, deformable_group, bias=None, relu=False, data_format="NHWC"):
     """custom_op.deform_conv_op (utility/custom_op.py:62; DeformConvOp cpp/Deform/deform_conv.cc:51-167) on NHWC tensors:
-    x bf16 [N,H,W,C], filter fp32 OIHW [Cout,C,kh,kw] (the reference's variable layout, custom_op.py:134), offset bf16
+    x bf16 [N,H,W,C], filter fp32 OIHW [Cout,C/num_groups,kh,kw] (the reference's variable layout, custom_op.py:134), offset bf16
     [N,Ho,Wo,dg*2*kh*kw].  rates / strides are the reference's 4-vectors [1,1,r,r] / [1,1,s,s].
     = deformable im2col (HIP gather kernel) followed by the MFMA convolution kernel run as a 1x1 GEMM over the samples,
     both inside danhip_deform_conv_fwd; the backward is danhip_deform_conv_bwd (DeformConvBackpropOp, :170-189).  `bias` / `relu` fuse the Python-side bias add of
-    deform_conv_2d (custom_op.py:145) and the activation that follows it into the GEMM epilogue."""
+    deform_conv_2d (custom_op.py:145) and the activation that follows it into the GEMM epilogue.
+
+    The op attributes no graph of the reference uses are exact compositions of the SAME / one-group / NHWC kernels (round 3):
+      data_format="NCHW"  (the op's default, deform_conv.cc:61): x [N,C,H,W] / offset [N,dg*2*kh*kw,Ho,Wo] -> [N,Cout,Ho,Wo], transposed around the call;
+      padding="VALID"     (stride 1): the VALID output (ho, wo) samples h = ho + i*r + off — what the SAME output (ho + pad, wo + pad) samples
+                          (GetWindowedOutputSize uses the undilated kernel, :473-479) — so the offsets are embedded into a SAME-sized
+                          tensor, the SAME op runs, and the VALID window is cropped out: same sample positions, same arithmetic;
+      num_groups=G > 1    (:487-515: G contiguous channel groups, weight [G, Cout/G, C/G*kh*kw]): one call per group on its channel slice,
+                          with the deformable groups that slice covers (needs G | dg or dg | G), outputs concatenated.
+    fp32 / fp64 activations stay unsupported on the training path (16-bit storage; the fp32 inference path is ops.*_f32)."""
     from .. import ops
-    if padding != "SAME":
-        raise ValueError("only padding='SAME' is used by the reference graphs (net/danet_deform.py:279)")
-    if num_groups != 1:
-        raise ValueError("num_groups must be 1 (custom_op.py:141)")
+    if data_format == "NCHW":
+        y = deform_conv_op(x.permute(0, 2, 3, 1).contiguous(), filter, offset.permute(0, 2, 3, 1).contiguous(), rates, padding, strides, num_groups,
+                           deformable_group, bias=bias, relu=relu)
+        return y.permute(0, 3, 1, 2).contiguous()
+    if data_format != "NHWC":
+        raise ValueError("data_format must be 'NHWC' or 'NCHW' (deform_conv.cc:61)")
     if len(rates) != 4 or len(strides) != 4 or rates[2] != rates[3] or strides[2] != strides[3]:
         raise ValueError("rates / strides must be [1, 1, r, r] / [1, 1, s, s] (deform_conv.cc:409-438)")
-    cout, cin, kh, kw = filter.shape
-    if x.shape[-1] != cin:
-        raise ValueError("filter expects %d input channels, input has %d" % (cin, x.shape[-1]))
+    cout, cin_g, kh, kw = filter.shape
+    if num_groups < 1 or x.shape[-1] != cin_g * num_groups or cout % num_groups != 0:
+        raise ValueError("filter [%d, %d, ...] does not fit %d input channels in %d groups (deform_conv.cc:426-438)"
+                         % (cout, cin_g, x.shape[-1], num_groups))
     if offset.shape[-1] != 2 * kh * kw * deformable_group:
         raise ValueError("offset must have 2*kh*kw*deformable_group = %d channels (deform_conv.cc:116), got %d"
                          % (2 * kh * kw * deformable_group, offset.shape[-1]))
+    if padding == "VALID":
+        if int(strides[2]) != 1:
+            raise ValueError("padding='VALID' is composed from the SAME kernels for stride 1 only")
+        H, W = x.shape[1], x.shape[2]
+        ho, wo = H - kh + 1, W - kw + 1
+        if tuple(offset.shape[1:3]) != (ho, wo):
+            raise ValueError("VALID offsets must be [N, %d, %d, .] (deform_conv.cc:473-479), got %s" % (ho, wo, tuple(offset.shape)))
+        pt, pl = (kh - 1) // 2, (kw - 1) // 2
+        full = torch.nn.functional.pad(offset, (0, 0, pl, W - wo - pl, pt, H - ho - pt))
+        y = deform_conv_op(x, filter, full, rates, "SAME", strides, num_groups, deformable_group, bias=bias, relu=relu)
+        return y[:, pt:pt + ho, pl:pl + wo, :].contiguous()
+    if padding != "SAME":
+        raise ValueError("padding must be 'SAME' or 'VALID'")
+    if num_groups != 1:
+        G, dg, C = num_groups, deformable_group, x.shape[-1]
+        if dg % G != 0 and G % dg != 0:
+            raise ValueError("num_groups = %d and deformable_group = %d: one must divide the other" % (G, dg))
+        T2 = 2 * kh * kw
+        outs = []
+        for gi in range(G):
+            xs = x[..., gi * cin_g:(gi + 1) * cin_g].contiguous()
+            if dg % G == 0:                          # the slice covers dg / G whole deformable groups
+                d0, dl = gi * (dg // G), dg // G
+            else:                                    # the slice lies inside ONE deformable group
+                d0, dl = gi // (G // dg), 1
+            offs = offset[..., d0 * T2:(d0 + dl) * T2].contiguous()
+            fg = filter[gi * (cout // G):(gi + 1) * (cout // G)]
+            bg = None if bias is None else bias[gi * (cout // G):(gi + 1) * (cout // G)]
+            outs.append(deform_conv_op(xs, fg, offs, rates, "SAME", strides, 1, dl, bias=bg, relu=relu))
+        return torch.cat(outs, dim=-1)
+    cin = cin_g
     w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
     if cout % 8 == 0:
         # DeformConvOp / DeformConvBackpropOp as single library calls (danhip_deform_conv_{fwd,bwd})

@@ -15,7 +15,16 @@ import torch
 from .tf_ops import same_pad
 
 
-def _sample_setup(x, offset, kh, kw, stride, dilation, dg):
+def _window(in_size, k, stride, padding):
+    """GetWindowedOutputSize as DeformConvOp calls it (deform_conv.cc:473-479: the UNDILATED kernel size): (pad_before, out)."""
+    if padding == "SAME":
+        before, _, out = same_pad(in_size, k, stride)
+        return before, out
+    assert padding == "VALID", padding
+    return 0, -(-(in_size - k + 1) // stride)
+
+
+def _sample_setup(x, offset, kh, kw, stride, dilation, dg, padding="SAME"):
     """Common sampling geometry. x [B,C,H,W], offset [B, dg*2*kh*kw, Ho, Wo].
 
     Returns dict with per-(b,g,tap,ho,wo) tensors mirroring the kernel's arithmetic:
@@ -24,8 +33,8 @@ def _sample_setup(x, offset, kh, kw, stride, dilation, dg):
     pad = TF SAME pad_before from the UNDILATED kernel (deform_conv.cc:473-479).
     """
     B, C, H, W = x.shape
-    pad_h, _, Ho = same_pad(H, kh, stride)
-    pad_w, _, Wo = same_pad(W, kw, stride)
+    pad_h, Ho = _window(H, kh, stride, padding)
+    pad_w, Wo = _window(W, kw, stride, padding)
     assert offset.shape == (B, dg * 2 * kh * kw, Ho, Wo), (offset.shape, (B, dg * 2 * kh * kw, Ho, Wo))
     off = offset.reshape(B, dg, kh * kw, 2, Ho, Wo)
     off_h, off_w = off[:, :, :, 0], off[:, :, :, 1]            # [B,dg,T,Ho,Wo]
@@ -43,9 +52,9 @@ def _sample_setup(x, offset, kh, kw, stride, dilation, dg):
                 map_h=map_h, map_w=map_w)
 
 
-def deform_im2col(x, offset, kh, kw, stride=1, dilation=1, dg=1):
+def deform_im2col(x, offset, kh, kw, stride=1, dilation=1, dg=1, padding="SAME"):
     """Returns col [B, C, kh*kw, Ho, Wo] (differentiable w.r.t. x through torch autograd)."""
-    g = _sample_setup(x, offset, kh, kw, stride, dilation, dg)
+    g = _sample_setup(x, offset, kh, kw, stride, dilation, dg, padding)
     B, C, H, W, Ho, Wo = g["B"], g["C"], g["H"], g["W"], g["Ho"], g["Wo"]
     cpg = C // dg
     inb = (g["h_im"] >= 0) & (g["w_im"] >= 0) & (g["h_im"] < H) & (g["w_im"] < W)
@@ -82,13 +91,18 @@ def deform_im2col(x, offset, kh, kw, stride=1, dilation=1, dg=1):
     return val.reshape(B, C, kh * kw, Ho, Wo)
 
 
-def deform_conv_forward(x, w_oihw, offset, stride=1, dilation=1, dg=1):
-    """DeformConvOp (deform_conv.cc:392-535): out[b] = W[Co, Cin*kh*kw] . col[b]  (num_groups=1).
-    x [B,Cin,H,W], w [Cout,Cin,kh,kw], offset [B,2*kh*kw*dg,Ho,Wo] -> [B,Cout,Ho,Wo]."""
-    co, ci, kh, kw = w_oihw.shape
-    col = deform_im2col(x, offset, kh, kw, stride, dilation, dg)
+def deform_conv_forward(x, w_oihw, offset, stride=1, dilation=1, dg=1, padding="SAME", num_groups=1):
+    """DeformConvOp (deform_conv.cc:392-535): out[b][g] = W[g][Co/G, Cin/G*kh*kw] . col[b][g] — the batched matmul over `group_`
+    contiguous channel groups of :487-515 (weight viewed [group, M, K], column buffer [group, K, N]).
+    x [B,Cin,H,W], w [Cout,Cin/G,kh,kw], offset [B,2*kh*kw*dg,Ho,Wo] -> [B,Cout,Ho,Wo]."""
+    co, cig, kh, kw = w_oihw.shape
+    col = deform_im2col(x, offset, kh, kw, stride, dilation, dg, padding)
     B, C, T, Ho, Wo = col.shape
-    return torch.einsum("ok,bkn->bon", w_oihw.reshape(co, ci * T), col.reshape(B, C * T, Ho * Wo)).reshape(B, co, Ho, Wo)
+    G = num_groups
+    assert C == cig * G and co % G == 0
+    colg = col.reshape(B, G, cig * T, Ho * Wo)
+    wg = w_oihw.reshape(G, co // G, cig * T)
+    return torch.einsum("gok,bgkn->bgon", wg, colg).reshape(B, co, Ho, Wo)
 
 
 def _coord_weight_parts(g, H, W):
@@ -110,11 +124,11 @@ def _coord_weight_parts(g, H, W):
     return oob, ih, iw, h_low, w_low, h_high, w_high
 
 
-def deform_conv_backward(x, w_oihw, offset, dy, stride=1, dilation=1, dg=1):
-    """DeformConvBackpropOp (deform_conv.cc:635-771): returns (dx, dw, doffset), explicit formulas."""
+def deform_conv_backward(x, w_oihw, offset, dy, stride=1, dilation=1, dg=1, padding="SAME"):
+    """DeformConvBackpropOp (deform_conv.cc:635-771): returns (dx, dw, doffset), explicit formulas (num_groups = 1)."""
     co, ci, kh, kw = w_oihw.shape
     T = kh * kw
-    g = _sample_setup(x, offset, kh, kw, stride, dilation, dg)
+    g = _sample_setup(x, offset, kh, kw, stride, dilation, dg, padding)
     B, C, H, W, Ho, Wo = g["B"], g["C"], g["H"], g["W"], g["Ho"], g["Wo"]
     cpg = C // dg
     # col_grad = W^T . dY   [B, C, T, Ho, Wo]   (deform_conv.cc:736)
@@ -174,7 +188,7 @@ def deform_conv_backward(x, w_oihw, offset, dy, stride=1, dilation=1, dg=1):
         dx.scatter_add_(3, idx, contrib.reshape(B, dg, cpg, -1))
     dx = dx.reshape(B, C, H, W)
     # ---- dW = sum_b dY_b . col_b^T  (deform_conv.cc:757-768)
-    col = deform_im2col(x, offset, kh, kw, stride, dilation, dg).reshape(B, C * T, Ho * Wo)
+    col = deform_im2col(x, offset, kh, kw, stride, dilation, dg, padding).reshape(B, C * T, Ho * Wo)
     dw = torch.einsum("bon,bkn->ok", dy.reshape(B, co, Ho * Wo), col).reshape(co, ci, kh, kw)
     return dx, dw, doffset
 
