@@ -45,7 +45,27 @@ struct WgRowsArgs {
   float* slab;         // optional workspace: every block stores its partial tile here (plain 16-byte stores) and wg_rows_reduce_kernel combines
   int splits;
   FastDiv div_tx, div_h, div_ci, div_pairs;
+#ifdef WR_TRACE
+  unsigned* trace;     // tools/halo2_trace.hip -DTRACE_WGRAD: [2 groups][128 K-steps][4 stamps] shader clocks of workgroup 0, waves 0 and 4
+#endif
 };
+
+#ifdef WR_TRACE
+// all-scalar time stamp into LDS behind the two rings (the dynamic LDS segment starts at LDS address 0)
+#define WR_STAMP(slot)                                                                                              \
+  do {                                                                                                              \
+    if (blockIdx.x == 0 && (wave & 3) == 0 && tr_step < 128) {                                                       \
+      const unsigned t_ = (unsigned)__builtin_readcyclecounter();                                                   \
+      const unsigned sa_ = (unsigned)(XBASE + DEPTH * XS + (((wave >> 2) * 128 + tr_step) * 4 + (slot)) * 4);       \
+      unsigned va_, vd_;                                                                                            \
+      asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\tds_write_b32 %0, %1" : "=&v"(va_), "=&v"(vd_) : "s"(sa_), "s"(t_) : "memory"); \
+    }                                                                                                               \
+  } while (0)
+#define WR_STEP_DONE() (++tr_step)
+#else
+#define WR_STAMP(slot) do { } while (0)
+#define WR_STEP_DONE() do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wr_wait_vmcnt() {
@@ -285,11 +305,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // them in the phase after that barrier, A one phase later.  b2 is off by default (option "wgrad_b2"; -2.5 % on the layer set): a slot is
   // rewritten only by waves that have passed the b1 after its last readers' reads completed (argument in conv_halo.hip's main loop).
   RowStep nxt;
+  [[maybe_unused]] int tr_step = 0;
   if (grp == 0) {
     gen_next(nxt, P);
     for (int v = 0; v < V; v += DEPTH) {
       auto step = [&](auto uc) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
+        WR_STAMP(0);
         dma_step(std::integral_constant<int, (U + P) % DEPTH>{}, nxt);   // geometry from the previous phase
         __builtin_amdgcn_sched_barrier(0);
         mem(uc);
@@ -297,12 +319,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         gen_next(nxt, P + 1);                        // the next K-step's DMA geometry (scalar work under the reads' latency)
         wr_wait_vmcnt<2 * (P - 1)>();
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+        WR_STAMP(1);
         __builtin_amdgcn_s_barrier();                // b1
+        WR_STAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         if (flags & 1ull) mma(uc);
         flags >>= 1;
         __builtin_amdgcn_sched_barrier(0);
+        WR_STAMP(3);
         if (a.b2) __builtin_amdgcn_s_barrier();      // b2
+        WR_STEP_DONE();
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
@@ -318,25 +344,35 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       auto step = [&](auto uc) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        WR_STAMP(0);
         __builtin_amdgcn_sched_barrier(0);
         if (flags & 1ull) mma(uc);
         flags >>= 1;
         __builtin_amdgcn_sched_barrier(0);
+        WR_STAMP(1);
         wr_wait_vmcnt<2 * (P - 1)>();
         __builtin_amdgcn_s_barrier();                // b1
+        WR_STAMP(2);
         dma_step(std::integral_constant<int, (U + 1 + P) % DEPTH>{}, nxt);
         __builtin_amdgcn_sched_barrier(0);
         mem(std::integral_constant<int, (U + 1) % DEPTH>{});
         __builtin_amdgcn_sched_barrier(0);
         gen_next(nxt, P + 1);
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        WR_STAMP(3);
         if (a.b2) __builtin_amdgcn_s_barrier();      // b2
+        WR_STEP_DONE();
       };
       step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
       step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
     }
   }
   wr_wait_vmcnt<0>();                                 // zero-fill pieces of the steps beyond the stream are still landing
+#ifdef WR_TRACE
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (int i = tid; i < 1024; i += 512) a.trace[i] = reinterpret_cast<const unsigned*>(smem + XBASE + DEPTH * XS)[i];
+#endif
 
   if (a.ablate) {
 #pragma unroll
@@ -422,6 +458,13 @@ __global__ __launch_bounds__(256) void wg_rows_reduce_kernel(const WgRowsArgs a)
   }
 }
 
+#ifdef WR_TRACE
+unsigned* wr_trace_buffer() {
+  static unsigned* p = [] { void* q = nullptr; (void)hipMalloc(&q, 4096 + 64); (void)hipMemset(q, 0, 4096 + 64); return (unsigned*)q; }();
+  return p;
+}
+#endif
+
 int wr_cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -434,7 +477,12 @@ int wr_cu_count() {
 
 template <int COT>
 int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
+#ifdef WR_TRACE
+  constexpr int LDS = 6 * (32 * COT * 2) + 6 * 40 * 128 + 4096;
+  a.trace = wr_trace_buffer();
+#else
   constexpr int LDS = 6 * (32 * COT * 2) + 6 * 40 * 128;
+#endif
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_kernel<COT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;

@@ -5,6 +5,7 @@
 // Build (the kernel source is compiled INTO this program with -DH2_TRACE; the library build has no stamps):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DH2_TRACE -I dan_amd/csrc -o tools/halo2_trace tools/halo2_trace.hip
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRACE_HALO1 -I dan_amd/csrc -o tools/halo1_trace tools/halo2_trace.hip     (conv_halo.hip)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRACE_WGRAD -I dan_amd/csrc -o tools/wgrad_trace tools/halo2_trace.hip     (conv_wgrad_rows.hip)
 // Run:  tools/halo2_trace [fwd|dgrad] [N H W C Co]       (default: conv3_2 of the benchmark, 16 x 160 x 160 x 256 -> 256)
 #include <hip/hip_runtime.h>
 
@@ -13,7 +14,11 @@
 #include <cstring>
 #include <vector>
 
-#ifdef TRACE_HALO1      // the production kernel (conv_halo.hip, 8 x 32 pixel tiles, 64-channel chunks) instead of conv_halo2.hip
+#ifdef TRACE_WGRAD      // the row-streaming weight gradient (conv_wgrad_rows.hip): "fwd" / "dgrad" on the command line are ignored
+#define WR_TRACE 1
+#include "../dan_amd/csrc/conv_wgrad_rows.hip"
+#define TRACE_BUFFER wr_trace_buffer
+#elif defined(TRACE_HALO1)      // the production kernel (conv_halo.hip, 8 x 32 pixel tiles, 64-channel chunks) instead of conv_halo2.hip
 #define H_TRACE 1
 #include "../dan_amd/csrc/conv_halo.hip"
 #define TRACE_LAUNCH danhip_launch_conv_halo
@@ -37,6 +42,7 @@ void danhip_set_error(const char* fmt, ...) {
 int danhip_option(const char* name) {
   if (!strcmp(name, "halo2")) return 1;
   if (!strcmp(name, "halo_b2")) { const char* e = getenv("DANHIP_HALO_B2"); return e ? atoi(e) : 0; }
+  if (!strcmp(name, "wgrad_b2")) { const char* e = getenv("DANHIP_WGRAD_B2"); return e ? atoi(e) : 0; }
   if (!strcmp(name, "halo2_ablate")) { const char* e = getenv("DANHIP_HALO2_ABLATE"); return e ? atoi(e) : 0; }
   return 0;
 }
@@ -64,6 +70,11 @@ int main(int argc, char** argv) {
   hipMalloc(&dx, nx * 2); hipMalloc(&dw, nw * 2); hipMalloc(&dy, ny * 2); hipMalloc(&db, Co * 4); hipMalloc(&dbits, ny / 8);
   hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice);
   hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice);
+  {                                                  // (the weight-gradient mode reads y as its dY operand)
+    std::vector<unsigned short> hy(ny);
+    for (auto& v : hy) v = rnd_bf16(st);
+    hipMemcpy(dy, hy.data(), ny * 2, hipMemcpyHostToDevice);
+  }
   hipMemset(db, 0, Co * 4);
   hipMemset(dbits, 0xA5, ny / 8);
   ConvArgs a{};
@@ -76,11 +87,20 @@ int main(int argc, char** argv) {
   hipStreamCreate(&s);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
+#ifdef TRACE_WGRAD
+  float* ddw;
+  hipMalloc(&ddw, (size_t)9 * C * Co * 4);
+  danhip_conv_desc dd{};
+  dd.N = N; dd.H = H; dd.W = W; dd.Cin = C; dd.Ho = H; dd.Wo = W; dd.Cout = Co; dd.kh = dd.kw = 3; dd.stride = 1;
+  auto launch = [&]() { hipMemsetAsync(ddw, 0, (size_t)9 * C * Co * 4, s); return danhip_launch_wgrad_rows(&dd, dx, dy, ddw, nullptr, C, s, nullptr, 0); };
+#else
+  auto launch = [&]() { return TRACE_LAUNCH(a, s); };
+#endif
   for (int i = 0; i < 3; ++i)
-    if (TRACE_LAUNCH(a, s) != 0) { fprintf(stderr, "not eligible / launch failed\n"); return 1; }
+    if (launch() != 0) { fprintf(stderr, "not eligible / launch failed\n"); return 1; }
   hipEventRecord(e0, s);
   const int reps = 20;
-  for (int i = 0; i < reps; ++i) TRACE_LAUNCH(a, s);
+  for (int i = 0; i < reps; ++i) launch();
   hipEventRecord(e1, s);
   hipStreamSynchronize(s);
   float ms = 0;
