@@ -688,3 +688,46 @@ def _halo2_case(shape, d, dev):
         assert (outs["mask"].float().cpu() - want).abs().max().item() <= 2.0 ** -6 * scale + 2e-3
         assert torch.equal(outs["bits"], outs["mask"]) and torch.equal(outs["bits_acc"], outs["mask_acc"])
         assert (outs["mask_acc"].float().cpu() - (want + old.float().cpu())).abs().max().item() <= 2.0 ** -6 * (scale + 4) + 2e-2
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(4, 160, 160, 128, 256), (3, 83, 121, 192, 136)])
+def test_one_barrier_per_step_is_bit_identical_to_the_two_barrier_form(N, H, W, Cin, Cout, dev):
+    """Round 3 dropped the second workgroup barrier per step of the 3x3 tile kernels (conv_halo.hip main-loop comment: b1 alone carries the
+    LDS hand-offs).  Forward and data gradient have no atomics, so the two forms must agree bit for bit, repeatedly, also while another
+    stream keeps the chip busy (tools/stress_determinism.py is the long version)."""
+    import ctypes
+    from dan_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    d = ops._desc(N, H, W, Cin, Cout, 3, 3, 1)
+    wf, wb = ops.pack_conv_weight(d, w, need_bwd=True)
+    co8 = (Cout + 7) // 8 * 8
+    dy = torch.zeros((N, H, W, co8), dtype=ops.ACT)
+    dy[..., :Cout] = torch.randn((N, H, W, Cout), generator=g).to(ops.ACT)
+    dy = dy.to(dev)
+    dw = torch.zeros((3, 3, Cin, Cout), dtype=torch.float32, device=dev)
+    db = torch.zeros((Cout,), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+
+    def run():
+        y = torch.empty((N, H, W, Cout), dtype=ops.ACT, device=dev)
+        dx = torch.empty_like(x)
+        _lib.call("danhip_conv2d_fwd", ctypes.byref(d), _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), _lib.ptr(y), _lib.BF16, 1, None, _lib.stream())
+        _lib.call("danhip_conv2d_bwd_data", ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wb), _lib.ptr(x), _lib.ptr(dx), 0, _lib.stream())
+        torch.cuda.synchronize()
+        return y, dx
+
+    try:
+        _lib.lib().danhip_set_option(b"halo_b2", 1)
+        y2, dx2 = run()
+        _lib.lib().danhip_set_option(b"halo_b2", 0)
+        for _ in range(12):
+            with torch.cuda.stream(side):
+                _lib.call("danhip_conv2d_bwd_weight", ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), Cin, _lib.stream())
+            y1, dx1 = run()
+            assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    finally:
+        _lib.lib().danhip_set_option(b"halo_b2", 0)
+        torch.cuda.synchronize()
