@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -16,6 +17,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 #define LDS_AS __attribute__((address_space(3)))
+static unsigned g_window = 2u << 20;
 
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned lds_addr) {
   unsigned keep;
@@ -29,6 +31,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // MODE 1: the same, but only the first third of the reads in the mem phase, the rest issued inside the MFMA phase (just-in-time)
 // MODE 2: MFMA only (no reads, no DMA, no barriers): the clock-limited ceiling of the box
 // MODE 3: all eight waves run the same stream (reads of the next step interleaved with the MFMAs, one barrier per phase)
+// MODE 4: MODE 0 without the second barrier (the round-3 form of the kernels)
 template <int NM, int NR, int ND, int MODE>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const unsigned short* __restrict__ src, float* __restrict__ out,
                                                                                           int phases, unsigned src_bytes, unsigned window) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mma(0, NM);
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();                // b2
+      if (MODE != 4) __builtin_amdgcn_s_barrier();                // b2
     }
   } else {
     for (int ph = 0; ph < phases; ++ph) {
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       reads(0, PRE, ph + 1);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_s_barrier();                // b2
+      if (MODE != 4) __builtin_amdgcn_s_barrier();                // b2
     }
   }
   wait_vmcnt<0>();
@@ -142,7 +145,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   out[(size_t)blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
 }
 
-static unsigned g_window = 2u << 20;
 
 template <int NM, int NR, int ND, int MODE>
 static void run(const char* name, const unsigned short* src, float* out, unsigned src_bytes, double mfma_only_tf) {
@@ -165,6 +167,88 @@ static void run(const char* name, const unsigned short* src, float* out, unsigne
   const double tf = flop / (ms * 1e-3) / 1e12;
   printf("%-44s N=%3d reads=%3d dma=%d  %8.3f ms  %8.1f TFLOP/s  %5.1f %% of the MFMA-only rate\n", name, NM, NR, ND, ms, tf,
          mfma_only_tf > 0 ? 100.0 * tf / mfma_only_tf : 100.0);
+}
+
+
+// ONE wave per SIMD (256-thread workgroup, the whole 512-register file per wave): every wave runs the software-pipelined stream -- the
+// fragment reads of phase ph + 1 are issued before the MFMAs of phase ph and land under them (two fragment sets), DMA issue first, one
+// barrier per phase.  No partner wave covers anything: what this reaches is what a one-wave design can reach.
+template <int NM, int NR, int ND>
+__global__ __launch_bounds__(256, 1) void probe_single(const unsigned short* __restrict__ src, float* __restrict__ out, int phases, unsigned src_bytes,
+                                                       unsigned window) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
+  const unsigned long long a = (unsigned long long)src;
+  const u32x4 rsrc = {(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, src_bytes, 0x00020000u};
+  for (int i = 0; i < 16; ++i) dma16(rsrc, (unsigned)((blockIdx.x * 64 + wave * 16 + i) * 1024 + lane * 16) & (src_bytes - 1u), lds0 + (wave * 16 + i) * 1024);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  f32x4 acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[2][8], fb[2][8];
+#pragma unroll
+  for (int sset = 0; sset < 2; ++sset)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fa[sset][i] = *reinterpret_cast<const bf16x8*>(smem + (i * 1024 + lane * 16));
+      fb[sset][i] = *reinterpret_cast<const bf16x8*>(smem + ((8 + i) * 1024 + lane * 16));
+    }
+  unsigned doff = (unsigned)(wave) * 65536u + (unsigned)lane * 16u;
+  const unsigned ring = 65536;
+  auto step = [&](auto setc, int ph) __attribute__((always_inline)) {
+    constexpr int S = decltype(setc)::value;
+#pragma unroll
+    for (int d = 0; d < 2 * ND; ++d) {               // four waves move what eight moved
+      dma16(rsrc, doff & (window - 1u), lds0 + ring + (unsigned)(((ph * 2 * ND + d) & 15) * 4 + wave) * 1024);
+      doff += 1024;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {                   // next phase's fragments into the other set
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + ((((r + ph) & 63) * 1024 + lane * 16)));
+      if (r & 1) fa[1 - S][(r >> 1) & 7] = v; else fb[1 - S][(r >> 1) & 7] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) acc[i & 31] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[S][i & 7], fb[S][(i >> 3) & 7], acc[i & 31], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<4 * ND>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int ph = 0; ph < phases; ph += 2) {
+    step(std::integral_constant<int, 0>{}, ph);
+    step(std::integral_constant<int, 1>{}, ph + 1);
+  }
+  wait_vmcnt<0>();
+  f32x4 s = acc[0];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) s += acc[i];
+  out[(size_t)blockIdx.x * 256 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int NM, int NR, int ND>
+static void run_single(const char* name, const unsigned short* src, float* out, unsigned src_bytes, double mfma_only_tf) {
+  const int lds = 128 * 1024;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_single<NM, NR, ND>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int phases = (400000 / NM) & ~1;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe_single<NM, NR, ND>), dim3(256), dim3(256), lds, 0, src, out, phases, src_bytes, g_window);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((probe_single<NM, NR, ND>), dim3(256), dim3(256), lds, 0, src, out, phases, src_bytes, g_window);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double tf = 256.0 * 4 * (double)phases * NM * 16384.0 / (ms * 1e-3) / 1e12;
+  printf("%-44s N=%3d reads=%3d dma=%d  %8.3f ms  %8.1f TFLOP/s  %5.1f %% of the MFMA-only rate\n", name, NM, NR, 2 * ND, ms, tf, 100.0 * tf / mfma_only_tf);
 }
 
 template <int NM, int NR, int ND, int MODE>
@@ -222,5 +306,14 @@ int main(int argc, char** argv) {
   run<64, 24, 3, 0>("64 MFMA, 24 reads, 3 DMA, two groups", src, out, src_bytes, peak);
   run<96, 36, 3, 0>("96 MFMA, 36 reads, 3 DMA", src, out, src_bytes, peak);
   run<36, 7, 1, 0>("wgrad ratio, 1 DMA", src, out, src_bytes, peak);
+  // round 3: the one-barrier form of today's kernels, and the one-wave-per-SIMD alternative ("open after round 3")
+  run<32, 16, 3, 4>("halo today, ONE barrier per phase", src, out, src_bytes, peak);
+  run<32, 12, 2, 4>("64px x 128co wave tile, one barrier", src, out, src_bytes, peak);
+  run<36, 7, 2, 4>("wgrad today, one barrier", src, out, src_bytes, peak);
+  run_single<32, 12, 1>("ONE wave per SIMD: 32 MFMA, 12 reads", src, out, src_bytes, peak);
+  run_single<64, 24, 2>("one wave per SIMD: 64 MFMA, 24 reads", src, out, src_bytes, peak);
+  run_single<64, 16, 2>("one wave per SIMD: 64 MFMA, 16 reads (128x128 wave tile)", src, out, src_bytes, peak);
+  run_single<128, 32, 3>("one wave per SIMD: 128 MFMA, 32 reads", src, out, src_bytes, peak);
+  run_single<64, 0, 0>("one wave per SIMD: MFMA + barrier only", src, out, src_bytes, peak);
   return 0;
 }
