@@ -743,6 +743,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   //   * the same argument with chunks for the two patch buffers (written from step 0 of chunk q, last read for the last step of chunk
   //     q-1) and for the ReLU-bit staging area (written in step 1 of an item, last read by the previous item's epilogues: A's in
   //     mem(0), B's before its MFMA phase of step 0 -- both before b1 of step 0).
+  // This holds because NO LDS read happens after b1 of its cycle.  The three-taps-per-step form (TPS == 3) reads its third tap's fragments
+  // INSIDE the MFMA phase: without b2 a faster wave of group A could start mem(c+1) -- and rewrite the slot / patch buffer of step c-1..c
+  // -- while a slower A wave is still reading tap 2 of step c.  Those instances keep the second barrier.
   // DMA queue of a wave, oldest first: A at its wait in cycle c: [W(c+1)] ... [W(c+D)] -> (D-1)*WL may stay in flight, plus
   // a patch if it was issued within the last D-1 cycles; B (which has issued up to cycle c-1): (D-2)*WL, patch age <= D-2.
   int chunk = 0, cc = 0;                           // running chunk number: patch buffer = chunk & 1
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mma(wbase, pofs, stepc);
         __builtin_amdgcn_sched_barrier(0);
         H_STAMP(3);
-        if (g.b2) __builtin_amdgcn_s_barrier();    // b2
+        if (TPS == 3 || g.b2) __builtin_amdgcn_s_barrier();      // b2 (always with three taps per step: see the hand-off notes)
         H_STEP_DONE();
       };
       cycle(std::integral_constant<int, 0>{});
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           if (STEP == 0 && p_ok) { issue_patch(); patch_age = 0; }
         }
         H_STAMP(3);
-        if (g.b2) __builtin_amdgcn_s_barrier();    // b2
+        if (TPS == 3 || g.b2) __builtin_amdgcn_s_barrier();      // b2 (always with three taps per step: see the hand-off notes)
         H_STEP_DONE();
       };
       cycle(std::integral_constant<int, 0>{});
