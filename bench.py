@@ -228,8 +228,8 @@ def main():
     # a backward kernel in the timed region includes the time it shares the chip.  For reference the same kernels are also timed
     # serialised (second stream off) in two extra steps AFTER the timed region; that figure is reported beside the in-region one.
     prof_serial = None
-    if os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1" and not args.no_serialized_roofline:   # every rank: the steps carry collectives
-        os.environ["DANHIP_WGRAD_STREAM"] = "0"
+    if ops.WGRAD_STREAM and not args.no_serialized_roofline:   # every rank: the steps carry collectives
+        ops.WGRAD_STREAM = False
         saved_graph, trainer._graph = trainer._graph, None
         ops.PROFILE = {}
         for _ in range(2):
@@ -237,7 +237,7 @@ def main():
         torch.cuda.synchronize()
         prof_serial, ops.PROFILE = ops.PROFILE, None
         trainer._graph = saved_graph
-        os.environ["DANHIP_WGRAD_STREAM"] = "1"
+        ops.WGRAD_STREAM = True
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -366,7 +366,7 @@ def main():
                        "step_launch": "hipGraph replay" if args.graph else "eager",
                        "rccl_ranks": dist.get_world_size() if multi else 1,
                        "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if multi else None,
-                       "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1")},
+                       "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and ops.WGRAD_STREAM)},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],

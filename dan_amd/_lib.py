@@ -85,7 +85,7 @@ SIGNATURES = {
     "danhip_resize_u8_linear": [P, I32, I32, P, I32, I32, I32, ctypes.c_double, ctypes.c_double, P],
     "danhip_bbox_vote": [P, P, I32, I32, ctypes.c_double, I32, P, P, P, ctypes.c_size_t, P],
     "danhip_deform_sample_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
-    "danhip_deform_sample_bwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, P],
+    "danhip_deform_sample_bwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_deform_conv_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_deform_conv_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_deform_conv_bwd_with_col": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
@@ -153,6 +153,8 @@ def lib():
         L.danhip_conv2d_bwd_weight_workspace_bytes.argtypes = [DESC]
         L.danhip_deform_conv_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
+        L.danhip_deform_sample_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.danhip_deform_sample_bwd_workspace_bytes.argtypes = [I32, I32, I32, I32]
         L.danhip_conv2d_fwd_emits_bits.restype = ctypes.c_int
         L.danhip_conv2d_fwd_emits_bits.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_data_takes_bits.restype = ctypes.c_int

@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/danhip.h"
 
@@ -16,7 +18,7 @@ void danhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* danhip_last_error(void) { return g_err; }
-extern "C" int danhip_version(void) { return 1; }
+extern "C" int danhip_version(void) { return 2; }   // 2: danhip_deform_sample_bwd takes workspace_bytes
 extern "C" int danhip_act_dtype(void) {
 #ifdef DANHIP_FP16
   return DANHIP_F16;
@@ -34,30 +36,35 @@ extern "C" int danhip_act_dtype(void) {
 //   "halo_general_epilogue" DANHIP_HALO_GENERAL_EPILOGUE  0 (default) / 1: conv_halo.hip always takes its general epilogue (A/B of the lean one)
 //   "halo2_ablate" DANHIP_HALO2_ABLATE  timing experiments of conv_halo2.hip (bit mask; 16 = second barrier per step)
 namespace {
-struct Opt { const char* name; const char* env; int def; int value; bool init; };
-Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, 0, false}, {"splitk", "DANHIP_SPLITK", 1, 0, false}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, 0, false},
-                {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, 0, false}, {"halo_b2", "DANHIP_HALO_B2", 0, 0, false},
-                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, 0, false}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, 0, false},
-                {"deform_bwd_form", "DANHIP_DEFORM_BWD_FORM", 0, 0, false}};
+// Thread safety ("no mutable globals" on the data path): the table is filled from the environment exactly once
+// (std::call_once, before the first read or write), every value is a relaxed atomic, and the kernels' host launchers read an option
+// once per call into their argument struct - a concurrent danhip_set_option changes which FORM later launches take (all forms are
+// result-equivalent up to fp32 summation order), never a launch already being assembled.
+struct Opt { const char* name; const char* env; int def; std::atomic<int> value; };
+Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, {0}}, {"splitk", "DANHIP_SPLITK", 1, {0}}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, {0}},
+                {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, {0}}, {"halo_b2", "DANHIP_HALO_B2", 0, {0}},
+                {"wgrad_b2", "DANHIP_WGRAD_B2", 0, {0}}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, {0}},
+                {"deform_bwd_form", "DANHIP_DEFORM_BWD_FORM", 0, {0}}};
+std::once_flag g_opts_once;
 Opt* find_opt(const char* name) {
+  std::call_once(g_opts_once, [] {
+    for (Opt& o : g_opts) { const char* e = getenv(o.env); o.value.store(e ? atoi(e) : o.def, std::memory_order_relaxed); }
+  });
   if (!name) return nullptr;
   for (Opt& o : g_opts)
-    if (strcmp(o.name, name) == 0) {
-      if (!o.init) { const char* e = getenv(o.env); o.value = e ? atoi(e) : o.def; o.init = true; }
-      return &o;
-    }
+    if (strcmp(o.name, name) == 0) return &o;
   return nullptr;
 }
 }  // namespace
 
 int danhip_option(const char* name) {
   Opt* o = find_opt(name);
-  return o ? o->value : 0;
+  return o ? o->value.load(std::memory_order_relaxed) : 0;
 }
 extern "C" int danhip_get_option(const char* name) { return danhip_option(name); }
 extern "C" int danhip_set_option(const char* name, int value) {
   Opt* o = find_opt(name);
   if (!o) { danhip_set_error("set_option: unknown option '%s'", name ? name : "(null)"); return DANHIP_EINVAL; }
-  o->value = value;
+  o->value.store(value, std::memory_order_relaxed);
   return DANHIP_OK;
 }

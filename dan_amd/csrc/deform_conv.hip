@@ -613,12 +613,20 @@ extern "C" int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offse
   return DANHIP_OK;
 }
 
+extern "C" size_t danhip_deform_sample_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  return ((size_t)N * H * W * C + 64) * sizeof(float);
+}
+
 /* dS [N*Ho*Wo, kh*kw*C] -> d_offsets bf16 [N,Ho,Wo,dg*2*kh*kw] (overwritten) and dx bf16 [N,H,W,C] (=|+= if accumulate).
  * workspace: N*H*W*C + 64 floats (fp32 scatter target + the far-corner statistic), zeroed inside. */
 extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
-                                        int32_t deformable_group, int accumulate, float* workspace, void* stream) {
+                                        int32_t deformable_group, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
   DH_REQUIRE(x && offsets && dS && dx && d_offsets && workspace, DANHIP_EINVAL, "deform_sample_bwd: null pointer");
+  DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && workspace_bytes >= danhip_deform_sample_bwd_workspace_bytes(N, H, W, C), DANHIP_EWORKSPACE,
+             "deform_sample_bwd: workspace of %zu bytes, needs %zu (N*H*W*C + 64 floats)", workspace_bytes,
+             danhip_deform_sample_bwd_workspace_bytes(N, H, W, C));
   DeformGeom g;
   int rc = make_geom(&g, N, H, W, C, kh, kw, stride, dilation, deformable_group, "deform_sample_bwd");
   if (rc) return rc;
@@ -739,7 +747,7 @@ extern "C" int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t
   int rc = danhip_conv2d_bwd_data(&d, dy, wb_packed, nullptr, dcol, 0, stream);                       // col gradient = W^T dOut (:700-712)
   if (rc) return rc;
   rc = danhip_deform_sample_bwd(x, offsets, dcol, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate_dx, scatter,
-                                stream);                                                              // col2im_coord + col2im (:716-741)
+                                workspace_bytes - 2 * colb, stream);                                                              // col2im_coord + col2im (:716-741)
   if (rc) return rc;
   if (!col_saved) {
     rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);   // re-im2col (:744-748)

@@ -5,7 +5,7 @@
 // Every (score, index) pair becomes ONE 64-bit key whose ascending order is the wanted order:
 //     key = (~monotone(score)) << 32 | index        monotone(x) = bits ^ (sign ? 0xFFFFFFFF : 0x80000000)
 // (descending score; equal scores — bit-identical, or +0 / -0, which compare equal and are mapped to the same key — by ascending index,
-// i.e. a STABLE sort; `ties_high_index_first` is numpy's argsort()[::-1] instead: eval_dan.py:255; positive NaNs sort first, like
+// i.e. a STABLE sort; `ties_high_index_first` is numpy's argsort()[::-1] instead: eval_dan.py:255; NaNs of either sign sort first, like
 // torch.sort(descending=True); the scores here are softmax outputs).  Keys are unique, so a plain bitonic network is exact.
 //
 // n <= 34 125 anchors at 640 x 640 and 87 360 at 1024 x 1024: the network runs on chunks of 8192 keys in LDS (64 KB, 1024 threads x 8
@@ -19,6 +19,8 @@ constexpr int CHUNK = 8192, THREADS = 1024;
 __device__ __forceinline__ unsigned long long sort_key(float score, unsigned idx) {
   unsigned b = __builtin_bit_cast(unsigned, score);
   if ((b << 1) == 0u) b = 0u;                                      // -0 == +0
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) b = 0x7FC00000u;            // every NaN (either sign, any payload) = one value above +inf: first, by index,
+                                                                   // as torch.sort(descending=True); also keeps real keys below the pad key ~0
   const unsigned mono = b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
   return ((unsigned long long)(~mono) << 32) | idx;
 }

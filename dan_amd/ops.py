@@ -172,13 +172,15 @@ def _prof_end(e0, d, which, st=None):
 # this on around its backward pass and joins before the gradients are consumed; tensors the side stream still reads are kept alive
 # until that join (no allocator reuse while in flight, also valid inside a hipGraph capture).
 _WGRAD = {"on": False, "side": None, "main": None, "keep": []}
+# read ONCE at import (DANHIP_WGRAD_STREAM=0: A/B on one stream); a process that wants to switch mid-run (bench.py's serialized
+# roofline leg, tests) assigns ops.WGRAD_STREAM - the environment is never re-read or written
+WGRAD_STREAM = os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1"
 
 
 def wgrad_overlap_begin():
     if not torch.cuda.is_available():
         return
-    import os
-    if os.environ.get("DANHIP_WGRAD_STREAM", "1") != "1":
+    if not WGRAD_STREAM:
         return
     if _WGRAD["side"] is None:
         _WGRAD["side"] = torch.cuda.Stream()
@@ -1011,7 +1013,7 @@ class _DeformSample(torch.autograd.Function):
         doff = torch.empty_like(offsets)
         ws = torch.empty(x.numel() + 64, dtype=torch.float32, device=x.device)      # scatter target + the far-corner statistic
         call("danhip_deform_sample_bwd", ptr(x), ptr(offsets), ptr(dS.contiguous()), ptr(dx), ptr(doff), N, H, W, C, kh, kw, stride, dilation, dg, 0,
-             ptr(ws), stream())
+             ptr(ws), ws.numel() * 4, stream())
         return dx, doff, None, None, None, None, None
 
 

@@ -309,10 +309,13 @@ int danhip_face_scores(const float* cls, float* score, int32_t* mask, float thre
  * ------------------------------------------------------------------------------------------------ */
 int danhip_deform_sample_fwd(const uint16_t* x, const uint16_t* offsets, uint16_t* S, int32_t N, int32_t H, int32_t W, int32_t C,
                              int32_t kh, int32_t kw, int32_t stride, int32_t dilation, int32_t deformable_group, void* stream);
-/* workspace: N*H*W*C + 64 floats (fp32 scatter target + the far-corner statistic that selects the gather or the scatter form on the device) */
+/* workspace: at least (N*H*W*C + 64) * sizeof(float) bytes = danhip_deform_sample_bwd_workspace_bytes (fp32 scatter target + the
+ * far-corner statistic that selects the gather or the scatter form on the device).  ABI version 2 (danhip_version): the call takes
+ * workspace_bytes and returns DANHIP_EWORKSPACE for a smaller buffer (version 1 took no size and sized the buffer N*H*W*C floats). */
+size_t danhip_deform_sample_bwd_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C);
 int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
-                             int32_t deformable_group, int accumulate, float* workspace, void* stream);
+                             int32_t deformable_group, int accumulate, float* workspace, size_t workspace_bytes, void* stream);
 
 /* DeformConvOp / DeformConvBackpropOp as single calls (the bindings custom_op.py:62-63 would make): same tensors and attrs as
  * the TF ops (strides / rates collapsed to one int each, num_groups = 1 as every call site uses), NHWC bf16, all samples in

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), "missing export " + n
     for n in _lib.SIGNATURES:
         assert n in names, "ctypes table binds %s which the header does not declare" % n
-    assert L.danhip_version() >= 1
+    assert L.danhip_version() >= 2       # 2: danhip_deform_sample_bwd(..., workspace, workspace_bytes, stream)
     assert L.danhip_act_dtype() == 1
     # the fp16 build of the same sources exports the same ABI
     L16 = ctypes.CDLL(build.OUT_F16)
@@ -49,6 +49,16 @@ def test_invalid_arguments_are_reported_not_thrown():
     # small_mining_match attribute validation mirrors the op constructor (small_mining_match.cc:291-306)
     rc = L.danhip_small_mining_match(None, 1, 1, 0.0, 0.4, 0.4, 6, 0.3, None, None, None, 0, None)
     assert rc == -1
+    # ABI 2: danhip_deform_sample_bwd refuses a workspace sized to the version-1 contract (N*H*W*C floats, without the 64 statistic words)
+    # before anything is launched (the pointers are never dereferenced on the host)
+    L.danhip_deform_sample_bwd_workspace_bytes.restype = ctypes.c_size_t
+    need = L.danhip_deform_sample_bwd_workspace_bytes(1, 8, 8, 64)
+    assert need == (8 * 8 * 64 + 64) * 4
+    buf = (ctypes.c_char * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = _lib.lib().danhip_deform_sample_bwd(p, p, p, p, p, 1, 8, 8, 64, 3, 3, 1, 1, 1, 0, p, 8 * 8 * 64 * 4, None)
+    assert rc == _lib.lib().danhip_deform_sample_bwd(p, p, p, p, p, 1, 8, 8, 64, 3, 3, 1, 1, 1, 0, p, need - 1, None) != 0
+    assert b"workspace" in L.danhip_last_error()
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

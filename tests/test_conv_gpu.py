@@ -731,3 +731,48 @@ def test_one_barrier_per_step_is_bit_identical_to_the_two_barrier_form(N, H, W, 
     finally:
         _lib.lib().danhip_set_option(b"halo_b2", 0)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(4, 160, 160, 128, 256, 3), (2, 96, 128, 256, 256, 3), (4, 160, 160, 256, 256, 1), (2, 80, 80, 2304, 256, 1)])
+def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H, W, Cin, Cout, k, dev):
+    """the default one-barrier K-step of conv_wgrad_rows.hip (3x3) / conv_wgrad_pw.hip (1x1) had no bit-identity check.  With
+    `wgrad_slab = 2` the partial tiles leave as plain stores and are combined in a fixed order (no atomics), so dW / db must be bit-identical
+    between the two-barrier form (`wgrad_b2 = 1`) and repeated one-barrier runs, also while another stream keeps the chip busy."""
+    import ctypes
+    from dan_amd import _lib, ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+    dy = torch.randn((N, H, W, Cout), generator=g).to(ops.ACT).to(dev)
+    d = ops._desc(N, H, W, Cin, Cout, k, k, 1)
+    L = _lib.lib()
+    side = torch.cuda.Stream()
+    try:
+        L.danhip_set_option(b"wgrad_slab", 2)
+        nws = L.danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+        assert nws > 0, "shape has no slab form: pick another"
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        w0 = (torch.randn((k, k, Cin, Cout), generator=g) / (k * k * Cin) ** 0.5).to(dev)
+        wf, _ = ops.pack_conv_weight(d, w0, need_bwd=False)
+        b0 = torch.zeros((Cout,), device=dev)
+
+        def run():
+            dw = torch.zeros((k, k, Cin, Cout), dtype=torch.float32, device=dev)
+            db = torch.zeros((Cout,), dtype=torch.float32, device=dev)
+            _lib.call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), Cin, _lib.ptr(ws), nws, _lib.stream())
+            torch.cuda.synchronize()
+            return dw, db
+
+        L.danhip_set_option(b"wgrad_b2", 1)
+        dw2, db2 = run()
+        L.danhip_set_option(b"wgrad_b2", 0)
+        assert dw2.abs().max().item() > 0
+        for _ in range(10):
+            with torch.cuda.stream(side):
+                y = torch.empty((N, H, W, Cout), dtype=ops.ACT, device=dev)
+                _lib.call("danhip_conv2d_fwd", ctypes.byref(d), _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b0), _lib.ptr(y), _lib.BF16, 1, None, _lib.stream())
+            dw1, db1 = run()
+            assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    finally:
+        L.danhip_set_option(b"wgrad_slab", 1)
+        L.danhip_set_option(b"wgrad_b2", 0)
+        torch.cuda.synchronize()

@@ -21,7 +21,7 @@ def test_gather_and_scatter_forms_of_the_deformable_backward_agree(sigma, dev):
         dx, doff = torch.empty_like(x), torch.empty_like(off)
         ws = torch.empty((x.numel() + 64,), dtype=torch.float32, device=dev)
         _lib.call("danhip_deform_sample_bwd", _lib.ptr(x), _lib.ptr(off), _lib.ptr(dS), _lib.ptr(dx), _lib.ptr(doff), N, H, W, C, 3, 3, 1, 1, dg, 0,
-                  _lib.ptr(ws), _lib.stream())
+                  _lib.ptr(ws), ws.numel() * 4, _lib.stream())
         torch.cuda.synchronize()
         return dx.float(), doff.float(), int(ws[-64:].view(torch.int32)[0].item())
 
@@ -58,7 +58,7 @@ def test_small_offsets_take_the_narrow_gather_window(dev):
             dx, doff = torch.empty_like(x), torch.empty_like(off)
             ws = torch.empty((x.numel() + 64,), dtype=torch.float32, device=dev)
             _lib.call("danhip_deform_sample_bwd", _lib.ptr(x), _lib.ptr(off), _lib.ptr(dS), _lib.ptr(dx), _lib.ptr(doff), N, H, W, C, 3, 3, 1, 1, dg, 0,
-                      _lib.ptr(ws), _lib.stream())
+                      _lib.ptr(ws), ws.numel() * 4, _lib.stream())
             torch.cuda.synchronize()
             outs.append((dx.clone(), doff.clone(), ws[-64:].view(torch.int32)[:2].tolist()))
     finally:

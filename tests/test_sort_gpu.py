@@ -36,6 +36,25 @@ def test_argsort_rejects_a_short_workspace_and_orders_infinities(dev):
         _lib.call("danhip_argsort_desc_f32", _lib.ptr(s), 5, 0, _lib.ptr(idx), _lib.ptr(ws), 64, _lib.stream())
 
 
+def test_nans_of_either_sign_sort_first_like_torch(dev):
+    """Diverged logits: torch.sort(descending=True) puts EVERY NaN first (stable among themselves); sign-bit NaNs used to land behind -inf
+    and 0xFFFFFFFF collided with the padding key."""
+    import struct
+    from dan_amd import ops
+    neg_nan = struct.unpack("f", struct.pack("I", 0xFFFFFFFF))[0]
+    neg_nan2 = struct.unpack("f", struct.pack("I", 0xFFC00001))[0]
+    for n in (9, 8200):
+        g = torch.Generator().manual_seed(n)
+        s = torch.rand((n,), generator=g) - 0.5
+        s[0], s[3], s[4], s[n - 1], s[n - 2] = neg_nan, float("nan"), float("inf"), neg_nan2, -float("inf")
+        s = s.to(dev)
+        want = torch.sort(s, descending=True, stable=True).indices
+        got = ops.argsort_desc(s)
+        assert torch.equal(got, want), (got[:6].tolist(), want[:6].tolist())
+        assert got[:3].tolist() == [0, 3, n - 1] and got[3].item() == 4 and got[-1].item() == n - 2
+        assert ops.argsort_desc(s, ties_high_index_first=True)[:3].tolist() == [n - 1, 3, 0]
+
+
 def test_sorted_candidates_feed_nms_like_before(dev):
     """sort_bboxes / nms_bboxes (bbox_util.py:61-91) on scores with ties: same selections as with torch's stable sort."""
     from dan_amd.utility import bbox_util as BU

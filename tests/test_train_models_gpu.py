@@ -108,8 +108,8 @@ def test_weight_gradient_stream_does_not_change_the_trajectory(dev, monkeypatch)
     anchors = AnchorConfig(160, 128, dev)
     loc_t, cls_t, _ = anchors.encode_batch(gts)
     runs = []
-    for on in ("1", "0"):
-        monkeypatch.setenv("DANHIP_WGRAD_STREAM", on)
+    for on in (True, False):
+        monkeypatch.setattr(ops, "WGRAD_STREAM", on)
         tr = SFDTrainer(SFDModel(device=dev, seed=6), world=1)
         tr.train_step(imgs, loc_t, cls_t)
         torch.cuda.synchronize()

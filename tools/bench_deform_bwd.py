@@ -12,7 +12,7 @@ dS = torch.randn((N * H * W, 9 * C), generator=g).to(torch.bfloat16).to(dev)
 dx = torch.empty_like(x); doff = torch.empty_like(off)
 ws = torch.empty((N * H * W * C + 64,), dtype=torch.float32, device=dev)
 def run():
-    call("danhip_deform_sample_bwd", ptr(x), ptr(off), ptr(dS), ptr(dx), ptr(doff), N, H, W, C, 3, 3, 1, 1, dg, 0, ptr(ws), stream())
+    call("danhip_deform_sample_bwd", ptr(x), ptr(off), ptr(dS), ptr(dx), ptr(doff), N, H, W, C, 3, 3, 1, 1, dg, 0, ptr(ws), ws.numel() * 4, stream())
 for _ in range(2): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -77,7 +77,14 @@ def main():
     import torch
     tmp = tempfile.mkdtemp()
     outs = {}
-    for arm, wire, port in (("fp32_a", "f32", 29711), ("fp32_b", "f32", 29712), ("bf16", "bf16", 29713)):
+    def free_port():                      # (as bench.py's spawn_ranks: never a fixed port another job on the box may hold)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            return so.getsockname()[1]
+
+    for arm, wire in (("fp32_a", "f32"), ("fp32_b", "f32"), ("bf16", "bf16")):
+        port = free_port()
         env = dict(os.environ, DANHIP_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                    DANHIP_DP_BUCKET_DTYPE=wire)
         env.pop("DANHIP_DIST_BACKEND", None)

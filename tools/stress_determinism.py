@@ -57,4 +57,46 @@ for name, N, H, W, Cin, Cout in SHAPES:
                 bad += 1
                 print("MISMATCH %s %s rep %d: %d elements differ" % (name, k, rep, int((t != ref[k]).sum().item())))
     print("%-8s %d repeats: forward and data gradient bit-identical" % (name, REPS) if not bad else "%s: %d mismatching runs so far" % (name, bad))
+
+# ---- the weight gradients (conv_wgrad_rows.hip for the 3x3 shapes, conv_wgrad_pw.hip for the 1x1 ones) in their atomic-free SLAB form
+# (wgrad_slab = 2: partial tiles as plain stores + a fixed-order combine pass), so dW / db are bit-reproducible: reference with the second
+# barrier per K-step (wgrad_b2 = 1), repeats in the default one-barrier form into a zeroed dw, with forward launches on a second stream
+WSHAPES = [("conv2_2", 16, 320, 320, 128, 128, 3), ("conv3_2", 16, 160, 160, 256, 256, 3), ("conv4_2", 16, 80, 80, 512, 512, 3), ("conv2_1", 16, 320, 320, 64, 128, 3),
+           ("lateral", 16, 160, 160, 256, 256, 1), ("up", 16, 80, 80, 512, 256, 1), ("deformK", 4, 160, 160, 2304, 256, 1)]
+lib().danhip_set_option(b"wgrad_slab", 2)
+try:
+    for name, N, H, W, Cin, Cout, k in WSHAPES:
+        g = torch.Generator(device="cpu").manual_seed(2)
+        x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+        dy = torch.randn((N, H, W, Cout), generator=g).to(ops.ACT).to(dev)
+        d = ops._desc(N, H, W, Cin, Cout, k, k, 1)
+        nws = lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
+        if not nws:
+            print("%-8s: the library offers no slab form for this shape - skipped" % name)
+            continue
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        w0 = (torch.randn((k, k, Cin, Cout), generator=g) / (k * k * Cin) ** 0.5).to(dev)
+        wf, _ = ops.pack_conv_weight(d, w0, need_bwd=False)
+        b0 = torch.zeros((Cout,), device=dev)
+        side = torch.cuda.Stream()
+        ref = None
+        for rep in range(REPS + 1):
+            lib().danhip_set_option(b"wgrad_b2", 1 if rep == 0 else 0)
+            if rep > 0:
+                with torch.cuda.stream(side):
+                    y = torch.empty((N, H, W, Cout), dtype=ops.ACT, device=dev)
+                    call("danhip_conv2d_fwd", ctypes.byref(d), ptr(x), ptr(wf), ptr(b0), ptr(y), BF16, 1, None, stream())
+            dw = torch.zeros((k, k, Cin, Cout), dtype=torch.float32, device=dev)
+            db = torch.zeros((Cout,), dtype=torch.float32, device=dev)
+            call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), Cin, ptr(ws), nws, stream())
+            torch.cuda.synchronize()
+            if rep == 0:
+                ref = (dw.clone(), db.clone())
+            elif not (torch.equal(dw, ref[0]) and torch.equal(db, ref[1])):
+                bad += 1
+                print("MISMATCH %s wgrad rep %d: %d / %d elements differ" % (name, rep, int((dw != ref[0]).sum().item()), int((db != ref[1]).sum().item())))
+        print("%-8s %d repeats: weight + bias gradient (slab form) bit-identical" % (name, REPS) if not bad else "%s: %d mismatching runs so far" % (name, bad))
+finally:
+    lib().danhip_set_option(b"wgrad_slab", 1)
+    lib().danhip_set_option(b"wgrad_b2", 0)
 sys.exit(1 if bad else 0)
