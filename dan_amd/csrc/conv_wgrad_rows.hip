@@ -48,7 +48,22 @@ struct WgRowsArgs {
 #ifdef WR_TRACE
   unsigned* trace;     // tools/halo2_trace.hip -DTRACE_WGRAD: [2 groups][128 K-steps][4 stamps] shader clocks of workgroup 0, waves 0 and 4
 #endif
+#ifdef WR_CLOCK
+  unsigned long long* clk;   // tools/clock_probe.hip: [blocks][8] = (s_memtime, s_memrealtime) at kernel entry / loop start / loop end / kernel end
+#endif
 };
+
+#ifdef WR_CLOCK
+#define WR_CLK(slot)                                                                                                   \
+  do {                                                                                                                 \
+    if (tid == 0) {                                                                                                    \
+      a.clk[(size_t)blockIdx.x * 8 + 2 * (slot)] = __builtin_amdgcn_s_memtime();                                       \
+      a.clk[(size_t)blockIdx.x * 8 + 2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();                               \
+    }                                                                                                                  \
+  } while (0)
+#else
+#define WR_CLK(slot) do { } while (0)
+#endif
 
 #ifdef WR_TRACE
 // all-scalar time stamp into LDS behind the two rings (the dynamic LDS segment starts at LDS address 0)
@@ -116,6 +131,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int wci = wave & 3;
   const int grp = wave >> 2;                          // phase group (0 = A, 1 = B) and co half
   const int wco = grp;
+  WR_CLK(0);                                          // (diagnostic build only; the store retires under the prologue's vmcnt(0))
 
   // ---- block -> (ci tile, co tile, split of the K-step stream); the (ci, co) pairs of one split read the same rows: same XCD
   const int pairs = a.ci_tiles * a.co_tiles;
@@ -297,6 +313,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     gen_next(s, 3); dma_step(std::integral_constant<int, 3>{}, s);
     static_assert(P == 4, "prologue issues P steps");
   }
+  WR_CLK(1);
   wr_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -368,6 +385,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   }
   wr_wait_vmcnt<0>();                                 // zero-fill pieces of the steps beyond the stream are still landing
+  WR_CLK(2);
 #ifdef WR_TRACE
   __syncthreads();
   if (blockIdx.x == 0)
@@ -379,6 +397,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int o = 0; o < NO; ++o) asm volatile("" ::"v"(acc[t][o]));
+    WR_CLK(3);
     return;
   }
   // ---- epilogue: lane holds dW[tap][ci = ci0 + wci*16 + g*4 + r][co = co0 + wco*NO*16 + o*16 + (lane & 15)]
@@ -396,6 +415,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int co = co0 + wco * NO * 16 + wci * 16 + (lane & 15);
       if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, accb[0]);
     }
+    WR_CLK(3);
     return;
   }
 #pragma unroll
@@ -414,6 +434,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int co = co0 + wco * NO * 16 + wci * 16 + (lane & 15);
     if (lane < 16 && co < a.Cout) atomicAdd(a.db + co, accb[0]);
   }
+#ifdef WR_CLOCK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's atomics have been accepted by the memory system when the end stamp is taken
+  WR_CLK(3);
+#endif
 }
 
 // Second pass of the slab form: a 256-thread workgroup owns 64 consecutive float4 slots of one (ci, co) tile; wave w sums the splits
@@ -457,6 +481,16 @@ __global__ __launch_bounds__(256) void wg_rows_reduce_kernel(const WgRowsArgs a)
     if (ci < a.cin_real) a.dw[(size_t)(t * a.cin_real + ci) * a.Cout + co] += sum[r];
   }
 }
+
+#ifdef WR_CLOCK
+static int g_wr_clock_blocks = 0, g_wr_clock_steps = 0;
+unsigned long long* wr_clock_buffer() {
+  static unsigned long long* p = [] { void* q = nullptr; (void)hipMalloc(&q, 4096 * 64); (void)hipMemset(q, 0, 4096 * 64); return (unsigned long long*)q; }();
+  return p;
+}
+int wr_clock_blocks() { return g_wr_clock_blocks; }
+int wr_clock_steps() { return g_wr_clock_steps; }
+#endif
 
 #ifdef WR_TRACE
 unsigned* wr_trace_buffer() {
@@ -506,6 +540,11 @@ int launch_wg_rows(WgRowsArgs& a, hipStream_t s) {
   // extra pass costs more than it saves (batch 16: conv3_2 0.426 against 0.428 ms, conv2_2 0.479 against 0.455; profiles/r3).
   const int slab_mode = danhip_option("wgrad_slab");
   if (a.slab && (splits < 2 || (slab_mode != 2 && a.rows_per_split > 192))) a.slab = nullptr;
+#ifdef WR_CLOCK
+  a.clk = wr_clock_buffer();
+  g_wr_clock_blocks = pairs * splits;
+  g_wr_clock_steps = a.rows_per_split;
+#endif
   hipLaunchKernelGGL((conv_wgrad_rows_kernel<COT>), dim3(pairs * splits), dim3(512), LDS, s, a);
   DH_LAUNCH_CHECK();
   if (a.slab) {

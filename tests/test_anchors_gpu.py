@@ -78,6 +78,13 @@ def test_small_mining_match_kats_and_ties(dev):
         i, s = AM.small_mining_match(torch.from_numpy(ov).to(dev), *args)
         assert i.cpu().tolist() == [4, 2, 1, 3, 3]
         assert np.array_equal(s.cpu().numpy(), np.array([0.7, 0.76, 0.94, 0.42, 0.42], np.float32))
+    # the hand-traced phase-3 KAT (kats.json "small_mining_match_phase3": equal IoUs in the heap, min_match binding, a stolen candidate)
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))["small_mining_match_phase3"]
+    i, s = AM.small_mining_match(torch.tensor(k["overlaps"], dtype=torch.float32, device=dev), *k["call"])
+    assert i.cpu().tolist() == k["match_indices"]
+    assert np.array_equal(s.cpu().numpy(), np.asarray(k["match_scores"], np.float32))
     rng = np.random.RandomState(11)
     for trial in range(12):
         A, G = int(rng.randint(50, 3000)), int(rng.randint(1, 30))

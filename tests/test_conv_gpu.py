@@ -736,7 +736,7 @@ def test_one_barrier_per_step_is_bit_identical_to_the_two_barrier_form(N, H, W, 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(4, 160, 160, 128, 256, 3), (2, 96, 128, 256, 256, 3), (4, 160, 160, 256, 256, 1), (2, 80, 80, 2304, 256, 1)])
 def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H, W, Cin, Cout, k, dev):
     """the default one-barrier K-step of conv_wgrad_rows.hip (3x3) / conv_wgrad_pw.hip (1x1) had no bit-identity check.  With
-    `wgrad_slab = 2` the partial tiles leave as plain stores and are combined in a fixed order (no atomics), so dW / db must be bit-identical
+    `wgrad_slab = 2` the partial tiles leave as plain stores and are combined in a fixed order (no atomics), so dW must be bit-identical (db: fp32 atomics, equal up to order)
     between the two-barrier form (`wgrad_b2 = 1`) and repeated one-barrier runs, also while another stream keeps the chip busy."""
     import ctypes
     from dan_amd import _lib, ops
@@ -771,7 +771,9 @@ def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H
                 y = torch.empty((N, H, W, Cout), dtype=ops.ACT, device=dev)
                 _lib.call("danhip_conv2d_fwd", ctypes.byref(d), _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b0), _lib.ptr(y), _lib.BF16, 1, None, _lib.stream())
             dw1, db1 = run()
-            assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+            assert torch.equal(dw1, dw2)
+            # (the bias gradient stays a handful of fp32 atomics per channel in both forms: equal up to summation order)
+            assert (db1 - db2).abs().max().item() <= 1e-5 * db2.abs().max().item()
     finally:
         L.danhip_set_option(b"wgrad_slab", 1)
         L.danhip_set_option(b"wgrad_b2", 0)

@@ -24,6 +24,32 @@ def test_small_mining_match_kat():
         assert np.allclose(s, np.asarray(k["match_scores"], np.float32), rtol=0, atol=0)
 
 
+def test_small_mining_match_phase3_kat():
+    """Hard-face compensation with a non-empty heap, equal IoUs and min_match binding (small_mining_match.cc:199-222): the answer was traced
+    by hand through libstdc++'s push_heap / adjust_heap (kats.json "_trace"), independently of oracle/extra_lib.cpp."""
+    k = KATS["small_mining_match_phase3"]
+    i, s = OE.small_mining_match(np.asarray(k["overlaps"], np.float32), *k["call"])
+    assert i.tolist() == k["match_indices"]
+    assert np.array_equal(s, np.asarray(k["match_scores"], np.float32))
+    assert k["overlaps"][1][0] == k["overlaps"][3][0] == k["overlaps"][4][0] and i[1] == 0 and i[3] == 0 and i[4] == -2    # the equal-IoU trio
+
+
+def test_routing_train_kat():
+    """Train-mode routing with a supplied uniform stream, traced by hand from dynamic_anchor_routing.cc:203-327 (kats.json "_trace")."""
+    k = KATS["routing_train"]
+    a = lambda key, dt: np.asarray(k[key], dt)
+    m, d = OE.dynamic_anchor_routing(a("anchors", np.float32), a("gt", np.float32), a("labels", np.float32), a("mask_in", np.int32), k["feat"][0],
+                                     k["feat"][1], k["depth"], k["stride"], 8, 12, True, k["thres"], k["ignore_thres"], u=a("u", np.float64))
+    assert m.tolist() == k["mask_out"]
+    assert np.allclose(d, a("decode_out", np.float32), rtol=3e-7, atol=0)
+    # the library's counter-based stream at the recorded (seed, counter0) takes the same accept / reject decisions (the GPU KAT relies on it)
+    u = OE.uniform_stream(k["stream"]["seed"], k["stream"]["counter0"], 6)
+    assert u[0] <= 0.5 and u[1] <= 1.0 / 3 and u[2] > 0.5 and u[4] <= 0.5
+    m2, d2 = OE.dynamic_anchor_routing(a("anchors", np.float32), a("gt", np.float32), a("labels", np.float32), a("mask_in", np.int32), k["feat"][0],
+                                       k["feat"][1], k["depth"], k["stride"], 8, 12, True, k["thres"], k["ignore_thres"], u=u)
+    assert np.array_equal(m2, m) and np.array_equal(d2, d)
+
+
 def test_routing_eval_kat():
     k = KATS["routing_eval"]
     m, d = OE.dynamic_anchor_routing(np.asarray(k["anchors"], np.float32), np.zeros((4, 4), np.float32), np.asarray(k["labels"], np.float32),

@@ -43,6 +43,19 @@ def test_routing_eval_kat(dev):
     assert do.cpu().tolist() == k["decode_out"]
 
 
+def test_routing_train_kat(dev):
+    """The hand-traced train-mode KAT (dynamic_anchor_routing.cc:203-327; kats.json "routing_train") on the HIP kernels: the library draws
+    from its counter-based stream, and the recorded (seed, counter0) takes the traced accept / reject decisions (tests/test_oracle_cpu.py)."""
+    from dan_amd.utility import custom_op
+    k = KATS["routing_train"]
+    t = lambda key, dt: torch.tensor(k[key], dtype=dt, device=dev)
+    mo, do = custom_op.dynamic_anchor_routing(t("anchors", torch.float32), t("gt", torch.float32), t("labels", torch.float32), t("mask_in", torch.int32),
+                                              k["feat"][0], k["feat"][1], k["depth"], k["stride"], 8, 12, True, k["thres"], k["ignore_thres"],
+                                              seed=k["stream"]["seed"], counter0=k["stream"]["counter0"])
+    assert mo.cpu().tolist() == k["mask_out"]
+    assert np.allclose(do.cpu().numpy(), np.asarray(k["decode_out"], np.float32), rtol=3e-7, atol=0)      # log() from the device libm
+
+
 @pytest.mark.parametrize("seed,fh,fw,depth,stride", [(0, 8, 8, 1, 4), (1, 16, 12, 1, 8), (2, 5, 7, 2, 16), (3, 40, 40, 1, 4), (5, 3, 3, 3, 32)])
 def test_routing_eval_matches_oracle(seed, fh, fw, depth, stride, dev):
     from dan_amd.utility import custom_op

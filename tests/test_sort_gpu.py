@@ -37,19 +37,20 @@ def test_argsort_rejects_a_short_workspace_and_orders_infinities(dev):
 
 
 def test_nans_of_either_sign_sort_first_like_torch(dev):
-    """Diverged logits: torch.sort(descending=True) puts EVERY NaN first (stable among themselves); sign-bit NaNs used to land behind -inf
-    and 0xFFFFFFFF collided with the padding key."""
-    import struct
+    """Diverged logits: torch.sort(descending=True) on the CPU and numpy's argsort()[::-1] (eval_dan.py:255) put EVERY NaN first (stable among
+    themselves); sign-bit NaNs used to land behind -inf and 0xFFFFFFFF collided with the padding key.  The reference here is the
+    CPU sort: torch's own stable GPU sort on this ROCm build orders sign-bit NaNs by their bits, i.e. after -inf."""
     from dan_amd import ops
-    neg_nan = struct.unpack("f", struct.pack("I", 0xFFFFFFFF))[0]
-    neg_nan2 = struct.unpack("f", struct.pack("I", 0xFFC00001))[0]
     for n in (9, 8200):
         g = torch.Generator().manual_seed(n)
         s = torch.rand((n,), generator=g) - 0.5
-        s[0], s[3], s[4], s[n - 1], s[n - 2] = neg_nan, float("nan"), float("inf"), neg_nan2, -float("inf")
+        import numpy as np
+        a = s.numpy().view(np.uint32)
+        a[0], a[n - 1] = 0xFFFFFFFF, 0xFFC00001                       # sign-bit NaNs with payloads (a Python float would lose them)
+        s[3], s[4], s[n - 2] = float("nan"), float("inf"), -float("inf")
+        want = torch.sort(s, descending=True, stable=True).indices    # CPU
         s = s.to(dev)
-        want = torch.sort(s, descending=True, stable=True).indices
-        got = ops.argsort_desc(s)
+        got = ops.argsort_desc(s).cpu()
         assert torch.equal(got, want), (got[:6].tolist(), want[:6].tolist())
         assert got[:3].tolist() == [0, 3, n - 1] and got[3].item() == 4 and got[-1].item() == n - 2
         assert ops.argsort_desc(s, ties_high_index_first=True)[:3].tolist() == [n - 1, 3, 0]

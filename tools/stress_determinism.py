@@ -92,10 +92,10 @@ try:
             torch.cuda.synchronize()
             if rep == 0:
                 ref = (dw.clone(), db.clone())
-            elif not (torch.equal(dw, ref[0]) and torch.equal(db, ref[1])):
-                bad += 1
-                print("MISMATCH %s wgrad rep %d: %d / %d elements differ" % (name, rep, int((dw != ref[0]).sum().item()), int((db != ref[1]).sum().item())))
-        print("%-8s %d repeats: weight + bias gradient (slab form) bit-identical" % (name, REPS) if not bad else "%s: %d mismatching runs so far" % (name, bad))
+            elif not torch.equal(dw, ref[0]) or (db - ref[1]).abs().max().item() > 1e-5 * ref[1].abs().max().item():
+                bad += 1          # (db stays a few fp32 atomics per channel in both forms: compared up to summation order)
+                print("MISMATCH %s wgrad rep %d: %d dW elements differ, db max |diff| %.3g" % (name, rep, int((dw != ref[0]).sum().item()), (db - ref[1]).abs().max().item()))
+        print("%-8s %d repeats: weight gradient (slab form) bit-identical" % (name, REPS) if not bad else "%s: %d mismatching runs so far" % (name, bad))
 finally:
     lib().danhip_set_option(b"wgrad_slab", 1)
     lib().danhip_set_option(b"wgrad_b2", 0)
