@@ -37,6 +37,52 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_debug_setup(rank):
+    """Multi-rank runs describe their own collectives: before the process group exists, point RCCL's INFO log (INIT + TUNING subsystems:
+    communicator shape and the algorithm / protocol chosen per collective size) at a per-rank file.  Defaults only - a caller's own
+    NCCL_DEBUG* settings win.  Returns the file rank 0 parses after the run (rccl_debug_parse), or None."""
+    import tempfile
+    if "NCCL_DEBUG_FILE" in os.environ:
+        return os.environ["NCCL_DEBUG_FILE"].replace("%h", "host").replace("%p", str(os.getpid()))
+    if "NCCL_DEBUG" in os.environ and os.environ["NCCL_DEBUG"].upper() not in ("INFO", "TRACE"):
+        return None
+    path = os.path.join(tempfile.gettempdir(), "danhip_rccl_%d_%d.log" % (os.getpid(), rank))
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def rccl_debug_parse(text):
+    """-> {"nranks", "nnodes", "channels", "algo": {...}, "proto": {...}, "transport": [...], "version"} from an RCCL / NCCL INFO log; every field
+    is best effort (None / empty when the log has no such line: e.g. a one-rank group never tunes a collective)."""
+    import re
+    out = {"version": None, "nranks": None, "nnodes": None, "channels": None, "algo": {}, "proto": {}, "transport": []}
+    m = re.search(r"(?:RCCL|NCCL) version ([0-9][^\s]*)", text)
+    if m:
+        out["version"] = m.group(1)
+    m = re.search(r"nranks (\d+)", text) or re.search(r"nRanks (\d+)", text)
+    if m:
+        out["nranks"] = int(m.group(1))
+    m = re.search(r"nNodes (\d+)", text) or re.search(r"nnodes (\d+)", text, re.I)
+    if m:
+        out["nnodes"] = int(m.group(1))
+    m = re.search(r"(\d+) coll channels", text) or re.search(r"Channel \d+/(\d+)", text)
+    if m:
+        out["channels"] = int(m.group(1))
+    algo_names = {"0": "Tree", "1": "Ring", "2": "CollNetDirect", "3": "CollNetChain", "4": "NVLS", "5": "NVLSTree"}
+    proto_names = {"0": "LL", "1": "LL128", "2": "Simple"}
+    # "AllReduce: 33554432 Bytes -> Algo 1 proto 2 time 123.4"  (TUNING subsystem)
+    for coll, nbytes, al, pr in re.findall(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", text):
+        key = "%s/%dMiB" % (coll, int(nbytes) >> 20) if int(nbytes) >= (1 << 20) else "%s/%dB" % (coll, int(nbytes))
+        out["algo"][key] = algo_names.get(al, al)
+        out["proto"][key] = proto_names.get(pr, pr)
+    for t in re.findall(r"via ((?:P2P|SHM|NET)[/\w]*)", text):
+        if t not in out["transport"]:
+            out["transport"].append(t)
+    return out
+
+
 def csrc_hash():
     """sha256 over the kernel sources (the stamp tools/pmc_traffic.py writes into the PMC traffic file)."""
     import glob
@@ -138,6 +184,9 @@ def main():
     from dan_amd.trainer import init_distributed
     from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
 
+    rccl_log = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("DANHIP_FORCE_DIST") == "1") and os.environ.get("DANHIP_BENCH_DRY") != "1":
+        rccl_log = rccl_debug_setup(int(os.environ.get("RANK", "0")))         # (before the communicator is created: RCCL reads these at init)
     rank, world, local = init_distributed()
     if os.environ.get("DANHIP_BENCH_DRY") == "1":      # tests/test_abi_cpu.py: the launch plumbing alone (no GPU): ranks rendezvous, rank 0 reports
         n = dist.get_world_size() if dist.is_initialized() else 1
@@ -238,10 +287,24 @@ def main():
         prof_serial, ops.PROFILE = ops.PROFILE, None
         trainer._graph = saved_graph
         ops.WGRAD_STREAM = True
+    # What the per-launch HIP events of the timed region cost: the same K steps again with NO event recorded, same
+    # barriers.  Reported beside `value` (which stays the region the roofline events were taken in); every rank runs it.
+    dt_noev = None
+    if prof is not None and not args.graph:
+        for _ in range(2):
+            trainer.train_step(*step_args)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(*step_args)
+        barrier()
+        dt_noev = time.perf_counter() - t1
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_noev if dt_noev is not None else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        if dt_noev is not None:
+            dt_noev = float(t[1].item())
 
     # ---- inference leg ("eval FPS"): eval_sfd.py / eval_dan.py single-scale graph (forward + softmax + decode [+ routing]) on the same
     # resident images, outside the timed training region; every rank runs it, the slowest rank's time counts
@@ -291,6 +354,13 @@ def main():
             enc_out = {"value": round(B / et, 1), "unit": "images/sec", "ms_per_batch": round(et * 1e3, 3), "gt_boxes_in_batch": int(sum(g.shape[0] for g in gts)),
                        "what": "IoU + small-mining match + target encode for the batch, one call (danhip_encode_anchors_batched), bit-exact index work"}
 
+    rccl_info = None
+    if rank == 0 and multi and rccl_log and os.path.exists(rccl_log):
+        try:
+            rccl_info = rccl_debug_parse(open(rccl_log, errors="replace").read())
+            rccl_info["bucket_bytes"] = int(getattr(trainer.buckets, "bucket_bytes", 0)) or None
+        except Exception as ex:                                    # the log format is RCCL's business: never fail the bench over it
+            rccl_info = {"error": repr(ex)}
     if rank == 0:
         lv = trainer.loss_values()
         first = [k for k in lv if k not in ("l2", "total")][0]
@@ -308,7 +378,9 @@ def main():
         # happen inside this process).  The file is stamped with the hash of the kernel sources it was measured on: with other sources
         # the numbers describe another binary and `traffic` is null (the stale figure is reported beside it, flagged).
         traffic, traffic_stale, pmc = None, None, {}
-        tj = os.path.join(ROOT, "profiles", "r3", "pmc_bench_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r4", "pmc_bench_traffic.json")
+        if not os.path.exists(tj):
+            tj = os.path.join(ROOT, "profiles", "r3", "pmc_bench_traffic.json")
         if os.path.exists(tj):
             pmc = json.load(open(tj))
             t = pmc.get(label)
@@ -316,7 +388,7 @@ def main():
             if t and same:
                 traffic = round(t["hbm_bytes_per_launch"])
             elif t:
-                traffic_stale = {"bytes": round(t["hbm_bytes_per_launch"]), "why": "profiles/r3/pmc_bench_traffic.json was measured on other kernel sources"}
+                traffic_stale = {"bytes": round(t["hbm_bytes_per_launch"]), "why": os.path.relpath(tj, ROOT) + " was measured on other kernel sources"}
             if not same:
                 pmc = {}
         calib = None        # library-GEMM peak measured on a box of this pool (tools/calibrate_peaks.py), next to the datasheet peak
@@ -365,8 +437,12 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
                        "step_launch": "hipGraph replay" if args.graph else "eager",
                        "rccl_ranks": dist.get_world_size() if multi else 1,
+                       "rccl": rccl_info,
                        "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if multi else None,
                        "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and ops.WGRAD_STREAM)},
+            "event_recording": ({"ms_per_step_without_events": round(dt_noev / args.steps * 1e3, 3), "value_without_events": round(world * B * args.steps / dt_noev, 3),
+                                 "what": "the same K steps repeated after the timed region with no per-launch HIP event recorded; `value` / `ms_per_step` are the "
+                                         "region the roofline events were recorded in"} if dt_noev else None),
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],

@@ -42,6 +42,12 @@ class Detector(object):
         boxes, scores = self.model.predict(image.unsqueeze(0).contiguous(), a)
         return boxes[0], scores[0]
 
+    def batch(self, images):
+        """B images of one size in ONE forward pass: uint8 [B,H,W,3] -> (bboxes [B,A,4], scores [B,A])."""
+        assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
+        a = self.anchors(images.shape[1], images.shape[2], images.device)
+        return self.model.predict(images.contiguous(), a)
+
 
 def resize_image(image, fx, fy):
     """cv2.resize(image, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) (eval_dan.py:97)."""
@@ -56,13 +62,11 @@ def resize_image(image, fx, fy):
 def _order_desc(scores):
     """argsort()[::-1]; ties resolved as a stable ascending sort read backwards (numpy's default sort leaves it open): libdanhip's
     arg-sort with ties_high_index_first.  The detections are fp32 (or fp32 values held in float64: bbox_vote's input); a caller that
-    passes scores an fp32 cannot hold keeps torch's sort."""
+    passes scores an fp32 cannot hold gets them rounded to fp32 first."""
     if scores.dtype != torch.float32:
-        s32 = scores.to(torch.float32)
-        if not bool((s32.to(scores.dtype) == scores).all()):
-            n = scores.shape[0]
-            return (n - 1) - torch.sort(scores.flip(0), descending=True, stable=True).indices
-        scores = s32
+        # every score of this pipeline is an fp32 softmax output (detect_face), at most carried in a float64 container (flip_test,
+        # bbox_vote's input): the cast back is exact, and no host round trip checks it (ADVICE r3)
+        scores = scores.to(torch.float32)
     return ops.argsort_desc(scores.contiguous(), ties_high_index_first=True)
 
 
@@ -188,6 +192,99 @@ def write_to_txt(f, det, event, im_name, select_threshold=SELECT_THRESHOLD):
     for i in range(valid.shape[0]):
         if valid[i]:
             f.write('{:.1f} {:.1f} {:.1f} {:.1f} {:.3f}\n'.format(np.floor(xmin[i]), np.floor(ymin[i]), np.ceil(bw[i]), np.ceil(bh[i]), sc[i]))
+
+
+# ---- the same pipeline for B images of ONE size, without a host round trip.  get_shrink and the scale lists of
+# multi_scale_test / multi_scale_test_pyramid depend on the image SIZE only, so every pass of eval_dan.py:452-459 runs as one batched
+# forward; the size filters (eval_dan.py:126,147-148,153,160-170) become validity masks over fixed-size [B, top] blocks instead of
+# boolean compactions (whose output shape the host would have to read), and the voting kernel takes the per-image counts from the device.
+def resize_images(images, fx, fy):
+    B, H, W, C = images.shape
+    Wo, Ho = int(np.rint(W * fx)), int(np.rint(H * fy))
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=images.device)
+    images = images.contiguous()
+    for b in range(B):
+        call("danhip_resize_u8_linear", ptr(images[b]), H, W, ptr(out[b]), Ho, Wo, C, float(fx), float(fy), stream())
+    return out
+
+
+def detect_face_batch(net, images, shrink, max_per_image=MAX_PER_IMAGE):
+    """detect_face for [B,H,W,3] -> det fp32 [B, top, 5], rows ordered as eval_dan.py:115-116 orders them."""
+    if shrink != 1:
+        images = resize_images(images, shrink, shrink)
+    bboxes, scores = net.batch(images)
+    s = torch.tensor(float(shrink), dtype=torch.float32, device=bboxes.device)
+    det = torch.stack((bboxes[..., 1] / s, bboxes[..., 0] / s, bboxes[..., 3] / s, bboxes[..., 2] / s, scores.to(torch.float32)), dim=2)
+    top = min(det.shape[1] - 1, int(max_per_image * 1.5))
+    order = torch.stack([_order_desc(det[b, :, 4])[:top] for b in range(det.shape[0])])
+    return torch.gather(det, 1, order.unsqueeze(2).expand(-1, -1, 5))
+
+
+def _big_mask(det):
+    return torch.maximum(det[..., 2] - det[..., 0] + 1, det[..., 3] - det[..., 1] + 1) > 30
+
+
+def _small_mask(det):
+    return torch.minimum(det[..., 2] - det[..., 0] + 1, det[..., 3] - det[..., 1] + 1) < 100
+
+
+def detect_images(net, images, pyramid=True, nms_threshold=NMS_THRESHOLD, max_per_image=MAX_PER_IMAGE):
+    """detect_image for a batch: uint8 [B,H,W,3] -> (dets fp32 [B, max_per_image, 5], num int32 [B]) on the device; rows beyond num[b]
+    are unspecified.  Per image the result equals detect_image(net, images[b], pyramid) whenever the forward passes agree (a batched
+    forward may take another split-K plan than a single image: same math, another fp32 summation order)."""
+    B, H, W, _ = images.shape
+    shrink, max_shrink = get_shrink(H, W)
+    parts = []                                             # (det [B, k, 5] float64, valid [B, k])
+    def add(det, mask=None):
+        parts.append((det.to(torch.float64), torch.ones(det.shape[:2], dtype=torch.bool, device=det.device) if mask is None else mask))
+    add(detect_face_batch(net, images, shrink))
+    # flip_test (eval_dan.py:188-199)
+    det_f = detect_face_batch(net, images.flip(2).contiguous(), shrink)
+    w = torch.tensor(float(W), dtype=torch.float32, device=det_f.device)
+    det_t = torch.empty(det_f.shape, dtype=torch.float64, device=det_f.device)
+    det_t[..., 0] = (w - det_f[..., 2]) - 1
+    det_t[..., 1] = det_f[..., 1]
+    det_t[..., 2] = (w - det_f[..., 0]) - 1
+    det_t[..., 3] = det_f[..., 3]
+    det_t[..., 4] = det_f[..., 4]
+    add(det_t)
+    # multi_scale_test (eval_dan.py:121-148)
+    st = 0.5 if max_shrink >= 0.75 else 0.5 * max_shrink
+    d = detect_face_batch(net, images, st)
+    add(d, _big_mask(d))
+    bt = min(2, max_shrink) if max_shrink > 1 else (st + max_shrink) / 2
+    bs = [detect_face_batch(net, images, bt)]
+    if max_shrink > 2:
+        bt *= 2
+        while bt < max_shrink:
+            bs.append(detect_face_batch(net, images, bt))
+            bt *= 2
+        bs.append(detect_face_batch(net, images, max_shrink))
+    for d in bs:
+        add(d, _small_mask(d) if bt > 1 else _big_mask(d))
+    # multi_scale_test_pyramid (eval_dan.py:151-175)
+    if pyramid:
+        d = detect_face_batch(net, images, 0.25)
+        add(d, _big_mask(d))
+        for sc in (0.75, 1.25, 1.5, 1.75):
+            if sc <= max_shrink:
+                d = detect_face_batch(net, images, sc)
+                add(d, _small_mask(d) if sc > 1 else _big_mask(d))
+    det = torch.cat([p[0] for p in parts], dim=1)
+    valid = torch.cat([p[1] for p in parts], dim=1)
+    n = det.shape[1]
+    # voting input: the valid rows in descending score order (ties: higher index first, as np.argsort()[::-1]); invalid rows carry -inf
+    # and fall behind every real score (scores are softmax outputs >= 0), and the relative index order of the valid rows is the order of
+    # the serial concatenation, so ties resolve alike
+    key = torch.where(valid, det[..., 4].to(torch.float32), torch.full((), float("-inf"), dtype=torch.float32, device=det.device))
+    order = torch.stack([ops.argsort_desc(key[b].contiguous(), ties_high_index_first=True) for b in range(B)])
+    packed = torch.gather(det, 1, order.unsqueeze(2).expand(-1, -1, 5)).contiguous()
+    counts = valid.sum(dim=1).to(torch.int32)
+    out = torch.empty((B, max_per_image, 5), dtype=torch.float32, device=det.device)
+    num = torch.empty((B,), dtype=torch.int32, device=det.device)
+    ws = torch.empty((lib().danhip_bbox_vote_workspace_bytes(B, n),), dtype=torch.uint8, device=det.device)
+    call("danhip_bbox_vote", ptr(packed), ptr(counts), B, n, float(nms_threshold), int(max_per_image), ptr(out), ptr(num), ptr(ws), ws.numel(), stream())
+    return out, num
 
 
 def detect_image(net, image, pyramid=True):

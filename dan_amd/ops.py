@@ -713,6 +713,8 @@ class _DetectionLoss(torch.autograd.Function):
         acc = torch.empty((4,), dtype=torch.float32, device=dev)
         call("danhip_hard_neg_select", ptr(cls), ptr(labels), ptr(score), ptr(counts), ptr(thr), ptr(k), B, A, float(ratio), int(at_least_one), stream())
         call("danhip_detection_loss_fwd", ptr(cls), ptr(loc), ptr(labels), ptr(loc_t), ptr(score), ptr(thr), ptr(sel), ptr(acc), B, A, stream())
+        if TRACE is not None:                           # tests: the hard-negative selection of this term (call order), imposed on the oracle's loss
+            TRACE.setdefault("loss_sel", []).append(sel)
         ctx.save_for_backward(cls, loc, loc_t, sel, acc)
         ctx.cfg = (ratio, scale)
         ctx.aux = (score, thr, k, counts)

@@ -131,6 +131,7 @@ class GradBuckets(object):
         # DANHIP_FAKE_ALLREDUCE=1 (diagnosis, single process): run the bucket machinery with a device-only stand-in for the collective
         self.fake = (not self.enabled) and os.environ.get("DANHIP_FAKE_ALLREDUCE") == "1" and flat.g.is_cuda
         self.enabled = self.enabled or self.fake
+        self.bucket_bytes = bucket_bytes
         per = max(1, bucket_bytes // 4)
         self.bounds = []
         end = flat.total

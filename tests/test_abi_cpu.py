@@ -248,3 +248,29 @@ def test_four_gib_activations_are_refused_not_wrapped():
     d.N = 8                                          # the BASELINE per-GPU shard (batch 8 at 1024 x 1024) is 2 GiB: accepted by the check
     r, c = ctypes.c_int64(), ctypes.c_int64()
     assert L.danhip_conv_packed_dims(ctypes.byref(d), 0, ctypes.byref(r), ctypes.byref(c)) == 0
+
+
+def test_bench_parses_an_rccl_info_log():
+    """bench.py --gpus N describes its own collectives: rank 0 parses the RCCL INFO log of the run.  The parser is fed
+    the line shapes RCCL / NCCL print (INIT: version / rank / nranks / channels; TUNING: algorithm and protocol per collective size; GRAPH:
+    transports); missing lines leave fields empty rather than failing."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    log = """
+box:123:123 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abcdef
+box:123:140 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 nvmlDev 0 busId c000 commId 0x1 - Init START
+box:123:140 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7
+box:123:140 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via P2P/IPC
+box:123:140 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer
+box:123:140 [0] NCCL INFO AllReduce: 33554432 Bytes -> Algo 1 proto 2 time 412.5
+box:123:140 [0] NCCL INFO AllReduce: 4096 Bytes -> Algo 0 proto 0 time 9.1
+"""
+    info = b.rccl_debug_parse(log)
+    assert info["version"].startswith("2.22") and info["nranks"] == 8 and info["channels"] == 16
+    assert info["algo"]["AllReduce/32MiB"] == "Ring" and info["proto"]["AllReduce/32MiB"] == "Simple"
+    assert info["algo"]["AllReduce/4096B"] == "Tree" and info["proto"]["AllReduce/4096B"] == "LL"
+    assert info["transport"] == ["P2P/IPC"]
+    empty = b.rccl_debug_parse("nothing here")
+    assert empty["nranks"] is None and empty["algo"] == {}

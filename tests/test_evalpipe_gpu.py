@@ -141,3 +141,48 @@ def test_detect_image_real_network_odd_size(model, dev):
     k = int(torch.argmax(s))
     if int((s == s.max()).sum()) == 1:
         assert torch.equal(got[0, :4], torch.stack((b[k, 1], b[k, 0], b[k, 3], b[k, 2])) / torch.tensor(0.5, device=dev))
+
+
+class _FakeBatchNet(object):
+    """The deterministic stand-in as a `net` with the Detector's two entry points: per image, or B images of one size in one call."""
+
+    def __call__(self, image):
+        return _fake_net_torch(image)
+
+    def batch(self, images):
+        outs = [_fake_net_torch(images[b]) for b in range(images.shape[0])]
+        return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
+
+
+@pytest.mark.parametrize("h,w,pyramid", [(240, 320, True), (400, 300, False), (683, 1024, True)])
+def test_batched_pipeline_equals_the_per_image_pipeline(h, w, pyramid, dev):
+    """detect_images (all scales of B images without a host round trip, size filters as validity masks, ONE voting launch
+    with device-side counts) against detect_image per image, bit for bit, with identical raw detections on both sides."""
+    from dan_amd import eval_dan as P
+    rng = np.random.RandomState(h * 3 + w)
+    imgs = torch.from_numpy(rng.randint(0, 256, (3, h, w, 3)).astype(np.uint8)).to(dev)
+    net = _FakeBatchNet()
+    out, num = P.detect_images(net, imgs, pyramid=pyramid)
+    assert out.shape == (3, P.MAX_PER_IMAGE, 5) and num.dtype == torch.int32
+    for b in range(3):
+        ref = P.detect_image(net, imgs[b], pyramid=pyramid)
+        n = int(num[b].item())
+        assert n == ref.shape[0] and n > 5
+        assert torch.equal(out[b, :n], ref)
+
+
+def test_batched_pipeline_real_network(dev):
+    """The same on the real S3FD graph: a batch of ONE runs the same forward shapes as the serial path (bit-identical); a batch of three
+    gives finite, score-ordered detections for every image."""
+    from dan_amd import eval_dan as P
+    from dan_amd import train_sfd
+    rng = np.random.RandomState(9)
+    imgs = torch.from_numpy(rng.randint(0, 256, (3, 203, 331, 3)).astype(np.uint8)).to(dev)
+    net = P.Detector(train_sfd.SFDModel(device=dev), lambda h, w, d: train_sfd.AnchorConfig(h, w, d))
+    out1, num1 = P.detect_images(net, imgs[:1], pyramid=False)
+    ref = P.detect_image(net, imgs[0], pyramid=False)
+    assert int(num1[0].item()) == ref.shape[0] and torch.equal(out1[0, :ref.shape[0]], ref)
+    out, num = P.detect_images(net, imgs, pyramid=False)
+    for b in range(3):
+        d = out[b, :int(num[b].item())].cpu().numpy()
+        assert d.shape[0] > 0 and np.isfinite(d).all() and (d[:, 4] >= 0).all() and (d[:, 4] <= 1).all()

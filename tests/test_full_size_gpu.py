@@ -99,3 +99,14 @@ def test_s3fd_training_step_at_640(dev):
         if rel > 0.08 and want.abs().max().item() > 1e-6:
             bad.append((name, rel))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("which,size", [("pb", 640), ("dan", 1024)])
+def test_training_step_at_baseline_size_with_decisions_imposed(which, size, dev):
+    """the FULL training step - every loss term and every variable's gradient - at the input size BASELINE.json quotes
+    for the graph (PyramidBox configs[2]: 640 x 640; DAN configs[3]: 1024 x 1024; one image so the CPU oracle finishes in a minute), with the
+    HIP forward's discrete decisions imposed on the oracle (tests/gradcheck.py::train_step_case): loss terms 3 %, gradients 0.05 per
+    variable.  DAN-Deform at 1024 x 1024 runs in the fp16 build (tests/fp16/cases.py), the build configs[4] names."""
+    import gradcheck as GC
+    checked = GC.train_step_case(which, size, size, dev, torch.bfloat16)
+    assert checked > 100

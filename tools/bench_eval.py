@@ -25,3 +25,17 @@ for name, fn in (("eval_sfd.detect_image (origin + flip + multi-scale + vote)", 
         out = fn()
     torch.cuda.synchronize()
     print("%-60s %8.1f ms / image   (%d boxes out)" % (name, (time.perf_counter() - t0) / n * 1e3, len(out)))
+# the batched pipeline (eval_dan.detect_images: every scale of B same-size images as one forward pass, no host round trip until the end)
+for B in (1, 4, 8):
+    imgs = synthetic.make_images(B, 768, 1024, dev, seed=5)
+    fn = lambda: eval_dan.detect_images(net, imgs, pyramid=False)
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        out, num = fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("%-60s %8.1f ms / image   %7.1f images/s   (batch %d, %s boxes out)" % ("eval_dan.detect_images, same passes, batched", dt / B * 1e3, B / dt, B, num.tolist()))
