@@ -24,6 +24,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Ho", "Wo", "Cout", "kh", "kw", "stride")]
 
 
+class ConvPitch(ctypes.Structure):
+    """danhip_conv_pitch: pixel pitches (elements) of a call's input / output operand and of a data gradient's mask (channel-slice views)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("x_pitch", "y_pitch", "aux_pitch")]
+
+
 class PackEntry(ctypes.Structure):
     _fields_ = [("w_hwio", ctypes.c_void_p), ("wf_packed", ctypes.c_void_p), ("wb_packed", ctypes.c_void_p)] + \
                [(n, ctypes.c_int32) for n in ("kh", "kw", "cin", "cin_real", "cout", "rows_f", "cols_f", "rows_b", "cols_b", "co8", "first_block", "pad_")]
@@ -57,6 +62,13 @@ SIGNATURES = {
     "danhip_conv2d_fwd_relu_bits": [DESC, P, P, P, P, P, P, P, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
     "danhip_conv2d_bwd_weight_ws": [DESC, P, P, P, P, I32, P, ctypes.c_size_t, P],
+    "danhip_avgpool2x2s1_same_fwd_strided": [P, I32, P, I32, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_avgpool2x2s1_same_bwd_strided": [P, I32, P, I32, I32, I32, I32, I32, P],
+    "danhip_add16": [P, P, P, I64, P],
+    "danhip_residual_bwd": [P, P, P, P, P, ctypes.c_int, I64, P],
+    "danhip_conv2d_fwd_strided": [DESC, P, P, P, P, ctypes.c_int, I32, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
+    "danhip_conv2d_bwd_data_strided": [DESC, P, P, P, P, ctypes.c_int, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
+    "danhip_conv2d_bwd_weight_strided": [DESC, P, P, P, P, I32, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
     "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],

@@ -23,6 +23,13 @@ struct ConvArgs {
   float* splitk_ws;      // split-K (conv_igemm.hip, maps too small to fill the chip): fp32 partial outputs [splits][M][Co]; null = no split
   int splits, kt_per_split;
   int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
+  // Channel-slice views (round 4: the DAN context block writes its branches straight into the concat buffer and reads branch inputs
+  // out of a wider tensor): pixel pitches in ELEMENTS of x, y and of the mask tensor of a data gradient (a slice [.., c0:c0+C] of an NHWC
+  // tensor of width ld is its base pointer + c0 and pitch ld).  fwd_args / bwd_args set them to the dense values C / Co / Co; only
+  // conv_pointwise.hip and conv_igemm.hip (+ split-K finish) honour other values - strided() sends the call there.
+  int ldx, ldy, ldm;
+  int relu_co;   // forward: ReLU applies to output channels < relu_co only (fused 1x1 block whose last columns stay linear); default Co
+  bool strided() const { return ldx != C || ldy != Co || (mask && ldm != Co) || (relu && relu_co < Co); }
 };
 
 // true when launch_conv's kernel for these args writes a.pool_y itself (conv_halo_c64.hip / conv_halo.hip forward tiles)
@@ -104,7 +111,7 @@ const char* danhip_wgrad_rows_label(const danhip_conv_desc* d);
 // Pointwise (1x1 / stride 1) weight gradient, 256 x 256 gradient tile per workgroup (conv_wgrad_pw.hip); same return convention.
 const char* danhip_wgrad_pw_label(const danhip_conv_desc* d);
 int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
-                           void* ws = nullptr, size_t ws_bytes = 0);
+                           void* ws = nullptr, size_t ws_bytes = 0, int ldx = 0, int ldy = 0);      // ldx / ldy: pixel pitches (0 = dense)
 size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d);
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
                              void* ws = nullptr, size_t ws_bytes = 0);
@@ -113,13 +120,15 @@ size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d);
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
 __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {
   if (co >= a.Co) return;
-  const size_t o = m * (size_t)a.Co + co;
+  const size_t o = m * (size_t)a.ldy + co;          // output (pitched view: ldy elements per pixel)
+  const size_t om = m * (size_t)a.ldm + co;         // mask tensor of a data gradient
+  const size_t orr = m * (size_t)a.Co + co;         // residual: always dense
   const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
   if (a.bias) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) if (co + r < a.Co) v[r] += a.bias[co + r];
   }
-  if (a.relu) {
+  if (a.relu && co < a.relu_co) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
   }
@@ -137,13 +146,13 @@ __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_
     bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
     if (full) {
       if (a.mask) {
-        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + om);
         const bf16_t* mp = reinterpret_cast<const bf16_t*>(&mk);
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
       }
       if (a.resid) {
-        const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + o);
+        const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + orr);
         const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
@@ -163,8 +172,8 @@ __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_
       for (int r = 0; r < 4; ++r) {
         if (co + r < a.Co) {
           float t = v[r];
-          if (a.mask && !(bf2f(a.mask[o + r]) > 0.f)) t = 0.f;
-          if (a.resid) t += bf2f(a.resid[o + r]);
+          if (a.mask && !(bf2f(a.mask[om + r]) > 0.f)) t = 0.f;
+          if (a.resid) t += bf2f(a.resid[orr + r]);
           if (a.accumulate) t += bf2f(y[r]);
           y[r] = f2bf(t);
         }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   // — 4 VALU per row and tile instead of ~15 (64-bit address build + zero-page select).
   const bool lean = FAST && a.dstride == 1 && a.taps <= 32;
   const __amdgpu_buffer_rsrc_t rsrc_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)(((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + (unsigned)a.C) * 2u), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)((unsigned)(gridDim.y * BN) * (unsigned)a.Kpad * 2u), 0x00020000);
   unsigned pbase[RA];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   if (lean) {
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      pbase[j] = (unsigned)((rn[j] + rh[j] * a.W + rw[j]) * a.C + schunk * 8) * 2u;        // may wrap for padding rows; exact for valid taps
+      pbase[j] = (unsigned)((rn[j] + rh[j] * a.W + rw[j]) * a.ldx + schunk * 8) * 2u;        // may wrap for padding rows; exact for valid taps
       unsigned mk = 0;
       for (int t = 0; t < a.taps; ++t) {
         const int i = (int)fdiv((unsigned)t, a.div_kw), jj = t - i * a.kw;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     char* sA = smem + buf * STAGE;
     char* sB = sA + BM * 128;
     if (FAST && lean) {
-      const unsigned toff = (unsigned)((ti * a.W + tj) * a.C + c0) * 2u;                  // wave-uniform
+      const unsigned toff = (unsigned)((ti * a.W + tj) * a.ldx + c0) * 2u;                // wave-uniform
       const unsigned tbit = 1u << tap;
 #pragma unroll
       for (int j = 0; j < RA; ++j) {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           hi >>= a.dshift; wi >>= a.dshift;
         }
         ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + c0 + schunk * 8) : zero;
+        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.ldx + c0 + schunk * 8) : zero;
         glds16(src, sA + (j * 32 + wave * 8) * 128);
       }
     } else {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           hi >>= a.dshift; wi >>= a.dshift;
         }
         ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.C + cc) : zero;
+        const bf16_t* src = ok ? a.x + ((size_t)(rn[j] + hi * a.W + wi) * a.ldx + cc) : zero;
         glds16(src, sA + (j * 32 + wave * 8) * 128);
       }
     }
@@ -246,13 +246,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int co = n0 + wn * TC + c * 16 + fq * 4;
       if (co >= a.Co) continue;
       float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
-      const size_t o = (size_t)m * a.Co + co;
+      const size_t o = (size_t)m * a.ldy + co;          // (pitched views: conv_common.h ConvArgs::ldx / ldy / ldm)
+      const size_t om = (size_t)m * a.ldm + co, orr = (size_t)m * a.Co + co;
       const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
       if (a.bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (co + r < a.Co) v[r] += a.bias[co + r];
       }
-      if (a.relu) {
+      if (a.relu && co < a.relu_co) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = dh_relu(v[r]);
       }
@@ -270,13 +271,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
         if (full) {
           if (a.mask) {
-            const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + o);
+            const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + om);
             const bf16_t* mp = reinterpret_cast<const bf16_t*>(&mk);
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (!(bf2f(mp[r]) > 0.f)) v[r] = 0.f;
           }
           if (a.resid) {
-            const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + o);
+            const uint2 rs = *reinterpret_cast<const uint2*>(a.resid + orr);
             const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rs);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += bf2f(rp[r]);
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           for (int r = 0; r < 4; ++r) {
             if (co + r < a.Co) {
               float t = v[r];
-              if (a.mask && !(bf2f(a.mask[o + r]) > 0.f)) t = 0.f;
-              if (a.resid) t += bf2f(a.resid[o + r]);
+              if (a.mask && !(bf2f(a.mask[om + r]) > 0.f)) t = 0.f;
+              if (a.resid) t += bf2f(a.resid[orr + r]);
               if (a.accumulate) t += bf2f(y[r]);
               y[r] = f2bf(t);
             }
@@ -424,16 +425,21 @@ int launch_cfg(const ConvArgs& a0, bool fast, hipStream_t s) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-  const int c8 = danhip_launch_conv_c8(a, s);          // conv1_1: 3 (padded to 8) -> 64 channels, bound by its output write
-  if (c8 <= 0) return c8;
-  const int cr = danhip_launch_conv_c64(a, s);         // 3x3 / stride-1, 64 -> 64 channels: register-resident weights
-  if (cr <= 0) return cr;
+  const bool view = a.strided();                       // channel-slice views / partial ReLU: the streaming GEMM and the flat-M kernel only
+  if (!view) {
+    const int c8 = danhip_launch_conv_c8(a, s);        // conv1_1: 3 (padded to 8) -> 64 channels, bound by its output write
+    if (c8 <= 0) return c8;
+    const int cr = danhip_launch_conv_c64(a, s);       // 3x3 / stride-1, 64 -> 64 channels: register-resident weights
+    if (cr <= 0) return cr;
+  }
   const bool sk = prefer_splitk(a);                    // too few tiles for the persistent kernels: split K over workgroups instead
   if (!sk) {
-    const int h2 = danhip_launch_conv_halo2(a, s);     // 3x3 / stride-1, Cout % 128 == 0, maps that fill 16 x 32 tiles: 512-pixel halo tiles
-    if (h2 <= 0) return h2;
-    const int hr = danhip_launch_conv_halo(a, s);      // 3x3 / stride-1 on large maps: halo-reuse kernel
-    if (hr <= 0) return hr;
+    if (!view) {
+      const int h2 = danhip_launch_conv_halo2(a, s);   // 3x3 / stride-1, Cout % 128 == 0, maps that fill 16 x 32 tiles: 512-pixel halo tiles
+      if (h2 <= 0) return h2;
+      const int hr = danhip_launch_conv_halo(a, s);    // 3x3 / stride-1 on large maps: halo-reuse kernel
+      if (hr <= 0) return hr;
+    }
     const int pr = danhip_launch_conv_pointwise(a, s); // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
     if (pr <= 0) return pr;
   }
@@ -581,6 +587,7 @@ ConvArgs fwd_args(const danhip_conv_desc* d) {
   a.cpt = a.C / 64;
   a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
   a.dstride = 1; a.dshift = 0;
+  a.ldx = a.C; a.ldy = a.Co; a.ldm = a.Co; a.relu_co = a.Co;
   return a;
 }
 ConvArgs bwd_args(const danhip_conv_desc* d) {
@@ -600,6 +607,7 @@ ConvArgs bwd_args(const danhip_conv_desc* d) {
   a.ktiles = a.Kpad / 64;
   a.cpt = a.C / 64;
   a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo); a.div_c = make_fastdiv(a.C); a.div_kw = make_fastdiv(a.kw);
+  a.ldx = a.C; a.ldy = a.Co; a.ldm = a.Co; a.relu_co = a.Co;
   return a;
 }
 }  // namespace
@@ -725,6 +733,55 @@ extern "C" int danhip_conv2d_fwd_ws(const danhip_conv_desc* d, const uint16_t* x
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
   a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
   if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 0) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
+  return launch_conv(a, (hipStream_t)stream);
+}
+
+// ---- channel-slice views (round 4).  x / y (and the data gradient's mask) may be channel slices of wider NHWC tensors: pointer = base + c0,
+// pitch = the wider tensor's channel count.  These calls run on the streaming GEMM / flat-M kernels only (the halo and 64 -> 64 kernels
+// address dense tensors), 16-bit output, no residual.
+static int check_pitch(const danhip_conv_pitch* p, int cx, int cy, const char* what) {
+  DH_REQUIRE(p != nullptr, DANHIP_EINVAL, "%s: null pitch", what);
+  DH_REQUIRE(p->x_pitch >= cx && p->y_pitch >= cy && (p->aux_pitch == 0 || p->aux_pitch >= cy), DANHIP_EINVAL,
+             "%s: a pitch is smaller than the channel count of its tensor", what);
+  DH_REQUIRE(((p->x_pitch | p->y_pitch | p->aux_pitch) & 7) == 0, DANHIP_EINVAL, "%s: pitches must be multiples of 8 channels", what);
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_conv2d_fwd_strided(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                         int relu, int32_t relu_channels, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd_strided: null pointer");
+  DH_REQUIRE(d->Cout % 8 == 0, DANHIP_EINVAL, "conv2d_fwd_strided: Cout must be a multiple of 8");
+  rc = check_pitch(pitch, d->Cin, d->Cout, "conv2d_fwd_strided");
+  if (rc) return rc;
+  DH_REQUIRE((int64_t)d->N * d->H * d->W * pitch->x_pitch < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * pitch->y_pitch < (1ll << 31), DANHIP_EINVAL,
+             "conv2d_fwd_strided: a viewed tensor exceeds 2^31 elements");
+  DH_REQUIRE(relu_channels >= 0 && relu_channels <= d->Cout && relu_channels % 8 == 0, DANHIP_EINVAL,
+             "conv2d_fwd_strided: relu_channels must be a multiple of 8 in [0, Cout]");
+  ConvArgs a = fwd_args(d);
+  a.x = x; a.w = wf_packed; a.bias = bias; a.y = y;
+  a.relu = (relu && relu_channels > 0) ? 1 : 0; a.relu_co = relu_channels;
+  a.ldx = pitch->x_pitch; a.ldy = pitch->y_pitch;
+  if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 0) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
+  return launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int danhip_conv2d_bwd_data_strided(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
+                                              uint16_t* dx, int accumulate, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(dy && wb_packed && dx, DANHIP_EINVAL, "conv2d_bwd_data_strided: null pointer");
+  DH_REQUIRE(d->stride == 1, DANHIP_EINVAL, "conv2d_bwd_data_strided: stride 1 only");
+  const int co8 = round_up(d->Cout, 8);
+  rc = check_pitch(pitch, co8, d->Cin, "conv2d_bwd_data_strided");
+  if (rc) return rc;
+  DH_REQUIRE((int64_t)d->N * d->Ho * d->Wo * pitch->x_pitch < (1ll << 31) && (int64_t)d->N * d->H * d->W * pitch->y_pitch < (1ll << 31), DANHIP_EINVAL,
+             "conv2d_bwd_data_strided: a viewed tensor exceeds 2^31 elements");
+  ConvArgs a = bwd_args(d);
+  a.x = dy; a.w = wb_packed; a.mask = relu_mask; a.y = dx; a.accumulate = accumulate;
+  a.ldx = pitch->x_pitch; a.ldy = pitch->y_pitch; a.ldm = pitch->aux_pitch ? pitch->aux_pitch : d->Cin;
+  if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 1) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
   return launch_conv(a, (hipStream_t)stream);
 }
 

@@ -110,13 +110,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // A rows (pixels): key = r & 7.  W rows: pairs of channel tiles are interleaved (lane row frow of tile c is output channel
   // (c>>1)*32 + (frow>>2)*8 + (c&1)*4 + (frow&3)), a ds_read_b128 group touches rows {0-3, 8-11 | 16-19, 24-27}: key = (r&3) | ((r>>3)&1)<<2.
   auto wkey = [](int r) __attribute__((always_inline)) -> int { return (r & 3) | (((r >> 3) & 1) << 2); };
-  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, (unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u);      // rows >= M are out of range: zero fill
+  // (pitched view: the last pixel's row ends C elements after its start, whatever the pitch)
+  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + (unsigned)a.C) * 2u);      // rows >= M are out of range: zero fill
   const pw_u32x4 rsrc_w = pw_make_rsrc(a.w, (unsigned)(g.NB * BN) * (unsigned)a.Kpad * 2u);
   unsigned avoff[APW], wvoff[WPW];
 #pragma unroll
   for (int k = 0; k < APW; ++k) {
     const int row = (wave * APW + k) * 8 + srow;
-    avoff[k] = (unsigned)row * (unsigned)(a.C * 2) + (unsigned)(((lane & 7) ^ (row & 7)) << 4);
+    avoff[k] = (unsigned)row * (unsigned)(a.ldx * 2) + (unsigned)(((lane & 7) ^ (row & 7)) << 4);
   }
 #pragma unroll
   for (int k = 0; k < WPW; ++k) {
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
           const unsigned ho = fdiv(rem, a.div_wo);
           const int rh = (int)ho * a.stride - a.pad_t, rw = (int)(rem - ho * (unsigned)a.Wo) * a.stride - a.pad_l;
-          pb = (unsigned)((((int)n * a.H + rh) * a.W + rw) * a.C) * 2u + (unsigned)(((lane & 7) ^ (row & 7)) << 4);   // may wrap; exact for valid taps
+          pb = (unsigned)((((int)n * a.H + rh) * a.W + rw) * a.ldx) * 2u + (unsigned)(((lane & 7) ^ (row & 7)) << 4);   // may wrap; exact for valid taps
           for (int t = 0; t < a.taps; ++t) {
             const int i = (int)fdiv((unsigned)t, a.div_kw), jj = t - i * a.kw;
             if ((unsigned)(rh + i) < (unsigned)a.H && (unsigned)(rw + jj) < (unsigned)a.W) mk |= 1u << t;
@@ -161,14 +162,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned inv = d_ok ? 0u : 0xFFFFFFFFu;
     const unsigned sw = (unsigned)(d_nb * BN) * (unsigned)(a.Kpad * 2) + (unsigned)(d_k * 128);
     if constexpr (TAPS) {
-      const unsigned toff = (unsigned)((d_ti * a.W + d_tj) * a.C + d_cc * 64) * 2u;       // wave-uniform
+      const unsigned toff = (unsigned)((d_ti * a.W + d_tj) * a.ldx + d_cc * 64) * 2u;       // wave-uniform
 #pragma unroll
       for (int k = 0; k < APW; ++k) {
         const unsigned voff = ((tmask[k] >> d_tap) & 1u) ? pbase[k] + toff : 0xFFFFFFFFu;
         pw_dma16(rsrc_x, voff | inv, base + (wave * APW + k) * 1024);
       }
     } else {
-      const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.C * 2) + (unsigned)(d_k * 128);
+      const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.ldx * 2) + (unsigned)(d_k * 128);
 #pragma unroll
       for (int k = 0; k < APW; ++k) pw_dma16(rsrc_x, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
     }
@@ -240,9 +241,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           const long mm = m < a.M ? m : (long)a.M - 1;
 #pragma unroll
           for (int q = 0; q < NPAIR; ++q) {
-            const size_t o = (size_t)mm * a.Co + cb + q * 32;
-            ld_m[p][q] = pw_load16(mbase + o);
-            ld_o[p][q] = pw_load16(obase + o);
+            // (a mode that is off reads the other mode's tensor at ITS pitch)
+            ld_m[p][q] = pw_load16(mbase + (size_t)mm * (a.mask ? a.ldm : a.ldy) + cb + q * 32);
+            ld_o[p][q] = pw_load16(obase + (size_t)mm * (a.accumulate ? a.ldy : a.ldm) + cb + q * 32);
           }
         }
       } else {
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           if constexpr (!DGRAD) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += bv[q][r];
-            if (a.relu) {
+            if (a.relu && cb + q * 32 < a.relu_co) {      // (relu_co is a multiple of 8: a lane's 8 channels are all on one side)
 #pragma unroll
               for (int r = 0; r < 8; ++r) v[r] = dh_relu(v[r]);
             }
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
           if (m < a.M) {
             const pw_u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-            *reinterpret_cast<pw_u32x4*>(reinterpret_cast<bf16_t*>(a.y) + (size_t)m * a.Co + cb + q * 32) = t;
+            *reinterpret_cast<pw_u32x4*>(reinterpret_cast<bf16_t*>(a.y) + (size_t)m * a.ldy + cb + q * 32) = t;
           }
           ++ns;
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -408,7 +409,8 @@ bool pw_eligible(const ConvArgs& a) {
   if (a.C % 64 != 0 || a.Co % 64 != 0 || a.C < 64 || a.Kpad != a.taps * a.C) return false;
   if (a.out_f32 || a.resid || a.pool_y) return false;
   if ((long)a.M < 2048) return false;                      // tiny maps: the flat-M kernel's smaller tiles fill the chip better
-  if ((long)a.N * a.H * a.W * a.C >= (1l << 31) || (long)a.Co * a.Kpad >= (1l << 31)) return false;
+  if ((long)a.N * a.H * a.W * a.ldx >= (1l << 31) || (long)a.Co * a.Kpad >= (1l << 31)) return false;
+  if ((a.ldx | a.ldy | a.ldm | a.relu_co) & 7) return false;         // 16-byte pieces: pitches (and the ReLU boundary) are multiples of 8 channels
   return true;
 }
 

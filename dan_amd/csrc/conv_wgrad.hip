@@ -18,6 +18,7 @@ struct WgradArgs {
   float* dw;           // [kh,kw,cin_real,Cout]
   float* db;           // [Cout] bias gradient (column sums of dy) or null
   int N, H, W, C, Ho, Wo, Co8, Cout, cin_real;
+  int ldx, ldy;        // pixel pitches of x / dy in elements (channel-slice views; dense: C / Co8)
   int kh, kw, stride, pad_t, pad_l;
   int M, ktiles, kt_per_split;
   int linear;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         const bf16_t* src = zero;
         if (a.linear) {                                               // pointwise, stride 1: pixel m of x IS pixel m of dy, no decomposition
           const int cc = ci0 + cs * 8;
-          if (m < a.M && cc < a.C) src = a.x + ((size_t)m * a.C + cc);
+          if (m < a.M && cc < a.C) src = a.x + ((size_t)m * a.ldx + cc);
         } else if (m < a.M) {
           const unsigned n = fdiv((unsigned)m, a.div_howo);
           const unsigned rem = (unsigned)m - n * (unsigned)(a.Ho * a.Wo);
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
           if (a.tapcols) { i = cs / a.kw; j = cs % a.kw; cc = 0; ok = cs < a.kh * a.kw; }
           const int hi = (int)ho * a.stride - a.pad_t + i, wi = (int)wo * a.stride - a.pad_l + j;
           ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && cc < a.C;
-          if (ok) src = a.x + ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.C + cc);
+          if (ok) src = a.x + ((size_t)(((int)n * a.H + hi) * a.W + wi) * a.ldx + cc);
         }
         glds16(src, sX + piece * 1024);
       }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         const int m = mb + prow;
         const int cs = yc ^ swz<RBY>(prow);
         const int cc = co0 + cs * 8;
-        const bf16_t* src = (m < a.M && cc < a.Co8) ? a.dy + ((size_t)m * a.Co8 + cc) : zero;
+        const bf16_t* src = (m < a.M && cc < a.Co8) ? a.dy + ((size_t)m * a.ldy + cc) : zero;
         glds16(src, sY + piece * 1024);
       }
     }
@@ -259,18 +260,16 @@ extern "C" size_t danhip_conv2d_bwd_weight_workspace_bytes(const danhip_conv_des
   return r ? r : danhip_wgrad_pw_workspace_bytes(d);
 }
 
-extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
-                                        int32_t cin_real, void* stream) {
-  return danhip_conv2d_bwd_weight_ws(d, x, dy, dw_hwio, db, cin_real, nullptr, 0, stream);
-}
-
-extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
-                                           int32_t cin_real, void* ws, size_t ws_bytes, void* stream) {
+static int bwd_weight_impl(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db, int32_t cin_real, int ldx, int ldy,
+                           void* ws, size_t ws_bytes, void* stream) {
   DH_REQUIRE(d && x && dy && dw_hwio, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
   DH_REQUIRE(d->Cin % 8 == 0, DANHIP_EINVAL, "conv2d_bwd_weight: Cin=%d must be a multiple of 8", d->Cin);
   DH_REQUIRE(cin_real > 0 && cin_real <= d->Cin, DANHIP_EINVAL, "conv2d_bwd_weight: cin_real out of range");
+  const int co8 = (d->Cout + 7) / 8 * 8;
+  const bool view = ldx != d->Cin || ldy != co8;
+  DH_REQUIRE(ldx >= d->Cin && ldy >= co8 && ((ldx | ldy) & 7) == 0, DANHIP_EINVAL, "conv2d_bwd_weight: pitches must be multiples of 8 and cover the channels");
   // the kernels address both activations through raw buffer descriptors with a 32-bit byte count: 2^31 16-bit elements = 4 GiB would wrap to 0
-  DH_REQUIRE((int64_t)d->N * d->H * d->W * d->Cin < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * (int64_t)((d->Cout + 7) / 8 * 8) < (1ll << 31),
+  DH_REQUIRE((int64_t)d->N * d->H * d->W * ldx < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * (int64_t)ldy < (1ll << 31),
              DANHIP_EINVAL, "conv2d_bwd_weight: tensor exceeds 2^31 elements (4 GiB): split the batch");
   {   // output size: TF 'same' (ceil(in / s); padding derived, more on the bottom / right) or 'valid' (floor((in - k) / s) + 1, no padding)
     const bool same = d->Ho == (d->H + d->stride - 1) / d->stride && d->Wo == (d->W + d->stride - 1) / d->stride;
@@ -278,14 +277,17 @@ extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint
     DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
   }
   {
-    const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
-    if (hr <= 0) return hr;
-    const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
+    if (!view) {                                    // (the row-streaming 3x3 kernel addresses dense tensors)
+      const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
+      if (hr <= 0) return hr;
+    }
+    const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes, ldx, ldy);
     if (pr <= 0) return pr;
   }
   WgradArgs a{};
   a.x = x; a.dy = dy; a.dw = dw_hwio; a.db = db;
-  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Co8 = (d->Cout + 7) / 8 * 8;
+  a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.Co8 = co8;
+  a.ldx = ldx; a.ldy = ldy;
   a.cin_real = cin_real;
   a.kh = d->kh; a.kw = d->kw; a.stride = d->stride;
   int total = (d->Ho - 1) * d->stride + d->kh - d->H; if (total < 0) total = 0; a.pad_t = total / 2;
@@ -294,7 +296,7 @@ extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint
   a.ktiles = (a.M + 63) / 64;
   a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo);
   hipStream_t s = (hipStream_t)stream;
-  if (d->Cin == 8 && d->kh * d->kw <= 16) {       // first layer: taps ride in the tile columns
+  if (d->Cin == 8 && d->kh * d->kw <= 16 && !view) {       // first layer: taps ride in the tile columns
     a.tapcols = 1;
     return a.Co8 > 64 ? launch_wgrad<128, 128, 2>(a, s) : launch_wgrad<128, 64, 2>(a, s);
   }
@@ -305,4 +307,22 @@ extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint
   if (ci_small) return launch_wgrad<64, 128, 2>(a, s);
   if (co_small) return launch_wgrad<128, 64, 2>(a, s);
   return launch_wgrad<128, 128, 2>(a, s);
+}
+
+extern "C" int danhip_conv2d_bwd_weight(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                        int32_t cin_real, void* stream) {
+  return danhip_conv2d_bwd_weight_ws(d, x, dy, dw_hwio, db, cin_real, nullptr, 0, stream);
+}
+
+extern "C" int danhip_conv2d_bwd_weight_ws(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                           int32_t cin_real, void* ws, size_t ws_bytes, void* stream) {
+  DH_REQUIRE(d != nullptr, DANHIP_EINVAL, "conv2d_bwd_weight: null pointer");
+  return bwd_weight_impl(d, x, dy, dw_hwio, db, cin_real, d->Cin, (d->Cout + 7) / 8 * 8, ws, ws_bytes, stream);
+}
+
+/* x / dy as channel-slice views: pitch->x_pitch / y_pitch = elements between consecutive pixels of x / dy (aux_pitch unused). */
+extern "C" int danhip_conv2d_bwd_weight_strided(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                                int32_t cin_real, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream) {
+  DH_REQUIRE(d != nullptr && pitch != nullptr, DANHIP_EINVAL, "conv2d_bwd_weight_strided: null pointer");
+  return bwd_weight_impl(d, x, dy, dw_hwio, db, cin_real, pitch->x_pitch, pitch->y_pitch, ws, ws_bytes, stream);
 }

@@ -27,6 +27,7 @@ struct WgPwArgs {
   float* dw;           // [cin_real,Cout]
   float* db;           // [Cout] or null
   int M, C, Co8, Cout, cin_real;
+  int ldx, ldy;        // pixel pitches of x / dy in elements (channel-slice views; dense: C / Co8)
   int ksteps, steps_per_split, ci_tiles, co_tiles, xcd_grouped;
   float* slab;         // optional: partial tiles as plain stores + wg_pw_reduce_kernel (short launches; see conv_wgrad_rows.hip)
   int splits;
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   if (k_begin >= k_end) return;
   const int V = (k_end - k_begin + DEPTH - 1) / DEPTH * DEPTH;
 
-  const wp_u32x4 rsrc_x = wp_make_rsrc(a.x, (unsigned)a.M * (unsigned)a.C * 2u);          // pixels >= M: out of range, zero fill
-  const wp_u32x4 rsrc_y = wp_make_rsrc(a.dy, (unsigned)a.M * (unsigned)a.Co8 * 2u);
+  const wp_u32x4 rsrc_x = wp_make_rsrc(a.x, ((unsigned)(a.M - 1) * (unsigned)a.ldx + (unsigned)a.C) * 2u);          // pixels >= M: out of range, zero fill
+  const wp_u32x4 rsrc_y = wp_make_rsrc(a.dy, ((unsigned)(a.M - 1) * (unsigned)a.ldy + (unsigned)a.Co8) * 2u);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
 
   // ---- DMA lane constants: wave w moves X pieces 2w, 2w+1 (sub-tile p >> 2, pixels 8 (p & 3) ..) and dY pieces 2w, 2w+1 (sub-tile
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int l8 = lane >> 3, pcol = pp * 8 + l8;
       const int chunk = (lane & 7) ^ (wp_f128(pcol) << 1);
       const int ci = ci0 + sub * 64;
-      vx[k] = ci < a.C ? (unsigned)pcol * (unsigned)(a.C * 2) + (unsigned)(ci * 2 + (chunk << 4)) : 0xFFFFFFFFu;
+      vx[k] = ci < a.C ? (unsigned)pcol * (unsigned)(a.ldx * 2) + (unsigned)(ci * 2 + (chunk << 4)) : 0xFFFFFFFFu;
       xdst[k] = XBASE + sub * XSUB + pp * 1024;
     }
     {
@@ -109,14 +110,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int lp = lane >> 4, cpos = lane & 15, px = pp * 4 + lp;
       const int chunk = cpos ^ (wp_f256(px) << 1);
       const int co = co0 + sub * 128 + chunk * 8;
-      vy[k] = co < a.Co8 ? (unsigned)px * (unsigned)(a.Co8 * 2) + (unsigned)(co * 2) : 0xFFFFFFFFu;
+      vy[k] = co < a.Co8 ? (unsigned)px * (unsigned)(a.ldy * 2) + (unsigned)(co * 2) : 0xFFFFFFFFu;
       ydst[k] = YBASE + sub * YSUB + pp * 1024;
     }
   }
   auto dma_step = [&](auto slc, int kstep) __attribute__((always_inline)) {      // K-step kstep (32 pixels) into ring slot SL
     constexpr int SL = decltype(slc)::value;
     const unsigned inv = kstep < k_end ? 0u : 0xFFFFFFFFu;                       // beyond this block's share: zero fill
-    const unsigned sx = (unsigned)(kstep * 32) * (unsigned)(a.C * 2), sy = (unsigned)(kstep * 32) * (unsigned)(a.Co8 * 2);
+    const unsigned sx = (unsigned)(kstep * 32) * (unsigned)(a.ldx * 2), sy = (unsigned)(kstep * 32) * (unsigned)(a.ldy * 2);
 #pragma unroll
     for (int k = 0; k < 2; ++k) wp_dma16(rsrc_x, (vx[k] + sx) | (vx[k] == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | inv, lds0 + SL * XS + xdst[k]);
 #pragma unroll
@@ -361,14 +362,20 @@ size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d) {
 
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
 int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
-                           void* ws, size_t ws_bytes) {
+                           void* ws, size_t ws_bytes, int ldx, int ldy) {
   if (!wg_pw_eligible(d)) return 1;
+  {   // a channel's 16-byte chunk offset inside a pixel row must keep the row's swizzle: within the 64-channel (X) / 128-channel (dY) sub-tile
+    const long M_ = (long)d->N * d->H * d->W;
+    if (ldx && M_ * ldx >= (1l << 31)) return 1;
+    if (ldy && M_ * ldy >= (1l << 31)) return 1;
+  }
   constexpr int LDS = 4 * (16384 + 16384);
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_pw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   WgPwArgs a{};
   a.x = x; a.dy = dy; a.dw = dw; a.db = db;
   a.M = d->N * d->H * d->W; a.C = d->Cin; a.Co8 = (d->Cout + 7) / 8 * 8; a.Cout = d->Cout; a.cin_real = cin_real;
+  a.ldx = ldx ? ldx : a.C; a.ldy = ldy ? ldy : a.Co8;
   a.ksteps = (a.M + 31) / 32;
   a.ci_tiles = (a.C + 255) / 256;
   a.co_tiles = (a.Co8 + 255) / 256;

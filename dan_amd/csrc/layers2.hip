@@ -107,7 +107,9 @@ __global__ void resize_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __res
 }
 
 // average_pooling2d((2,2), 1, 'same'): window (h..h+1, w..w+1) clipped to the map; divisor = number of valid taps
-__global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C) {
+// (ldx / ldy: pixel pitches in elements - channel-slice views; relu: y = max(avg, 0), the DAN context block's branch 2 with its 1x1
+// convolution moved in front of the pool)
+__global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, int ldx, int ldy, int relu) {
   const int cg = C / 8;
   const long total = (long)N * H * W * cg;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -124,7 +126,7 @@ __global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
       for (int dw = 0; dw < 2; ++dw) {
         if (h + dh < H && w + dw < W) {
           float f[8];
-          unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + h + dh) * W + w + dw) * C + g * 8), f);
+          unpack8(*reinterpret_cast<const uint4*>(x + (((long)n * H + h + dh) * W + w + dw) * ldx + g * 8), f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) s[i] += f[i];
           ++cnt;
@@ -133,12 +135,16 @@ __global__ void avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
     const float d = (float)cnt;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = s[i] / d;
-    *reinterpret_cast<uint4*>(y + idx * 8) = pack8(s);
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = fmaxf(s[i], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + (idx / cg) * ldy + g * 8) = pack8(s);
   }
 }
 
 __global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xmask, bf16_t* __restrict__ dx, int N, int H, int W,
-                                   int C, int accumulate) {
+                                   int C, int accumulate, int ldy, int ldx) {
   const int cg = C / 8;
   const long total = (long)N * H * W * cg;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -156,16 +162,16 @@ __global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* 
         if (ho >= 0 && wo >= 0) {
           const int cnt = ((ho + 1 < H) ? 2 : 1) * ((wo + 1 < W) ? 2 : 1);
           float f[8];
-          unpack8(*reinterpret_cast<const uint4*>(dy + (((long)n * H + ho) * W + wo) * C + g * 8), f);
+          unpack8(*reinterpret_cast<const uint4*>(dy + (((long)n * H + ho) * W + wo) * ldy + g * 8), f);
           const float d = (float)cnt;
 #pragma unroll
           for (int i = 0; i < 8; ++i) s[i] += f[i] / d;
         }
       }
-    uint4* dst = reinterpret_cast<uint4*>(dx + idx * 8);
+    uint4* dst = reinterpret_cast<uint4*>(dx + (idx / cg) * ldx + g * 8);
     if (xmask) {                                          // x is a ReLU output: fold its backward in (x > 0)
       float m[8];
-      unpack8(*reinterpret_cast<const uint4*>(xmask + idx * 8), m);
+      unpack8(*reinterpret_cast<const uint4*>(xmask + (idx / cg) * ldx + g * 8), m);
 #pragma unroll
       for (int i = 0; i < 8; ++i) if (!(m[i] > 0.f)) s[i] = 0.f;
     }
@@ -314,10 +320,89 @@ extern "C" int danhip_resize_bilinear_add_bwd(const uint16_t* dout, uint16_t* du
   return DANHIP_OK;
 }
 
+namespace {
+// out = a + b (16-bit, 8 elements per thread): the context block's residual sum relu(conv(hyper)) + features (net/danet.py:913-918)
+__global__ void add16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    unpack8(reinterpret_cast<const uint4*>(a)[i], fa);
+    unpack8(reinterpret_cast<const uint4*>(b)[i], fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+    reinterpret_cast<uint4*>(out)[i] = pack8(fa);
+  }
+}
+// backward of y = r + x with r = relu(.) in ONE pass over dy:  dr = dy * (r > 0)   and   dx (+)= dy * (xmask > 0 | no mask)
+__global__ void residual_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ r, const bf16_t* __restrict__ xmask, bf16_t* __restrict__ dr,
+                                    bf16_t* __restrict__ dx, int accumulate, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float g[8], m[8], t[8];
+    unpack8(reinterpret_cast<const uint4*>(dy)[i], g);
+    unpack8(reinterpret_cast<const uint4*>(r)[i], m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = m[e] > 0.f ? g[e] : 0.f;
+    reinterpret_cast<uint4*>(dr)[i] = pack8(t);
+    if (dx) {
+      if (xmask) {
+        unpack8(reinterpret_cast<const uint4*>(xmask)[i], m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (!(m[e] > 0.f)) g[e] = 0.f;
+      }
+      if (accumulate) {
+        unpack8(reinterpret_cast<const uint4*>(dx)[i], m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] += m[e];
+      }
+      reinterpret_cast<uint4*>(dx)[i] = pack8(g);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int danhip_add16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
+  DH_REQUIRE(a && b && out && n > 0 && n % 8 == 0, DANHIP_EINVAL, "add16: null pointer or n not a multiple of 8");
+  hipLaunchKernelGGL(add16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)(n / 8));
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_residual_bwd(const uint16_t* dy, const uint16_t* r, const uint16_t* x_mask, uint16_t* dr, uint16_t* dx, int accumulate, int64_t n,
+                                   void* stream) {
+  DH_REQUIRE(dy && r && dr && n > 0 && n % 8 == 0, DANHIP_EINVAL, "residual_bwd: null pointer or n not a multiple of 8");
+  hipLaunchKernelGGL(residual_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, dy, r, x_mask, dr, dx, accumulate, (long)(n / 8));
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
 extern "C" int danhip_avgpool2x2s1_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
   DH_REQUIRE(x && y, DANHIP_EINVAL, "avgpool2x2s1_same_fwd: null pointer");
   DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "avgpool2x2s1_same_fwd: bad dims (C %% 8 == 0)");
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, C, C, 0);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+/* The same pool on channel-slice views (x_pitch / y_pitch elements between pixels), optionally followed by ReLU; and its backward
+ * (dy at y_pitch -> dx at x_pitch, overwritten; the ReLU backward is the caller's: dy arrives masked).  net/danet.py:854-861 with the
+ * branch's 1x1 convolution commuted in front of the (linear) pool. */
+extern "C" int danhip_avgpool2x2s1_same_fwd_strided(const uint16_t* x, int32_t x_pitch, uint16_t* y, int32_t y_pitch, int32_t N, int32_t H, int32_t W,
+                                                    int32_t C, int relu, void* stream) {
+  DH_REQUIRE(x && y, DANHIP_EINVAL, "avgpool2x2s1_same_fwd_strided: null pointer");
+  DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && x_pitch >= C && y_pitch >= C && ((x_pitch | y_pitch) & 7) == 0, DANHIP_EINVAL,
+             "avgpool2x2s1_same_fwd_strided: bad dims (C and the pitches multiples of 8, pitch >= C)");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, x_pitch, y_pitch,
+                     relu ? 1 : 0);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_avgpool2x2s1_same_bwd_strided(const uint16_t* dy, int32_t y_pitch, uint16_t* dx, int32_t x_pitch, int32_t N, int32_t H, int32_t W,
+                                                    int32_t C, void* stream) {
+  DH_REQUIRE(dy && dx, DANHIP_EINVAL, "avgpool2x2s1_same_bwd_strided: null pointer");
+  DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && x_pitch >= C && y_pitch >= C && ((x_pitch | y_pitch) & 7) == 0, DANHIP_EINVAL,
+             "avgpool2x2s1_same_bwd_strided: bad dims (C and the pitches multiples of 8, pitch >= C)");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, (const bf16_t*)nullptr, dx, N, H, W, C, 0,
+                     y_pitch, x_pitch);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -326,7 +411,7 @@ extern "C" int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, const uint16_t* 
                                             int accumulate, void* stream) {
   DH_REQUIRE(dy && dx, DANHIP_EINVAL, "avgpool2x2s1_same_bwd: null pointer");
   DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "avgpool2x2s1_same_bwd: bad dims (C %% 8 == 0)");
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, x_mask, dx, N, H, W, C, accumulate);
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, x_mask, dx, N, H, W, C, accumulate, C, C);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }

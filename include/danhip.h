@@ -136,6 +136,21 @@ int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d);
 int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
                                 uint16_t* dx, int accumulate, void* stream);
 
+/* Channel-slice views (round 4; net/danet.py:842-918: every branch of the context block is a channel slice of a wider tensor - the fused
+ * input 1x1's output, the concat buffer).  A slice [.., c0 : c0 + C] of an NHWC tensor whose pixels are `ld` elements apart is its base
+ * pointer + c0 and pitch ld: x_pitch / y_pitch are the pitches of the call's input / output operand (forward: x, y; data gradient: dy,
+ * dx; weight gradient: x, dy), aux_pitch that of the data gradient's relu_mask (0 = dx's channel count).  Multiples of 8 elements.
+ * These calls run on the streaming GEMM / flat-M kernels (the halo and 64 -> 64 kernels address dense tensors); 16-bit output, no residual.
+ * relu_channels (forward): ReLU applies to output channels < relu_channels only (a fused block of 1x1 convolutions whose last columns
+ * stay linear); pass Cout for a plain conv_relu, anything with relu = 0 for none. */
+typedef struct { int32_t x_pitch, y_pitch, aux_pitch; } danhip_conv_pitch;
+int danhip_conv2d_fwd_strided(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                              int relu, int32_t relu_channels, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream);
+int danhip_conv2d_bwd_data_strided(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
+                                   uint16_t* dx, int accumulate, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream);
+int danhip_conv2d_bwd_weight_strided(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* dy, float* dw_hwio, float* db,
+                                     int32_t cin_real, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream);
+
 /* dw_hwio fp32 [kh,kw,Cin,Cout] += sum_pixels x (x) dy   (atomic fp32 accumulation: zero it first).
  * db (optional) fp32 [Cout] += sum_pixels dy  (bias gradient, computed by the same kernel: no extra pass over dy).
  * cin_real: number of leading input channels that exist in dw (dw is [kh,kw,cin_real,Cout]). */
@@ -186,6 +201,19 @@ int danhip_avgpool2x2s1_same_fwd(const uint16_t* x, uint16_t* y, int32_t N, int3
 /* x_mask (may be NULL): the pooled tensor when it is a ReLU output — dx is then multiplied by (x > 0). */
 int danhip_avgpool2x2s1_same_bwd(const uint16_t* dy, const uint16_t* x_mask, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                  int accumulate, void* stream);
+/* The residual sum of the DAN context block (net/danet.py:913-918), y = relu(conv(hyper)) + features: out = a + b over n 16-bit elements
+ * (n % 8 == 0), and its backward in ONE pass over dy: dr = dy * (r > 0) (the conv's ReLU backward, materialised for its two gradient
+ * kernels) and, when dx != NULL, dx (+)= dy * (x_mask > 0, or all when x_mask == NULL) (the skip path into the producer's gradient). */
+int danhip_add16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+int danhip_residual_bwd(const uint16_t* dy, const uint16_t* r, const uint16_t* x_mask, uint16_t* dr, uint16_t* dx, int accumulate, int64_t n,
+                        void* stream);
+/* The same pool on channel-slice views (pitches in elements, multiples of 8), optionally followed by ReLU, and its backward (dy -> dx,
+ * overwritten; a ReLU's backward is the caller's: dy arrives masked).  The DAN context block (net/danet.py:854-861) runs branch 2's 1x1
+ * convolution IN FRONT of the (linear) pool, on the 64 output channels instead of the C input channels. */
+int danhip_avgpool2x2s1_same_fwd_strided(const uint16_t* x, int32_t x_pitch, uint16_t* y, int32_t y_pitch, int32_t N, int32_t H, int32_t W,
+                                         int32_t C, int relu, void* stream);
+int danhip_avgpool2x2s1_same_bwd_strided(const uint16_t* dy, int32_t y_pitch, uint16_t* dx, int32_t x_pitch, int32_t N, int32_t H, int32_t W,
+                                         int32_t C, void* stream);
 /* Backward of tf.concat(axis=-1) / of a residual add (net/danet.py:911-918), one input at a time:
  *   out[m][c] (+)= (mask == NULL || mask[m*ldm + c] > 0) ? dy[m*ldy + c0 + c] : 0      for c < C,   out[m][c] = 0 for C <= c < Cpad (first write)
  * out rows have Cpad (>= C, multiple of 8) elements: the channel-padded gradient layout danhip_conv2d_bwd_* take for a ragged Cout. */
