@@ -1,6 +1,8 @@
 """DAN graph on the libdanhip kernels — mirrors net/danet.py (class VGG16Backbone: backbone, build_lfpn :339-380 with a
 256-channel fused conv, se_inception_block V1 :842-918, get_features_stage1 :920-929, get_features_stage2 :931-954,
 get_predict_module with shared conv :469-532) with the reference's variable names."""
+import os
+
 import torch
 
 from .. import ops
@@ -54,9 +56,16 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             return self.conv2d(hyper, filters, (1, 1), 1, name, relu=True, residual=x)
         return ops.add(self._cr(hyper, filters, (1, 1), name), x)
 
+    # False (or DANHIP_FUSED_CONTEXT=0 at import): the block as ten separate convolutions + concat + add (the round-3 form; A/B and tests)
+    FUSED_CONTEXT_BLOCK = os.environ.get("DANHIP_FUSED_CONTEXT", "1") == "1"
+
     def se_inception_block(self, inputs, name=None):
         """DAN context module V1 — net/danet.py:842-918."""
         c = inputs.shape[-1]
+        # (training AND 16-bit inference: once the trainer has laid the three fused 1x1 kernels out side by side they are strided views, which
+        # only the fused call consumes; the fp32 inference path reads the TF variables as they are)
+        if self.FUSED_CONTEXT_BLOCK and inputs.dtype == ops.ACT and c % 64 == 0 and inputs.is_contiguous():
+            return self._se_inception_block_fused(inputs, name)
         b1 = self._cr(inputs, 64, (1, 1), name + "/branch1_conv_1x1")
         b2 = self._cr(ops.avg_pool_2x2_s1(inputs), 64, (1, 1), name + "/branch2_conv_1x1")
         b3 = self._cr(inputs, 64, (1, 1), name + "/branch3_conv_1x1")
@@ -68,6 +77,39 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         b4b = self._cr(b4, 32, (1, 3), name + "/branch4_conv_3x1")
         hyper = ops.concat([b1, b2, b3a, b3b, b4a, b4b])
         return self._residual_conv(hyper, c, name + "/residual_conv", inputs)
+
+    def _se_inception_block_fused(self, inputs, name):
+        """The same block as ONE autograd node over channel-slice views (ops._ContextBlock): the three 1x1s of branches 3, 4 and 2 run as
+        one convolution (their kernels side by side in the trainer's flat buffer: VariableStore.fuse), branch 2's average pool moves behind
+        its 1x1, every branch writes its slice of the concat buffer directly and reads its slice of the concat's gradient in place.
+        Variables are created in the reference's order under the reference's names."""
+        c = inputs.shape[-1]
+        V = self.vs
+
+        def var(scope, kh, kw, cin, cout):
+            return (V.get(name + "/" + scope + "/kernel", (kh, kw, cin, cout), "glorot"), V.get(name + "/" + scope + "/bias", (cout,), "zeros"))
+
+        w1, c1 = var("branch1_conv_1x1", 1, 1, c, 64)
+        w2, c2 = var("branch2_conv_1x1", 1, 1, c, 64)
+        w3, c3 = var("branch3_conv_1x1", 1, 1, c, 64)
+        w3a, c3a = var("branch3_conv_3x1", 3, 1, 64, 32)
+        w3b, c3b = var("branch3_conv_1x3", 1, 3, 64, 32)
+        w4, c4 = var("branch4_conv_1x1", 1, 1, c, 64)
+        w43, c43 = var("branch4_conv_3x3", 3, 3, 64, 64)
+        w4a, c4a = var("branch4_conv_1x3", 3, 1, 64, 32)           # (sic) the reference swaps these two names
+        w4b, c4b = var("branch4_conv_3x1", 1, 3, 64, 32)
+        wr, cr = var("residual_conv", 1, 1, 256, c)
+        pre = name + "/"
+        kn = (pre + "branch3_conv_1x1/kernel", pre + "branch4_conv_1x1/kernel", pre + "branch2_conv_1x1/kernel")
+        bn = (pre + "branch3_conv_1x1/bias", pre + "branch4_conv_1x1/bias", pre + "branch2_conv_1x1/bias")
+        wcat, ccat = V.fuse(kn, axis=3), V.fuse(bn, axis=0)        # one block each in the trainer's flat buffer, or None (plain autograd)
+        if wcat is None or ccat is None:
+            wcat, ccat = torch.cat([w3, w4, w2], dim=3).contiguous(), torch.cat([c3, c4, c2])
+        params = [(w1, c1), (wcat, ccat), (w3a, c3a), (w3b, c3b), (w43, c43), (w4a, c4a), (w4b, c4b), (wr, cr)]
+        # gradient buckets: descending position in the flat buffer (the fused block stands where branch3_conv_1x1 stood)
+        hooks = [wr, w4b, w4a, w43, w3b, w3a, w4, w3, w2, w1]
+        trace = {"b1": w1, "b2": w2, "b3": w3, "b3a": w3a, "b3b": w3b, "b4": w4, "b43": w43, "b4a": w4a, "b4b": w4b, "res": wr}
+        return ops.context_block(inputs, params, hooks, trace)
 
     def get_features_stage1(self, feature_layers, name=None):
         """net/danet.py:920-929."""

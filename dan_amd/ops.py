@@ -945,6 +945,219 @@ def add(a, b):
     return y
 
 
+def _vptr(t):
+    """Device pointer of an NHWC activation that may be a CHANNEL-SLICE VIEW of a wider tensor (dense channel axis, pixels t.stride(-2)
+    elements apart): what the *_strided entry points take together with that pitch."""
+    assert t.dim() == 4 and t.stride(3) == 1, "channel-slice view: NHWC with a dense channel axis"
+    N, H, W, _ = t.shape
+    ld = t.stride(2)
+    assert ld % 8 == 0 and t.stride(1) == W * ld and t.stride(0) == H * W * ld and t.storage_offset() % 8 == 0, "not a channel slice of a contiguous NHWC tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _wgrad_launch(d, xv, dyv, dw, db, cin_real, keep):
+    """Weight (+ bias) gradient of descriptor d with x / dy given as (possibly channel-slice) views, on the weight-gradient stream when the
+    trainer has it on (same ordering rules as _Conv2d.backward)."""
+    pitch = _lib.ConvPitch(xv.stride(2), dyv.stride(2), 0)
+    ws, nws = _wgrad_scratch(d, dyv.device)
+    if _WGRAD["on"]:
+        side = _WGRAD["side"]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        e0 = _prof_begin(side)
+        call("danhip_conv2d_bwd_weight_strided", ctypes.byref(d), _vptr(xv), _vptr(dyv), ptr(dw), ptr(db), cin_real, ctypes.byref(pitch), ptr(ws), nws,
+             ctypes.c_void_p(side.cuda_stream))
+        _prof_end(e0, d, 2, side)
+        _WGRAD["keep"].append((xv, dyv, ws) + tuple(keep))
+    else:
+        e0 = _prof_begin()
+        call("danhip_conv2d_bwd_weight_strided", ctypes.byref(d), _vptr(xv), _vptr(dyv), ptr(dw), ptr(db), cin_real, ctypes.byref(pitch), ptr(ws), nws, stream())
+        _prof_end(e0, d, 2)
+
+
+class _ContextBlock(torch.autograd.Function):
+    """DAN context module V1, se_inception_block (net/danet.py:842-918), as ONE autograd node over channel-slice views — round 4.
+
+    Forward (10 launches instead of 13 + torch.cat + torch add):
+        hyper[.., 0:64]      = relu(conv1x1_b1(x))                                   written straight into the concat buffer
+        T = [b3 | b4 | p2]   = conv1x1(x) with the three kernels side by side (192 columns; ReLU on the first 128 only)
+        hyper[.., 64:128]    = relu(avg_pool_2x2_s1(p2))        branch 2's 1x1 commuted in front of the (linear) pool: conv(avg(x)) = avg(conv(x)),
+                                                                its bias included (the average of a constant is the constant)
+        hyper[.., 128:192]   = relu(conv3x1(b3)) | relu(conv1x3(b3))                 inputs are slices of T, outputs slices of hyper
+        U                    = relu(conv3x3(b4));  hyper[.., 192:256] = relu(conv3x1(U)) | relu(conv1x3(U))
+        out                  = relu(conv1x1_res(hyper)) + x
+    Backward: d hyper comes out of the residual conv's data gradient already multiplied by (hyper > 0) = every branch's own ReLU mask;
+    each branch convolution reads ITS slice of it in place (no slice copies), gradients meet in dT / dU by accumulation, and x receives
+    three deliveries (skip path, fused 1x1, b1) instead of seven.  Variable names, creation order and arithmetic per output element are
+    the reference's."""
+
+    @staticmethod
+    def forward(ctx, x, xslot, yslot, handles, hook_order, *wb):
+        N, H, W, C = x.shape
+        dev = x.device
+        assert x.dtype == ACT and x.is_contiguous() and C % 64 == 0
+        pairs = list(zip(wb[0::2], wb[1::2]))                       # b1, cat, b3a, b3b, b43, b4a, b4b, res
+        need_bwd = any(t.requires_grad for t in wb) or x.requires_grad or any(_sink_trainable(t) for t in wb)
+        T = torch.empty((N, H, W, 192), dtype=ACT, device=dev)
+        hyper = torch.empty((N, H, W, 256), dtype=ACT, device=dev)
+        U = torch.empty((N, H, W, 64), dtype=ACT, device=dev)
+        r = torch.empty((N, H, W, C), dtype=ACT, device=dev)
+        out = torch.empty((N, H, W, C), dtype=ACT, device=dev)
+        descs, wbs = [], []
+
+        def conv(i, xv, yv, kh, kw, relu_ch):
+            w, b = pairs[i]
+            d = _desc(N, H, W, xv.shape[-1], yv.shape[-1], kh, kw, 1)
+            wf, wbk = packed_weights(d, w, handles[i][0], need_bwd)
+            pitch = _lib.ConvPitch(xv.stride(2), yv.stride(2), 0)
+            sc, nsc = _conv_scratch(d, 0, dev)
+            e0 = _prof_begin()
+            call("danhip_conv2d_fwd_strided", ctypes.byref(d), _vptr(xv), ptr(wf), ptr(b.detach()), _vptr(yv), 1, relu_ch, ctypes.byref(pitch), ptr(sc), nsc,
+                 stream())
+            _prof_end(e0, d, 0)
+            descs.append(d)
+            wbs.append(wbk)
+
+        conv(0, x, hyper[..., 0:64], 1, 1, 64)
+        conv(1, x, T, 1, 1, 128)
+        call("danhip_avgpool2x2s1_same_fwd_strided", _vptr(T[..., 128:192]), 192, _vptr(hyper[..., 64:128]), 256, N, H, W, 64, 1, stream())
+        conv(2, T[..., 0:64], hyper[..., 128:160], 3, 1, 32)
+        conv(3, T[..., 0:64], hyper[..., 160:192], 1, 3, 32)
+        conv(4, T[..., 64:128], U, 3, 3, 64)
+        conv(5, U, hyper[..., 192:224], 3, 1, 32)
+        conv(6, U, hyper[..., 224:256], 1, 3, 32)
+        conv(7, hyper, r, 1, 1, C)
+        call("danhip_add16", ptr(r), ptr(x), ptr(out), out.numel(), stream())
+        ctx.descs, ctx.handles, ctx.hook_order = descs, handles, hook_order
+        ctx.xslot, ctx.yslot = xslot, yslot
+        ctx.nw = len(wb)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, T, hyper, U, r, *wbs)
+        ctx.blocks = [(_sink_trainable(w), _sink_trainable(b)) for w, b in pairs]
+        ctx.cin_real = [w.shape[2] for w, _ in pairs]
+        ctx.couts = [w.shape[3] for w, _ in pairs]
+        ctx.khw = [(w.shape[0], w.shape[1]) for w, _ in pairs]
+        if TRACE is not None:                           # the block's ten ReLU decisions (tests): context_block() files them under their kernel variables
+            _CB_LAST.clear()
+            _CB_LAST.update({"b1": hyper[..., 0:64], "b2": hyper[..., 64:128], "b3": T[..., 0:64], "b3a": hyper[..., 128:160], "b3b": hyper[..., 160:192],
+                             "b4": T[..., 64:128], "b43": U, "b4a": hyper[..., 192:224], "b4b": hyper[..., 224:256], "res": r})
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, T, hyper, U, r = ctx.saved_tensors[:5]
+        wbs = ctx.saved_tensors[5:]
+        N, H, W, C = x.shape
+        dev = x.device
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dy is not None:
+            g = dy.contiguous() if g is None else g.add_(dy)
+        if g is None:
+            return (None,) * (5 + ctx.nw)
+        xs = ctx.xslot
+        need_dx = ctx.needs_input_grad[0]
+        dx_ret, xbuf, xacc, xmask = None, None, 0, None
+        if need_dx:
+            if xs is not None:
+                xbuf, xacc = xs.target()
+                xmask = x if xs.is_relu else None
+            else:
+                xbuf = dx_ret = torch.empty_like(x)
+        gr = torch.empty_like(g)
+        call("danhip_residual_bwd", ptr(g), ptr(r), ptr(xmask), ptr(gr), ptr(xbuf), xacc, g.numel(), stream())
+        dhyper = torch.empty_like(hyper)
+        dT = torch.empty_like(T)
+        dU = torch.empty_like(U)
+        grads = [None] * ctx.nw
+        dbs, dws = [None] * 8, [None] * 8
+
+        def sinks(i):
+            wp, bp = ctx.handles[i]
+            need_dw = ctx.needs_input_grad[5 + 2 * i] or ctx.blocks[i][0]
+            need_db = ctx.needs_input_grad[6 + 2 * i] or ctx.blocks[i][1]
+            dw = db = None
+            if need_dw:
+                sk = _grad_sink(wp) if wp is not None else None
+                dw = sk if sk is not None else torch.zeros(ctx.khw[i] + (ctx.cin_real[i], ctx.couts[i]), dtype=torch.float32, device=dev)
+                if sk is None:
+                    grads[2 * i] = dw
+            if need_db:
+                sk = _grad_sink(bp) if bp is not None else None
+                db = sk if sk is not None else torch.zeros(ctx.couts[i], dtype=torch.float32, device=dev)
+                if sk is None:
+                    grads[2 * i + 1] = db
+            return dw, db
+
+        def dgrad(i, dyv, mask, dxv, acc):
+            d = ctx.descs[i]
+            pitch = _lib.ConvPitch(dyv.stride(2), dxv.stride(2), mask.stride(2) if mask is not None else 0)
+            sc, nsc = _conv_scratch(d, 1, dev)
+            e0 = _prof_begin()
+            call("danhip_conv2d_bwd_data_strided", ctypes.byref(d), _vptr(dyv), ptr(wbs[i]), _vptr(mask) if mask is not None else None, _vptr(dxv), acc,
+                 ctypes.byref(pitch), ptr(sc), nsc, stream())
+            _prof_end(e0, d, 5 if mask is not None else 1)
+
+        def wgrad(i, xv, dyv):
+            dw, db = sinks(i)
+            if dw is None:
+                if db is not None:                               # (never in the reference graphs: a trainable bias comes with its kernel)
+                    db.add_(dyv.to(torch.float32).sum((0, 1, 2)))
+                return
+            _wgrad_launch(ctx.descs[i], xv, dyv, dw, db, ctx.cin_real[i], (gr, dhyper, dT, dU))
+
+        # residual conv: d hyper = (gr . W^T) * (hyper > 0); then every branch on its slice
+        dgrad(7, gr, hyper, dhyper, 0)
+        wgrad(7, hyper, gr)
+        dgrad(5, dhyper[..., 192:224], U, dU, 0)
+        wgrad(5, U, dhyper[..., 192:224])
+        dgrad(6, dhyper[..., 224:256], U, dU, 1)
+        wgrad(6, U, dhyper[..., 224:256])
+        dgrad(4, dU, T[..., 64:128], dT[..., 64:128], 0)
+        wgrad(4, T[..., 64:128], dU)
+        dgrad(2, dhyper[..., 128:160], T[..., 0:64], dT[..., 0:64], 0)
+        wgrad(2, T[..., 0:64], dhyper[..., 128:160])
+        dgrad(3, dhyper[..., 160:192], T[..., 0:64], dT[..., 0:64], 1)
+        wgrad(3, T[..., 0:64], dhyper[..., 160:192])
+        call("danhip_avgpool2x2s1_same_bwd_strided", _vptr(dhyper[..., 64:128]), 256, _vptr(dT[..., 128:192]), 192, N, H, W, 64, stream())
+        if need_dx:
+            dgrad(1, dT, xmask, xbuf, 1)
+        wgrad(1, x, dT)
+        if need_dx:
+            dgrad(0, dhyper[..., 0:64], xmask, xbuf, 1)
+        wgrad(0, x, dhyper[..., 0:64])
+        if GRAD_READY_HOOK is not None:
+            for p_ in ctx.hook_order:                            # all of the block's gradients are issued: declare them in reverse creation order
+                GRAD_READY_HOOK(p_)
+        return (dx_ret, None, None, None, None) + tuple(grads)
+
+
+_CB_LAST = {}
+
+
+def context_block(x, params, hook_order, trace_params=None):
+    """params: eight (w, b) pairs in the order b1, cat(b3 | b4 | b2), b3a (3x1), b3b (1x3), b43 (3x3), b4a (3x1), b4b (1x3), res;
+    hook_order: the block's kernel Parameters in reverse creation order (data-parallel gradient buckets); trace_params: {"b1", "b2", "b3",
+    "b3a", "b3b", "b4", "b43", "b4a", "b4b", "res"} -> kernel Parameter (ops.TRACE: tests).  -> out (with a gradient slot)."""
+    track = torch.is_grad_enabled()
+    handles, flat = [], []
+    for w, b in params:
+        wp = w if (isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad")) else None
+        bp = b if (isinstance(b, torch.nn.Parameter) or hasattr(b, "_danhip_grad")) else None
+        handles.append((wp, bp))
+        flat += [w, b]
+    yslot = _new_slot(track)
+    out = _ContextBlock.apply(x, _slot_of(x) if (track and x.requires_grad) else None, yslot, handles, hook_order, *flat)
+    if TRACE is not None and trace_params:
+        for k, prm in trace_params.items():
+            TRACE[id(prm)] = _CB_LAST[k].detach().contiguous()
+        _CB_LAST.clear()
+    if yslot is not None:
+        yslot.__init__(out, False)
+        out._dh_slot = yslot
+    return out
+
+
 class _BatchNorm(torch.autograd.Function):
     """tf.layers.batch_normalization(training=True) (+ optional ReLU) over NHWC bf16 — net/sfd_net.py:91-119."""
 
