@@ -153,7 +153,7 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--global-batch", type=int, default=0,
@@ -169,8 +169,9 @@ def main():
                     help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
                          "fractional, spread-out positions (SURVEY 8d asks for a second run at R = 2)")
     ap.add_argument("--no-serialized-roofline", action="store_true",
-                    help="skip the two extra steps that time the dominant kernel with the weight-gradient stream off (use under rocprofv3 so "
-                         "its per-kernel averages cover the timed region's launches only)")
+                    help="skip every step outside the warm-up and the timed region: the two that time the dominant kernel with the weight-gradient "
+                         "stream off and the repeat without per-launch events (use under rocprofv3 so its per-kernel totals cover warm-up + timed "
+                         "steps only)")
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
@@ -290,7 +291,7 @@ def main():
     # What the per-launch HIP events of the timed region cost: the same K steps again with NO event recorded, same
     # barriers.  Reported beside `value` (which stays the region the roofline events were taken in); every rank runs it.
     dt_noev = None
-    if prof is not None and not args.graph:
+    if prof is not None and not args.graph and not args.no_serialized_roofline:       # (skipped with the other extra steps under rocprofv3)
         for _ in range(2):
             trainer.train_step(*step_args)
         barrier()

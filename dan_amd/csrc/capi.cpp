@@ -28,21 +28,18 @@ extern "C" int danhip_act_dtype(void) {
 }
 
 // ---- kernel-selection switches (process-wide; initial values from the environment): danhip_set_option / danhip_get_option.
-//   "halo2"      DANHIP_HALO2       0 (default) / 1: 3x3 convolutions that fill 16 x 32 pixel tiles run on conv_halo2.hip instead of conv_halo.hip
 //   "splitk"     DANHIP_SPLITK      1 (default) / 0: split-K for maps with too few output tiles (when the caller passes scratch)
 //   "wgrad_slab" DANHIP_WGRAD_SLAB  1 (default: short launches) / 0 (never) / 2 (always): weight-gradient partials as stores + combine pass
 //   "halo_b2"    DANHIP_HALO_B2     0 (default) / 1: second workgroup barrier per step in conv_halo.hip (the round-2 form; A/B switch)
 //   "wgrad_b2"   DANHIP_WGRAD_B2    0 (default) / 1: the same for conv_wgrad_rows.hip / conv_wgrad_pw.hip
 //   "halo_general_epilogue" DANHIP_HALO_GENERAL_EPILOGUE  0 (default) / 1: conv_halo.hip always takes its general epilogue (A/B of the lean one)
-//   "halo2_ablate" DANHIP_HALO2_ABLATE  timing experiments of conv_halo2.hip (bit mask; 16 = second barrier per step)
 namespace {
 // Thread safety ("no mutable globals" on the data path): the table is filled from the environment exactly once
 // (std::call_once, before the first read or write), every value is a relaxed atomic, and the kernels' host launchers read an option
 // once per call into their argument struct - a concurrent danhip_set_option changes which FORM later launches take (all forms are
 // result-equivalent up to fp32 summation order), never a launch already being assembled.
 struct Opt { const char* name; const char* env; int def; std::atomic<int> value; };
-Opt g_opts[] = {{"halo2", "DANHIP_HALO2", 0, {0}}, {"splitk", "DANHIP_SPLITK", 1, {0}}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, {0}},
-                {"halo2_ablate", "DANHIP_HALO2_ABLATE", 0, {0}}, {"halo_b2", "DANHIP_HALO_B2", 0, {0}},
+Opt g_opts[] = {{"splitk", "DANHIP_SPLITK", 1, {0}}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, {0}}, {"halo_b2", "DANHIP_HALO_B2", 0, {0}},
                 {"wgrad_b2", "DANHIP_WGRAD_B2", 0, {0}}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, {0}},
                 {"deform_bwd_form", "DANHIP_DEFORM_BWD_FORM", 0, {0}}};
 std::once_flag g_opts_once;

@@ -89,10 +89,6 @@ int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s);
 bool danhip_conv_halo_takes_bits(const ConvArgs& a);
 bool danhip_conv_halo_emits_bits(const ConvArgs& a);   // the forward instance for these args writes ConvArgs::bits_out (and pool_bits_out with a fused pool)   // the data-gradient instance for these args reads ConvArgs::mask_bits
 const char* danhip_conv_halo_label(const ConvArgs& a, bool dgrad);
-// Second form of the halo kernel: 16 x 32 pixel tiles x 128 channels, 32-channel chunks (conv_halo2.hip); same return convention.
-int danhip_launch_conv_halo2(const ConvArgs& a, hipStream_t s);
-bool danhip_conv_halo2_eligible(const ConvArgs& a);
-const char* danhip_conv_halo2_label(const ConvArgs& a, bool dgrad);
 // 64 -> 64 channel special case with register-resident weights (conv_halo_c64.hip); same return convention.
 int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s);
 const char* danhip_conv_c64_label(const ConvArgs& a, bool dgrad);   // kernel-instance label or nullptr when not eligible

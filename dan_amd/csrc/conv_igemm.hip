@@ -435,8 +435,6 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   const bool sk = prefer_splitk(a);                    // too few tiles for the persistent kernels: split K over workgroups instead
   if (!sk) {
     if (!view) {
-      const int h2 = danhip_launch_conv_halo2(a, s);   // 3x3 / stride-1, Cout % 128 == 0, maps that fill 16 x 32 tiles: 512-pixel halo tiles
-      if (h2 <= 0) return h2;
       const int hr = danhip_launch_conv_halo(a, s);    // 3x3 / stride-1 on large maps: halo-reuse kernel
       if (hr <= 0) return hr;
     }
@@ -636,13 +634,6 @@ extern "C" const char* danhip_conv_kernel_label(const danhip_conv_desc* d, int w
     const char* cl = danhip_conv_c64_label(a, which == 1);
     if (cl) return cl;
     const bool sk = !noscratch && wants_splitk(a);     // (callers that pass the scratch buffer: dan_amd.ops always does)
-    if (!sk) {
-      ConvArgs a2 = a;
-      if (which == 1) { if (masked) a2.mask = &dummy_mask; }
-      else { static const float one1 = 1.f; a2.bias = &one1; a2.relu = 1; }
-      const char* h2 = danhip_conv_halo2_label(a2, which == 1);
-      if (h2 && danhip_conv_halo_label(a, which == 1)) return h2;
-    }
     const char* hl = sk ? nullptr : danhip_conv_halo_label(a, which == 1);
     if (hl) return hl;
     if (which == 1) { if (masked) a.mask = &dummy_mask; }
@@ -820,7 +811,7 @@ extern "C" int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_
   a.bias = &one; a.relu = 1;
   if (danhip_conv_c8_label(a)) return with_pool ? 0 : 1;        // the first layer's store-bound kernel writes the mask beside its output
   if (danhip_conv_c64_eligible(a)) return 0;
-  if (!danhip_conv_halo_emits_bits(a)) return 0;       // (every shape conv_halo2.hip takes passes this test too: Cout % 128 == 0)
+  if (!danhip_conv_halo_emits_bits(a)) return 0;
   if (with_pool) { a.pool_y = &dummy; if (!danhip_conv_halo_pool_fusable(a)) return 0; }
   return 1;
 }
@@ -837,7 +828,6 @@ extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint
   a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
   a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits;
   if (danhip_conv_c8_label(a)) return danhip_launch_conv_c8(a, (hipStream_t)stream);
-  { const int h2 = danhip_launch_conv_halo2(a, (hipStream_t)stream); if (h2 <= 0) return h2; }
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }
 
@@ -936,6 +926,5 @@ extern "C" int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint
   a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = nullptr; a.mask_bits = relu_bits; a.resid = nullptr; a.y = dx;
   a.relu = 0; a.out_f32 = 0; a.accumulate = accumulate;
   if (danhip_conv_c64_eligible(a)) return danhip_launch_conv_c64(a, (hipStream_t)stream);
-  { const int h2 = danhip_launch_conv_halo2(a, (hipStream_t)stream); if (h2 <= 0) return h2; }
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }

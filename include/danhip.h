@@ -42,16 +42,15 @@ extern "C" {
 
 const char* danhip_last_error(void);
 int danhip_version(void);
-/* Process-wide kernel-selection switches (defaults from the environment variables in brackets):
- *   "halo2"      [DANHIP_HALO2, 0]       1: 3x3 / stride-1 convolutions with Cout % 128 == 0 on maps that fill 16 x 32 pixel tiles run on the 512-pixel-tile
- *                                           kernel (csrc/conv_halo2.hip) instead of csrc/conv_halo.hip
+/* Process-wide kernel-FORM switches (A/B and test hooks; defaults from the environment variables in brackets, read once; values are
+ * atomics and a launcher reads a switch once per call):
  *   "splitk"     [DANHIP_SPLITK, 1]      0: never split K (danhip_conv2d_workspace_bytes answers 0)
  *   "wgrad_slab" [DANHIP_WGRAD_SLAB, 1]  0: weight-gradient partial sums always by fp32 atomics; 2: always stores + combine pass; 1: by launch length
  *   "halo_b2"    [DANHIP_HALO_B2, 0]     1: a second workgroup barrier per step in csrc/conv_halo.hip (the round-2 form; timing A/B only)
  *   "wgrad_b2"   [DANHIP_WGRAD_B2, 0]    1: the same for csrc/conv_wgrad_rows.hip and csrc/conv_wgrad_pw.hip
  *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 form by the offsets' statistics (on the device), 1 always the
  *                                           gather form with a +-2 px window, 2 always the fp32-atomics scatter form, 3 gather form, +-1 px
- *   "halo2_ablate" [DANHIP_HALO2_ABLATE, 0]  timing experiments of csrc/conv_halo2.hip (bit mask; results are WRONG with bits 1, 2, 4, 8 set)
+ *   "halo_general_epilogue" [DANHIP_HALO_GENERAL_EPILOGUE, 0]  1: csrc/conv_halo.hip always takes its general epilogue (A/B of the lean one)
  * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
 int danhip_set_option(const char* name, int value);
 int danhip_get_option(const char* name);

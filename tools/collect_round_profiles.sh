@@ -12,7 +12,7 @@ python3 bench.py > $OUT/s3fd_b16_bench_line.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o s3fd -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/s3fd_b16_bench_line_under_rocprof.json 2> $OUT/prof.err
 cp $OUT/prof/*kernel_stats.csv $OUT/s3fd_b16_kernel_stats.csv 2>/dev/null || find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/s3fd_b16_kernel_stats.csv \;
-bash tools/pmc_bench.sh r3 > $OUT/pmc.log 2>&1
+bash tools/pmc_bench.sh r4 > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc_bench_traffic.json $OUT/ 2>/dev/null
 : > $OUT/models_bench_lines.jsonl
 for m in pb dan dan_deform; do

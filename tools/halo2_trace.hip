@@ -1,9 +1,9 @@
-// Where does a step of conv_halo2.hip go?  Shader-clock stamps of workgroup 0 (wave 0 of group A, wave 4 of group B) at four points of every
+// Where does a step of the two-wave-group kernels go?  (named after the round-3 experiment conv_halo2.hip, removed in round 4: it ended 2-4 % /
+// 15-20 % behind conv_halo.hip; profiles/r3 keeps its traces)  Shader-clock stamps of workgroup 0 (wave 0 of group A, wave 4 of group B) at four points of every
 // step of the first 128 steps, kept in LDS (a global store would count in vmcnt and perturb the counted waits) and dumped at the end:
 //   group A:  0 step start   1 memory phase done (fragments read, DMA issued, counted wait passed)   2 past barrier b1   3 MFMAs issued
 //   group B:  0 step start   1 MFMAs issued   2 past barrier b1 (counted wait before it)             3 memory phase done
 // Build (the kernel source is compiled INTO this program with -DH2_TRACE; the library build has no stamps):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DH2_TRACE -I dan_amd/csrc -o tools/halo2_trace tools/halo2_trace.hip
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRACE_HALO1 -I dan_amd/csrc -o tools/halo1_trace tools/halo2_trace.hip     (conv_halo.hip)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTRACE_WGRAD -I dan_amd/csrc -o tools/wgrad_trace tools/halo2_trace.hip     (conv_wgrad_rows.hip)
 // Run:  tools/halo2_trace [fwd|dgrad] [N H W C Co]       (default: conv3_2 of the benchmark, 16 x 160 x 160 x 256 -> 256)
@@ -23,11 +23,8 @@
 #include "../dan_amd/csrc/conv_halo.hip"
 #define TRACE_LAUNCH danhip_launch_conv_halo
 #define TRACE_BUFFER h_trace_buffer
-bool danhip_conv_halo2_eligible(const ConvArgs&) { return false; }
 #else
-#include "../dan_amd/csrc/conv_halo2.hip"
-#define TRACE_LAUNCH danhip_launch_conv_halo2
-#define TRACE_BUFFER h2_trace_buffer
+#error "build with -DTRACE_HALO1 (conv_halo.hip) or -DTRACE_WGRAD (conv_wgrad_rows.hip): the 512-pixel-tile experiment conv_halo2.hip was removed in round 4"
 #endif
 
 #include <cstdarg>
