@@ -903,14 +903,19 @@ def concat(tensors):
 
 
 class _Add(torch.autograd.Function):
-    """a + b of two activations (the context module's residual, net/danet.py:913-918): backward delivers dY into both producers' slots,
-    each with its own ReLU backward folded in."""
+    """a + b of two activations (the context module's residual, net/danet.py:913-918 / net/danet_deform.py:286-290): one library kernel forward
+    (danhip_add16); backward delivers dY into both producers' slots, each with its own ReLU backward folded in — in ONE pass over dY
+    (danhip_residual_bwd) when `a` is a ReLU output receiving its first delivery (the shape of every residual in the reference graphs)."""
 
     @staticmethod
     def forward(ctx, a, b, sa, sb, yslot):
         ctx.slots, ctx.yslot = (sa, sb), yslot
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*[t if (s is not None and s.is_relu) else None for t, s in ((a, sa), (b, sb))])
+        if a.dtype == ACT and a.is_contiguous() and b.is_contiguous() and a.is_cuda and a.numel() % 8 == 0:
+            out = torch.empty_like(a)
+            call("danhip_add16", ptr(a), ptr(b), ptr(out), a.numel(), stream())
+            return out
         return a + b
 
     @staticmethod
@@ -920,6 +925,14 @@ class _Add(torch.autograd.Function):
             g = dy.contiguous() if g is None else g.add_(dy)
         if g is None:
             return (None,) * 5
+        sa, sb = ctx.slots
+        ta, tb = ctx.saved_tensors
+        if (sa is not None and sb is not None and sa.is_relu and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and sa.buf is None
+                and g.numel() % 8 == 0):
+            bufa, _ = sa.target()                                # first delivery into a's slot: written, not accumulated
+            bufb, accb = sb.target()
+            call("danhip_residual_bwd", ptr(g), ptr(ta), ptr(tb) if sb.is_relu else None, ptr(bufa), ptr(bufb), accb, g.numel(), stream())
+            return None, None, None, None, None
         out = []
         for i, (s, t) in enumerate(zip(ctx.slots, ctx.saved_tensors)):
             if not ctx.needs_input_grad[i]:

