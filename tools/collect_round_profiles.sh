@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-python3 bench.py > $OUT/s3fd_b16_bench_line.json 2> $OUT/bench.err
+python3 bench.py --steps 20 > $OUT/s3fd_b16_bench_line.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o s3fd -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/s3fd_b16_bench_line_under_rocprof.json 2> $OUT/prof.err
 cp $OUT/prof/*kernel_stats.csv $OUT/s3fd_b16_kernel_stats.csv 2>/dev/null || find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/s3fd_b16_kernel_stats.csv \;
