@@ -8,6 +8,9 @@
 
 One "step" = one optimisation step on a synthetic batch of 16 images per GPU (BASELINE.json configs[1]); inputs
 (uint8 images, encoded anchor targets) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Regions, in order: W warm-up steps | the TIMED region (exactly K steps between barrier + synchronize pairs: `value`, `ms_per_step`) | the
+roofline region (the same K steps again with two HIP events per convolution launch: `roofline`, `kernels`, `event_recording`) | two steps
+with the weight-gradient stream off (`roofline.serialized`) | inference / target-encoder / CPU-baseline legs.
 """
 import argparse
 import json
@@ -164,14 +167,15 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the training step (incl. the bucketed RCCL all-reduce when N > 1) in a hipGraph; off by default")
     ap.add_argument("--eager", action="store_true", help="never capture the step (below 8 images per GPU the step is host-launch-bound and the default is "
                     "hipGraph replay: ~180 launches of 5-30 us kernels)")
+    ap.add_argument("--events-steps", type=int, default=0, help="steps of the roofline (event-recording) region behind the timed one (default: K; 2 for a graph run)")
     ap.add_argument("--no-eval", action="store_true", help="skip the inference-FPS leg (the 'eval FPS' half of BASELINE.json's metric)")
     ap.add_argument("--deform-offsets", type=float, default=0.0,
                     help="dan_deform: set the (zero-initialised) offset convs' biases ~ U(-R, R) pixels so the sampling kernels run on "
                          "fractional, spread-out positions (SURVEY 8d asks for a second run at R = 2)")
     ap.add_argument("--no-serialized-roofline", action="store_true",
-                    help="skip every step outside the warm-up and the timed region: the two that time the dominant kernel with the weight-gradient "
-                         "stream off and the repeat without per-launch events (use under rocprofv3 so its per-kernel totals cover warm-up + timed "
-                         "steps only)")
+                    help="keep the steps outside the warm-up and the timed region to ONE: skips the two that time the dominant kernel with the "
+                         "weight-gradient stream off and shortens the event-recording region to one step (use under rocprofv3: its per-kernel totals "
+                         "then cover warm-up + K + 1 steps)")
     ap.add_argument("--model", default="sfd", choices=["sfd", "pb", "dan", "dan_deform"],
                     help="sfd = BASELINE.json configs[1] (the metric's single-GPU configuration); the others are the per-GPU shards of configs[2..4]")
     args = ap.parse_args()
@@ -255,25 +259,33 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(*step_args)
     barrier()
-    ops.PROFILE = {} if not args.graph else None      # per-kernel events cannot be recorded inside a replayed graph
-    ops.PROFILE_BYTES = {} if ops.PROFILE is not None else None
+    # ---- the timed region: EXACTLY K steps between two barrier + synchronize pairs, nothing else in it.  (Rounds 1-3 also recorded two HIP
+    # events per convolution launch in here for the roofline; measured in round 4, that cost 4 % of the step - 13.70 against 13.16 ms - so
+    # the events moved to a second, equally long region right behind this one: VERDICT r3 item 9.)
+    ops.PROFILE = ops.PROFILE_BYTES = None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_step(*step_args)
     barrier()
     dt = time.perf_counter() - t0
+    # ---- the roofline region: the same steps again, every convolution launch bracketed by HIP events on its launch stream (eager launches
+    # only: events cannot be recorded inside a replayed graph, so a graph run records them over two eager steps)
+    saved_graph0 = trainer._graph
+    prof_steps = args.steps if not args.graph else 2
+    if args.no_serialized_roofline:                   # (profiling runs: one step is enough to name the dominant kernel)
+        prof_steps = 1
+    if args.events_steps:
+        prof_steps = args.events_steps
+    trainer._graph = None
+    ops.PROFILE, ops.PROFILE_BYTES = {}, {}
+    t1 = time.perf_counter()
+    for _ in range(prof_steps):
+        trainer.train_step(*step_args)
+    barrier()
+    dt_prof = time.perf_counter() - t1
     prof, ops.PROFILE = ops.PROFILE, None
     prof_bytes, ops.PROFILE_BYTES = ops.PROFILE_BYTES, None
-    prof_steps = args.steps
-    if prof is None:                                   # graph mode: the roofline events come from two eager steps after the timed region
-        trainer._graph = None
-        ops.PROFILE, ops.PROFILE_BYTES = {}, {}
-        prof_steps = 2
-        for _ in range(prof_steps):
-            trainer.train_step(*step_args)
-        barrier()
-        prof, ops.PROFILE = ops.PROFILE, None
-        prof_bytes, ops.PROFILE_BYTES = ops.PROFILE_BYTES, None
+    trainer._graph = saved_graph0
     # Weight gradients run on a second stream next to the data gradients (ops.wgrad_overlap_begin), so the event-bracketed duration of
     # a backward kernel in the timed region includes the time it shares the chip.  For reference the same kernels are also timed
     # serialised (second stream off) in two extra steps AFTER the timed region; that figure is reported beside the in-region one.
@@ -288,24 +300,10 @@ def main():
         prof_serial, ops.PROFILE = ops.PROFILE, None
         trainer._graph = saved_graph
         ops.WGRAD_STREAM = True
-    # What the per-launch HIP events of the timed region cost: the same K steps again with NO event recorded, same
-    # barriers.  Reported beside `value` (which stays the region the roofline events were taken in); every rank runs it.
-    dt_noev = None
-    if prof is not None and not args.graph and not args.no_serialized_roofline:       # (skipped with the other extra steps under rocprofv3)
-        for _ in range(2):
-            trainer.train_step(*step_args)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.train_step(*step_args)
-        barrier()
-        dt_noev = time.perf_counter() - t1
     if multi:
-        t = torch.tensor([dt, dt_noev if dt_noev is not None else 0.0], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_prof], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0].item())
-        if dt_noev is not None:
-            dt_noev = float(t[1].item())
+        dt, dt_prof = float(t[0].item()), float(t[1].item())
 
     # ---- inference leg ("eval FPS"): eval_sfd.py / eval_dan.py single-scale graph (forward + softmax + decode [+ routing]) on the same
     # resident images, outside the timed training region; every rank runs it, the slowest rank's time counts
@@ -411,7 +409,7 @@ def main():
                                              if traffic and prof_bytes and prof_bytes.get(label) else None),
                 "launches_per_step": n // prof_steps,
                 "avg_launch_ms": round(ms / n, 4), "flop_per_launch": fl / n,
-                "share_of_step_time": round(ms / prof_steps / (dt / args.steps * 1e3), 4), "calibrated": calib,
+                "share_of_step_time": round(ms / prof_steps / (dt_prof / prof_steps * 1e3), 4), "calibrated": calib,
                 "whole_step": {"what": "all convolution launches of the timed region (forward, data and weight gradients): algorithmic FLOP / wall time",
                                "tflop_per_step": round(sum(f for _, _, _, f in stats) / prof_steps / 1e12, 3),
                                "achieved": round(sum(f for _, _, _, f in stats) / prof_steps / (dt / args.steps) / 1e12, 1),
@@ -441,9 +439,9 @@ def main():
                        "rccl": rccl_info,
                        "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if multi else None,
                        "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and ops.WGRAD_STREAM)},
-            "event_recording": ({"ms_per_step_without_events": round(dt_noev / args.steps * 1e3, 3), "value_without_events": round(world * B * args.steps / dt_noev, 3),
-                                 "what": "the same K steps repeated after the timed region with no per-launch HIP event recorded; `value` / `ms_per_step` are the "
-                                         "region the roofline events were recorded in"} if dt_noev else None),
+            "event_recording": {"steps": prof_steps, "ms_per_step": round(dt_prof / prof_steps * 1e3, 3), "launch": "eager",
+                                "what": "the roofline region: the same steps repeated right after the timed region with two HIP events per convolution launch "
+                                        "(the timed region records none); its own wall time per step shows what the events cost"},
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],

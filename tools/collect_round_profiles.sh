@@ -29,18 +29,18 @@ done
 python3 bench.py --model dan --size 1024 --batch-per-gpu 8 --steps 5 --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
 DANHIP_DTYPE=fp16 python3 bench.py --model dan_deform --size 1024 --batch-per-gpu 8 --steps 5 --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
 DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_dan1024 -o s -- python3 bench.py --eager --model dan --size 1024 --batch-per-gpu 8 --steps 3 --warmup 1 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_dan1024.log 2>&1
-python3 tools/prof_db.py $OUT/serial_dan1024/s_results.db 4 40 > $OUT/dan_1024_b8_serialized_kernels.txt
+python3 tools/prof_db.py $OUT/serial_dan1024/s_results.db 5 40 > $OUT/dan_1024_b8_serialized_kernels.txt
 rm -rf $OUT/serial_dan1024
 DANHIP_DTYPE=fp16 DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_dd1024 -o s -- python3 bench.py --eager --model dan_deform --size 1024 --batch-per-gpu 8 --steps 3 --warmup 1 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_dd1024.log 2>&1
-python3 tools/prof_db.py $OUT/serial_dd1024/s_results.db 4 40 > $OUT/dan_deform_fp16_1024_b8_serialized_kernels.txt
+python3 tools/prof_db.py $OUT/serial_dd1024/s_results.db 5 40 > $OUT/dan_deform_fp16_1024_b8_serialized_kernels.txt
 rm -rf $OUT/serial_dd1024
 # the per-rank shape of an 8-GPU strong-scaling run (2 images per GPU): serialized kernel list
 DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_b2 -o s -- python3 bench.py --eager --batch-per-gpu 2 --steps 4 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_b2.log 2>&1
-python3 tools/prof_db.py $OUT/serial_b2/s_results.db 6 50 > $OUT/sfd_b2_serialized_kernels.txt
+python3 tools/prof_db.py $OUT/serial_b2/s_results.db 7 50 > $OUT/sfd_b2_serialized_kernels.txt
 rm -rf $OUT/serial_b2
 for m in sfd dan dan_deform pb; do
   DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_$m -o s -- python3 bench.py --eager --model $m --steps 4 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_$m.log 2>&1
-  python3 tools/prof_db.py $OUT/serial_$m/s_results.db 6 60 > $OUT/${m}_b16_serialized_kernels.txt
+  python3 tools/prof_db.py $OUT/serial_$m/s_results.db 7 60 > $OUT/${m}_b16_serialized_kernels.txt
   rm -rf $OUT/serial_$m
 done
 rm -rf $OUT/prof
