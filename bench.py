@@ -45,12 +45,14 @@ def rccl_debug_setup(rank):
     communicator shape and the algorithm / protocol chosen per collective size) at a per-rank file.  Defaults only - a caller's own
     NCCL_DEBUG* settings win.  Returns the file rank 0 parses after the run (rccl_debug_parse), or None."""
     import tempfile
+    if os.environ.get("DANHIP_BENCH_RCCL_LOG", "1") == "0":
+        return None
     if "NCCL_DEBUG_FILE" in os.environ:
         return os.environ["NCCL_DEBUG_FILE"].replace("%h", "host").replace("%p", str(os.getpid()))
-    if "NCCL_DEBUG" in os.environ and os.environ["NCCL_DEBUG"].upper() not in ("INFO", "TRACE"):
-        return None
     path = os.path.join(tempfile.gettempdir(), "danhip_rccl_%d_%d.log" % (os.getpid(), rank))
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    # (the GPU boxes export NCCL_DEBUG=VERSION: anything quieter than INFO is raised - the log goes to the file, not to the terminal)
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        os.environ["NCCL_DEBUG"] = "INFO"
     os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING,GRAPH")
     os.environ["NCCL_DEBUG_FILE"] = path
     return path
@@ -61,10 +63,10 @@ def rccl_debug_parse(text):
     is best effort (None / empty when the log has no such line: e.g. a one-rank group never tunes a collective)."""
     import re
     out = {"version": None, "nranks": None, "nnodes": None, "channels": None, "algo": {}, "proto": {}, "transport": []}
-    m = re.search(r"(?:RCCL|NCCL) version ([0-9][^\s]*)", text)
+    m = re.search(r"(?:RCCL|NCCL) version\s*:?\s*([0-9][^\s]*)", text)
     if m:
         out["version"] = m.group(1)
-    m = re.search(r"nranks (\d+)", text) or re.search(r"nRanks (\d+)", text)
+    m = re.search(r"nranks (\d+)", text) or re.search(r"nRanks 0*(\d+)", text)
     if m:
         out["nranks"] = int(m.group(1))
     m = re.search(r"nNodes (\d+)", text) or re.search(r"nnodes (\d+)", text, re.I)
@@ -80,6 +82,12 @@ def rccl_debug_parse(text):
         key = "%s/%dMiB" % (coll, int(nbytes) >> 20) if int(nbytes) >= (1 << 20) else "%s/%dB" % (coll, int(nbytes))
         out["algo"][key] = algo_names.get(al, al)
         out["proto"][key] = proto_names.get(pr, pr)
+    # other spellings of the same information ("... algorithm RING protocol LL128 ...")
+    for coll, al, pr in re.findall(r"(AllReduce|ReduceScatter|AllGather|Broadcast)[^\n]*?[Aa]lgorithm[ =:]+(\w+)[^\n]*?[Pp]rotocol[ =:]+(\w+)", text):
+        out["algo"].setdefault(coll, al)
+        out["proto"].setdefault(coll, pr)
+    out["rings"] = len(set(re.findall(r"Ring (\d+) :", text))) or None
+    out["log_lines"] = text.count("\n")
     for t in re.findall(r"via ((?:P2P|SHM|NET)[/\w]*)", text):
         if t not in out["transport"]:
             out["transport"].append(t)

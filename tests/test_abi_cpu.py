@@ -272,5 +272,14 @@ box:123:140 [0] NCCL INFO AllReduce: 4096 Bytes -> Algo 0 proto 0 time 9.1
     assert info["algo"]["AllReduce/32MiB"] == "Ring" and info["proto"]["AllReduce/32MiB"] == "Simple"
     assert info["algo"]["AllReduce/4096B"] == "Tree" and info["proto"]["AllReduce/4096B"] == "LL"
     assert info["transport"] == ["P2P/IPC"]
+    # the line shapes RCCL 2.26 (ROCm 7.0 wheel) prints on the GPU boxes, one-rank group
+    info = b.rccl_debug_parse("""
+runc:1:1 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6
+runc:1:2 [0] NCCL INFO Ring 126 : 0 -> 0 -> 0 comm 0x63 nRanks 01 busId a7000
+runc:1:2 [0] NCCL INFO Ring 127 : 0 -> 0 -> 0 comm 0x63 nRanks 01 busId a7000
+runc:1:2 [0] NCCL INFO 128 coll channels, 128 collnet channels, 0 nvls channels, 64 p2p channels, 128 p2p channels per peer
+runc:1:2 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x63 rank 0 nranks 1 cudaDev 0 nvmlDev 0 busId a7000 commId 0x52 - Init COMPLETE
+""")
+    assert info["version"].startswith("2.26.6") and info["nranks"] == 1 and info["channels"] == 128 and info["rings"] == 2
     empty = b.rccl_debug_parse("nothing here")
     assert empty["nranks"] is None and empty["algo"] == {}
