@@ -167,6 +167,8 @@ def lib():
         L.danhip_deform_conv_workspace_bytes.argtypes = [I32, I32, I32, I32, I32, I32, I32, ctypes.c_int]
         L.danhip_deform_sample_bwd_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_deform_sample_bwd_workspace_bytes.argtypes = [I32, I32, I32, I32]
+        L.danhip_conv2d_fwd_pool_only.restype = ctypes.c_int
+        L.danhip_conv2d_fwd_pool_only.argtypes = [DESC]
         L.danhip_conv2d_fwd_emits_bits.restype = ctypes.c_int
         L.danhip_conv2d_fwd_emits_bits.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_data_takes_bits.restype = ctypes.c_int

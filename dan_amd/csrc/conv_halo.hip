@@ -507,8 +507,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // store) and no mode branches per fragment.  The epilogue is instruction-issue bound -- both waves of a SIMD run theirs at the
         // same time -- so its length is its instruction count (tools/halo2_trace.hip -DTRACE_HALO1).
         constexpr unsigned OOB = 0x80000000u;
+        // (a.y == NULL - the pool-only inference call, danhip_conv2d_fwd_pool(y = NULL) - makes the descriptor ZERO bytes long: every store
+        // of the full-resolution map is out of range and dropped by the hardware, without a branch)
         const __amdgpu_buffer_rsrc_t rsrc_y =
-            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co * 2u), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y ? (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co * 2u) : 0, 0x00020000);
         unsigned pix[NPT];
         bool okp[NPT];
 #pragma unroll
@@ -980,7 +982,8 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.crem = (a.C % 64) / 8;
   g.b2 = danhip_option("halo_b2");
   g.fast = (NCU == 0 && !a.out_f32 && !a.mask && !a.resid && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
-            !danhip_option("halo_general_epilogue")) ? 1 : 0;
+            (!danhip_option("halo_general_epilogue") || !a.y)) ? 1 : 0;
+  if (!a.y && !(g.fast && POOL)) { danhip_set_error("conv_halo: y == NULL (pool-only) needs the pool-fusing instance with the lean epilogue"); return DANHIP_EINVAL; }
 #ifdef H_TRACE
   g.trace = h_trace_buffer();
 #endif

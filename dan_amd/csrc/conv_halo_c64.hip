@@ -270,7 +270,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // (mask and old value were folded into acc above)
           }
           const u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
+          if (a.y)            // (uniform; NULL = the pool-only inference call: the full-resolution map is never written)
+            __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
           pk[p] = tt;
         }
 #pragma unroll

@@ -788,16 +788,30 @@ extern "C" int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t*
                                       uint16_t* pool_y, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  DH_REQUIRE(x && wf_packed && bias && y && pool_y, DANHIP_EINVAL, "conv2d_fwd_pool: null pointer");
+  DH_REQUIRE(x && wf_packed && bias && pool_y, DANHIP_EINVAL, "conv2d_fwd_pool: null pointer");
   DH_REQUIRE(d->Cout % 8 == 0, DANHIP_EINVAL, "conv2d_fwd_pool: Cout must be a multiple of 8");
   ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = nullptr; a.y = y;
   a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
   const bool fused = danhip_conv_pool_fusable(a);
+  // y == NULL: only the pooled map is wanted (inference: nothing reads the full-resolution activation of conv1_2 / conv2_2) - the fusing
+  // kernels then skip its stores; ask danhip_conv2d_fwd_pool_only(d) first
+  DH_REQUIRE(y || fused, DANHIP_EINVAL, "conv2d_fwd_pool: y == NULL needs a kernel that pools in its epilogue (danhip_conv2d_fwd_pool_only)");
   a.pool_y = fused ? pool_y : nullptr;
   rc = launch_conv(a, (hipStream_t)stream);
   if (rc || fused) return rc;
   return danhip_maxpool2x2_fwd(y, pool_y, d->N, d->Ho, d->Wo, d->Cout, stream);
+}
+
+extern "C" int danhip_conv2d_fwd_pool_only(const danhip_conv_desc* d) {
+  if (!d || check_desc(d) != DANHIP_OK || d->Cout % 8 != 0) return 0;
+  static const float one = 1.f;
+  static bf16_t dummy = 0;
+  ConvArgs a = fwd_args(d);
+  a.bias = &one; a.relu = 1; a.pool_y = &dummy;
+  if (!danhip_conv_pool_fusable(a)) return 0;
+  if (danhip_conv_c64_eligible(a)) return 1;
+  return (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) ? 1 : 0;      // (the halo kernel's lean epilogue: the one with descriptor stores)
 }
 
 // conv_relu (+ the fused 2x2 max-pool when pool_y is given) that ALSO writes the ReLU bit masks of its outputs (danhip_relu_bits layout) from

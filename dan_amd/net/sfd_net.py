@@ -25,19 +25,19 @@ class VGG16Backbone(object):
         w = self.vs.get((name or "l2_normalize") + "/weight", (inputs.shape[-1],), init_value)
         return ops.l2_normalize(inputs, w)
 
-    def conv2d(self, inputs, filters, kernel_size, strides, scope, relu, out_f32=False, residual=None, init="glorot", pool=False):
+    def conv2d(self, inputs, filters, kernel_size, strides, scope, relu, out_f32=False, residual=None, init="glorot", pool=False, pool_only=False):
         kh, kw = kernel_size
         s = strides[0] if isinstance(strides, (tuple, list)) else strides
         cin = inputs.shape[-1]
         w = self.vs.get(scope + "/kernel", (kh, kw, getattr(inputs, "_real_channels", cin), filters), init)
         b = self.vs.get(scope + "/bias", (filters,), "zeros")
-        return ops.conv2d(inputs, w, b, stride=s, relu=relu, out_f32=out_f32, residual=residual, pool=pool)
+        return ops.conv2d(inputs, w, b, stride=s, relu=relu, out_f32=out_f32, residual=residual, pool=pool, pool_only=pool_only)
 
-    def conv_relu(self, inputs, filters, kernel_size, strides, scope, padding="same", dilate_rate=1, reuse=None, pool=False):
+    def conv_relu(self, inputs, filters, kernel_size, strides, scope, padding="same", dilate_rate=1, reuse=None, pool=False, pool_only=False):
         """net/sfd_net.py:81-89.  pool=True (not in the reference signature): the caller max-pools the result next, so the conv
         kernel produces the pooled map in its epilogue (ops.max_pool_2x2 then just hands it over)."""
         assert padding == "same" and dilate_rate == 1
-        return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True, pool=pool)
+        return self.conv2d(inputs, filters, kernel_size, strides, scope + "/conv2d", relu=True, pool=pool, pool_only=pool_only)
 
     # ---- batch-norm surface (net/sfd_net.py:91-119): defined on every VGG16Backbone, used by no VGG graph ------------
     def _bn(self, inputs, scope, training, relu):
@@ -70,10 +70,13 @@ class VGG16Backbone(object):
         assert padding == "same" and dilate_rate == 1
         return self._bn(self._conv_nobias(inputs, filters, kernel_size, strides, scope), scope, training, relu=False)
 
-    def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None, pool_after=False):
-        """net/sfd_net.py:121-125.  pool_after: the block is followed by max_pooling2d (get_featmaps): fuse it into the last conv."""
+    def conv_block(self, inputs, num_blocks, filters, kernel_size, strides, name, reuse=None, pool_after=False, pool_only=False):
+        """net/sfd_net.py:121-125.  pool_after: the block is followed by max_pooling2d (get_featmaps): fuse it into the last conv.
+        pool_only: nothing but that pool reads the block's output (conv1, conv2) - at inference its full-resolution map is never written."""
         for ind in range(1, num_blocks + 1):
-            inputs = self.conv_relu(inputs, filters, kernel_size, strides, "{0}/{0}_{1}".format(name, ind), pool=pool_after and ind == num_blocks)
+            last = ind == num_blocks
+            inputs = self.conv_relu(inputs, filters, kernel_size, strides, "{0}/{0}_{1}".format(name, ind), pool=pool_after and last,
+                                    pool_only=pool_only and pool_after and last)
         return inputs
 
     def get_featmaps(self, inputs, training=False):
@@ -84,9 +87,9 @@ class VGG16Backbone(object):
         # first, so the L2 normalisation and the head convolutions run on the fp32 kernels (how much of the 16-bit
         # path's box error the heads cause - DESIGN section 4 has the measurement)
         tap = (lambda t: t.float()) if getattr(self, "fp32_heads", False) and not torch.is_grad_enabled() else (lambda t: t)
-        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1", pool_after=True)
+        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1", pool_after=True, pool_only=True)
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2", pool_after=True)
+        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2", pool_after=True, pool_only=True)
         inputs = ops.max_pool_2x2(inputs)
         inputs = self.conv_block(inputs, 3, 256, (3, 3), (1, 1), "conv3", pool_after=True)
         feature_layers.append(self.l2_normalize(tap(inputs), 10, training, "l2_norm_layer_3"))

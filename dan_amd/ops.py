@@ -316,7 +316,8 @@ class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0, xbits=None, bits_out=None):
+    def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0, xbits=None, bits_out=None,
+                pool_only=False):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
@@ -324,6 +325,14 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(N, H, W, C, cout, kh, kw, stride, valid)
         need_bwd = w.requires_grad or x.requires_grad or bool(block_grads)
         wf, wb = packed_weights(d, w, w_param, need_bwd)
+        if pool_only and pool_out is not None and _lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d)):      # (conv2d() passes pool_only only when nothing is tracked)
+            # inference: nothing but the pool reads this activation - the kernel pools in its epilogue and never writes the full-resolution map
+            pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
+            e0 = _prof_begin()
+            call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), None, ptr(pooled), stream())
+            _prof_end(e0, d, 4)
+            pooled._dh_already_pooled = True
+            return pooled
         y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
         e0 = _prof_begin()
         emit = (bits_out is not None and relu and not out_f32 and residual is None and b is not None
@@ -398,7 +407,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 16
+            return (None,) * 17
         db_in_wgrad = need_db and need_dw                        # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -456,7 +465,7 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None and not hooked:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None
 
 
 # ---- fp32 inference path (csrc/f32_infer.hip): every op below accepts fp32 NHWC activations and then runs the fp32 kernels — forward
@@ -480,8 +489,10 @@ def _conv2d_f32(x, w, b, stride, relu, residual, padding):
     return y
 
 
-def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same"):
-    """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up."""
+def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same", pool_only=False):
+    """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up.
+    pool_only=True (with pool, no gradient tracked): the caller promises that ONLY the pooled map is used - where the kernel pools in its
+    epilogue the full-resolution activation is never written and the POOLED tensor is returned (ops.max_pool_2x2 passes it through)."""
     if _f32_infer(x):
         return _conv2d_f32(x, w, b, stride, relu, residual, padding)
     # a plain tensor carrying a gradient sink is a fused block of parameters (FlatParams): cached packing, gradients written in place
@@ -500,7 +511,10 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     xs = _slot_of(x) if track else None
     xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
     bits_out = [] if (track and relu and USE_RELU_BITS) else None
-    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out)
+    y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out,
+                      bool(pool_only and not track))
+    if getattr(y, "_dh_already_pooled", False):
+        return y
     if TRACE is not None and relu and wp is not None:
         TRACE[id(wp)] = y.detach()
     if bits_out:                                         # the forward kernel wrote the masks: the holders of y (and its pooled map) start filled
@@ -563,6 +577,8 @@ def _pool_deliver_ok(ctx, dy):
 
 
 def max_pool_2x2(x):
+    if getattr(x, "_dh_already_pooled", False):           # conv2d(pool=True, pool_only=True) already returned the pooled map
+        return x
     if _f32_infer(x):
         N, H, W, C = x.shape
         y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)

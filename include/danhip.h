@@ -105,6 +105,10 @@ int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16
  * 16-bit type.  3x3 kernels that own whole row pairs per wave pool in their epilogue; other shapes run the pool kernel. */
 int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
                            uint16_t* pool_y, void* stream);
+/* 1 when danhip_conv2d_fwd_pool may be called with y == NULL for this descriptor: only the pooled map is produced and the full-resolution
+ * activation is never written (inference: nothing but the pool reads conv1_2's / conv2_2's output - 839 + 419 MB of stores per batch of
+ * 16 at 640 x 640).  0: the pool is a separate kernel for this shape, y is needed. */
+int danhip_conv2d_fwd_pool_only(const danhip_conv_desc* d);
 
 /* dx = conv_transpose(dy, w) (* (relu_mask > 0) if relu_mask != NULL: fuses the ReLU backward of the layer
  * that produced x).  dy bf16 [N,Ho,Wo,Cout_pad8]; dx bf16 [N,H,W,Cin]. accumulate: dx += instead of = . */

@@ -693,3 +693,24 @@ def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H
         L.danhip_set_option(b"wgrad_slab", 1)
         L.danhip_set_option(b"wgrad_b2", 0)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 96, 64, 64), (2, 64, 64, 128, 128), (1, 45, 67, 128, 256), (2, 40, 40, 512, 512)])
+def test_pool_only_inference_conv_equals_conv_then_pool(N, H, W, Cin, Cout, dev):
+    """Inference (round 4): conv1_2 / conv2_2 feed nothing but their 2x2 pool, so danhip_conv2d_fwd_pool(y = NULL) never writes the
+    full-resolution map where the kernel pools in its epilogue (the 64 -> 64 kernel; the halo kernel's lean epilogue: a zero-length store
+    descriptor).  The pooled map must be bit-identical to conv + pool; shapes whose pool is a separate kernel take the ordinary route."""
+    from dan_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + Cin)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    with torch.no_grad():
+        want = ops.max_pool_2x2(ops.conv2d(x, w, b, relu=True, pool=True))
+        got = ops.max_pool_2x2(ops.conv2d(x, w, b, relu=True, pool=True, pool_only=True))
+    torch.cuda.synchronize()
+    assert got.shape == (N, (H + 1) // 2, (W + 1) // 2, Cout) and torch.equal(got, want)
+    # with a gradient tracked the promise is ignored: the full-resolution map exists for the backward pass
+    xg = x.clone().requires_grad_(True)
+    y = ops.conv2d(xg, w, b, relu=True, pool=True, pool_only=True)
+    assert y.shape == (N, H, W, Cout)
