@@ -2,10 +2,16 @@
 (class VGG16Backbone: l2_normalize, conv_relu, conv_block, get_featmaps, multibox_head; same argument meaning),
 native layout NHWC bf16 activations / fp32 HWIO variables under the reference's TF variable names.
 """
+import os
+
 import torch
 
 from .. import ops
 from .variables import VariableStore
+
+
+# inference: conv1_2 / conv2_2 feed nothing but their pool, so their full-resolution maps are never written (DANHIP_POOL_ONLY=0: A/B)
+POOL_ONLY = os.environ.get("DANHIP_POOL_ONLY", "1") == "1"
 
 
 class VGG16Backbone(object):
@@ -87,9 +93,9 @@ class VGG16Backbone(object):
         # first, so the L2 normalisation and the head convolutions run on the fp32 kernels (how much of the 16-bit
         # path's box error the heads cause - DESIGN section 4 has the measurement)
         tap = (lambda t: t.float()) if getattr(self, "fp32_heads", False) and not torch.is_grad_enabled() else (lambda t: t)
-        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1", pool_after=True, pool_only=True)
+        inputs = self.conv_block(inputs, 2, 64, (3, 3), (1, 1), "conv1", pool_after=True, pool_only=POOL_ONLY)
         inputs = ops.max_pool_2x2(inputs)
-        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2", pool_after=True, pool_only=True)
+        inputs = self.conv_block(inputs, 2, 128, (3, 3), (1, 1), "conv2", pool_after=True, pool_only=POOL_ONLY)
         inputs = ops.max_pool_2x2(inputs)
         inputs = self.conv_block(inputs, 3, 256, (3, 3), (1, 1), "conv3", pool_after=True)
         feature_layers.append(self.l2_normalize(tap(inputs), 10, training, "l2_norm_layer_3"))

@@ -695,7 +695,7 @@ def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 96, 64, 64), (2, 64, 64, 128, 128), (1, 45, 67, 128, 256), (2, 40, 40, 512, 512)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 96, 64, 64), (4, 160, 160, 128, 128), (2, 64, 64, 128, 128), (1, 45, 67, 128, 256), (2, 40, 40, 512, 512)])
 def test_pool_only_inference_conv_equals_conv_then_pool(N, H, W, Cin, Cout, dev):
     """Inference (round 4): conv1_2 / conv2_2 feed nothing but their 2x2 pool, so danhip_conv2d_fwd_pool(y = NULL) never writes the
     full-resolution map where the kernel pools in its epilogue (the 64 -> 64 kernel; the halo kernel's lean epilogue: a zero-length store
@@ -709,7 +709,11 @@ def test_pool_only_inference_conv_equals_conv_then_pool(N, H, W, Cin, Cout, dev)
         want = ops.max_pool_2x2(ops.conv2d(x, w, b, relu=True, pool=True))
         got = ops.max_pool_2x2(ops.conv2d(x, w, b, relu=True, pool=True, pool_only=True))
     torch.cuda.synchronize()
-    assert got.shape == (N, (H + 1) // 2, (W + 1) // 2, Cout) and torch.equal(got, want)
+    assert got.shape == (N, (H + 1) // 2, (W + 1) // 2, Cout)
+    if N * H * W >= 65536 or Cin == 64:          # both routes on the same kernel: bit-identical
+        assert torch.equal(got, want)
+    else:                                        # (the small maps' ordinary route may split K over workgroups: another fp32 summation order)
+        assert (got.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
     # with a gradient tracked the promise is ignored: the full-resolution map exists for the backward pass
     xg = x.clone().requires_grad_(True)
     y = ops.conv2d(xg, w, b, relu=True, pool=True, pool_only=True)
