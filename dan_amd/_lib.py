@@ -71,6 +71,10 @@ SIGNATURES = {
     "danhip_conv2d_bwd_weight_strided": [DESC, P, P, P, P, I32, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
+    "danhip_maxpool2x2_fwd_arg": [P, P, P, I32, I32, I32, I32, P],
+    "danhip_maxpool2x2_bwd_arg": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
+    "danhip_conv2d_fwd_pool_arg": [DESC, P, P, P, P, P, P, P],
+    "danhip_conv2d_fwd_relu_bits_arg": [DESC, P, P, P, P, P, P, P, P, P],
     "danhip_maxpool2x2_bwd": [P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
     "danhip_l2norm_fwd": [P, P, P, I64, I32, P],
     "danhip_l2norm_bwd": [P, P, P, P, P, I64, I32, ctypes.c_int, ctypes.c_int, P],

@@ -13,6 +13,8 @@ struct ConvArgs {
   unsigned char* bits_out;        // forward conv_relu on the 128-wide halo tiles: also writes the ReLU bit mask of y ([M][Co/8] bytes) ...
   unsigned char* pool_bits_out;   // ... and of the fused pooled output
   bf16_t* pool_y;   // optional: 2x2/stride-2 SAME max-pool of y (ReLU outputs), written by the kernels that can fuse it
+  unsigned char* pool_arg_out;    // optional, with pool_y: 2-bit arg-max codes of the pooled map ([pooled pixel][Co/4] bytes, channel c in bits
+                                  // 2(c%4).. of byte c/4; code = 2*dh + dw of the FIRST maximum in row-major window order) for danhip_maxpool2x2_bwd_arg
   int N, H, W, C;
   int Ho, Wo, Co;
   int kh, kw, stride, pad_t, pad_l;
@@ -72,6 +74,35 @@ __device__ __forceinline__ unsigned dh_pos_bits8_acc(const dh_u32x4& t, unsigned
     bits = __builtin_amdgcn_udot2(dh_pos2(t[e]), dh_u16x2{(unsigned short)(1u << (SHIFT + 2 * e)), (unsigned short)(2u << (SHIFT + 2 * e))}, bits, false);
   return bits;
 }
+// ---- 2-bit arg-max codes of a 2x2 max-pool window, from the packed ReLU outputs the pooling epilogues hold (round 4: the pool's backward
+// then scatters through the codes instead of re-reading the full-resolution activation).  a / b / c = top-left / top-right / bottom-left
+// values of two channels per 32-bit word, m = the window maximum (pkmax_relu); all non-negative 16-bit floats, so they order as unsigned
+// integers and m - x is 0 exactly where x is a maximum (packed ops: no borrow between the halves).  TF's MaxPoolGrad takes the FIRST maximum
+// in row-major order (the rule of maxpool_bwd_kernel): code = 0 if a == m, else 1 if b == m, else 2 if c == m, else 3 = ne_a (1 + ne_b (1 + ne_c)).
+__device__ __forceinline__ unsigned dh_pk_ne(unsigned m, unsigned x) {      // per half: 0 where x == m, 1 elsewhere
+  unsigned d, r;
+  asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(m), "v"(x));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(d), "s"(0x00010001u));
+  return r;
+}
+__device__ __forceinline__ unsigned dh_argmax2x2_pk(unsigned a, unsigned b, unsigned c, unsigned m) {   // -> per half a code 0..3
+  const unsigned na = dh_pk_ne(m, a), nb = dh_pk_ne(m, b), nc = dh_pk_ne(m, c);
+  unsigned t, r;
+  asm("v_pk_mad_u16 %0, %1, %2, %1" : "=v"(t) : "v"(nb), "v"(nc));         // nb * nc + nb
+  asm("v_pk_mad_u16 %0, %1, %2, %1" : "=v"(r) : "v"(na), "v"(t));          // na * t + na
+  return r;
+}
+// the eight codes of a lane's eight consecutive channels (four words of two) as 16 bits: channel j in bits 2j, 2j+1
+__device__ __forceinline__ unsigned dh_argmax2x2_codes16(const dh_u32x4& a, const dh_u32x4& b, const dh_u32x4& c, const dh_u32x4& m) {
+  unsigned out = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned w = dh_argmax2x2_pk(a[e], b[e], c[e], m[e]);
+    out |= ((w | (w >> 14)) & 0xFu) << (4 * e);
+  }
+  return out;
+}
+
 // x | x(lane ^ 16) | x(lane ^ 32) | x(lane ^ 48) with the gfx950 row swaps (VALU) instead of two ds_bpermute round trips:
 //   v_permlane16_swap(x, x) -> {rows [0,0,2,2], rows [1,1,3,3]};  v_permlane32_swap(y, y) -> {lower half twice, upper half twice}
 __device__ __forceinline__ unsigned dh_or_rows(unsigned x) {

@@ -613,6 +613,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               if constexpr (EMIT_OK) {
                 if (a.pool_bits_out) pb2[q & 1] = pos_bits8(m);
               }
+              if (a.pool_arg_out) {                  // (uniform) arg-max codes of the window for danhip_maxpool2x2_bwd_arg: 2 bytes per lane and channel pair
+                u32x4 tr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tr[e] = dh_lane_xor1(pk[q][p][e]);
+                const unsigned codes = dh_argmax2x2_codes16(pk[q][p], tr, pk[q][p + PV], m);
+                if (pok && cok[q])
+                  *reinterpret_cast<unsigned short*>(a.pool_arg_out + (size_t)ppix * (a.Co / 4) + (cb + q * 32) / 4) = (unsigned short)codes;
+              }
             }
             if constexpr (EMIT_OK) {
               if (a.pool_bits_out) {
@@ -714,6 +722,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             if (okp) *reinterpret_cast<u32x4*>(a.pool_y + op + q * 32) = m;
             if constexpr (EMIT_OK) pb2[q & 1] = pos_bits8(m);
+            if (a.pool_arg_out) {
+              u32x4 tr;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) tr[e] = dh_lane_xor1(pk[q][p][e]);
+              const unsigned codes = dh_argmax2x2_codes16(pk[q][p], tr, pk[q][p + PV], m);
+              if (okp && cb + q * 32 < a.Co)
+                *reinterpret_cast<unsigned short*>(a.pool_arg_out + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * (a.Co / 4) + (cb + q * 32) / 4) = (unsigned short)codes;
+            }
           }
           if constexpr (EMIT_OK) {
             if (a.pool_bits_out) {

@@ -293,6 +293,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
           if (y < a.H && x < a.W && (frow & 1) == 0)
             *reinterpret_cast<u32x4*>(a.pool_y + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * 64 + cbase) = m;
+          if (a.pool_arg_out) {                      // (uniform) 2-bit arg-max codes of the window for the pool's backward: 2 bytes per lane
+            u32x4 tr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tr[e] = dh_lane_xor1(pk[p][e]);
+            const unsigned codes = dh_argmax2x2_codes16(pk[p], tr, pk[p + 2], m);
+            if (y < a.H && x < a.W && (frow & 1) == 0)
+              *reinterpret_cast<unsigned short*>(a.pool_arg_out + ((size_t)((n * Hp + (y >> 1)) * Wp + (x >> 1))) * 16 + cbase / 4) = (unsigned short)codes;
+          }
         }
       }
     }

@@ -786,6 +786,11 @@ bool danhip_conv_pool_fusable(const ConvArgs& a) {
 
 extern "C" int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
                                       uint16_t* pool_y, void* stream) {
+  return danhip_conv2d_fwd_pool_arg(d, x, wf_packed, bias, y, pool_y, nullptr, stream);
+}
+
+extern "C" int danhip_conv2d_fwd_pool_arg(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                          uint16_t* pool_y, uint8_t* pool_arg, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   DH_REQUIRE(x && wf_packed && bias && pool_y, DANHIP_EINVAL, "conv2d_fwd_pool: null pointer");
@@ -798,9 +803,10 @@ extern "C" int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t*
   // kernels then skip its stores; ask danhip_conv2d_fwd_pool_only(d) first
   DH_REQUIRE(y || fused, DANHIP_EINVAL, "conv2d_fwd_pool: y == NULL needs a kernel that pools in its epilogue (danhip_conv2d_fwd_pool_only)");
   a.pool_y = fused ? pool_y : nullptr;
+  a.pool_arg_out = fused ? pool_arg : nullptr;
   rc = launch_conv(a, (hipStream_t)stream);
   if (rc || fused) return rc;
-  return danhip_maxpool2x2_fwd(y, pool_y, d->N, d->Ho, d->Wo, d->Cout, stream);
+  return danhip_maxpool2x2_fwd_arg(y, pool_y, pool_arg, d->N, d->Ho, d->Wo, d->Cout, stream);
 }
 
 extern "C" int danhip_conv2d_fwd_pool_only(const danhip_conv_desc* d) {
@@ -832,6 +838,11 @@ extern "C" int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_
 
 extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
                                            uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, void* stream) {
+  return danhip_conv2d_fwd_relu_bits_arg(d, x, wf_packed, bias, y, y_bits, pool_y, pool_bits, nullptr, stream);
+}
+
+extern "C" int danhip_conv2d_fwd_relu_bits_arg(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                               uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, uint8_t* pool_arg, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   DH_REQUIRE(x && wf_packed && bias && y && y_bits && (!pool_y == !pool_bits), DANHIP_EINVAL, "conv2d_fwd_relu_bits: null pointer");
@@ -840,7 +851,7 @@ extern "C" int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint
   ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = nullptr; a.y = y;
   a.relu = 1; a.out_f32 = 0; a.accumulate = 0;
-  a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits;
+  a.pool_y = pool_y; a.bits_out = y_bits; a.pool_bits_out = pool_bits; a.pool_arg_out = pool_y ? pool_arg : nullptr;
   if (danhip_conv_c8_label(a)) return danhip_launch_conv_c8(a, (hipStream_t)stream);
   return danhip_launch_conv_halo(a, (hipStream_t)stream);
 }

@@ -312,12 +312,25 @@ def _wgrad_scratch(d, dev):
     return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
 
 
+# USE_POOL_ARG (round 4): the 2 x 2 max-pool keeps 2-bit arg-max codes from its forward pass (written by the pooling conv epilogues / the pool
+# kernel) and its backward scatters the pooled gradient through them instead of re-reading the full-resolution activation to find each
+# window's maximum (danhip_maxpool2x2_bwd_arg: 1.28 instead of 2.25 map-sized HBM passes).  DANHIP_POOL_ARG=0: the round-3 form (A/B).
+USE_POOL_ARG = os.environ.get("DANHIP_POOL_ARG", "1") == "1"
+
+
+def _pool_arg_buffer(pooled, need_bwd):
+    if not (USE_POOL_ARG and need_bwd):
+        return None
+    c = pooled.shape[-1]
+    return torch.empty((pooled.numel() // c, c // 4), dtype=torch.uint8, device=pooled.device)
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv2d_same(x, w) + b) [+ residual]; tf.layers.conv2d semantics (net/sfd_net.py:81-89)."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0, xbits=None, bits_out=None,
-                pool_only=False):
+                pool_only=False, tracked=True):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
@@ -339,23 +352,26 @@ class _Conv2d(torch.autograd.Function):
                 and _lib.lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d), 1 if pool_out is not None else 0))
         if emit:                                         # conv_relu (+ fused pool) that also leaves the ReLU bit masks for the next conv's data gradient
             ybits = torch.empty((N * d.Ho * d.Wo, cout // 8), dtype=torch.uint8, device=x.device)
-            pooled = pbits = None
+            pooled = pbits = parg = None
             if pool_out is not None:
                 pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
                 pbits = torch.empty((pooled.numel() // cout, cout // 8), dtype=torch.uint8, device=x.device)
-                pool_out.append(pooled)
-            call("danhip_conv2d_fwd_relu_bits", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(ybits), ptr(pooled), ptr(pbits), stream())
+                parg = _pool_arg_buffer(pooled, need_bwd and tracked)
+                pool_out.extend([pooled, parg])
+            call("danhip_conv2d_fwd_relu_bits_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(ybits), ptr(pooled), ptr(pbits), ptr(parg),
+                 stream())
             bits_out.extend([ybits, pbits])
         elif pool_out is not None:                       # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
             assert relu and not out_f32 and residual is None and b is not None and cout % 8 == 0
             pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
+            parg = _pool_arg_buffer(pooled, need_bwd and tracked)
             ws, nws = _conv_scratch(d, 0, x.device)
             if nws:                                      # a map small enough to split K: no kernel of it fuses the pool anyway
                 call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), BF16, 1, None, ptr(ws), nws, stream())
-                call("danhip_maxpool2x2_fwd", ptr(y), ptr(pooled), N, d.Ho, d.Wo, cout, stream())
+                call("danhip_maxpool2x2_fwd_arg", ptr(y), ptr(pooled), ptr(parg), N, d.Ho, d.Wo, cout, stream())
             else:
-                call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), stream())
-            pool_out.append(pooled)
+                call("danhip_conv2d_fwd_pool_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), ptr(parg), stream())
+            pool_out.extend([pooled, parg])
         else:
             ws, nws = _conv_scratch(d, 0, x.device)
             call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
@@ -407,7 +423,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 17
+            return (None,) * 18
         db_in_wgrad = need_db and need_dw                        # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -465,7 +481,7 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if GRAD_READY_HOOK is not None and wp is not None and not hooked:
             GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ---- fp32 inference path (csrc/f32_infer.hip): every op below accepts fp32 NHWC activations and then runs the fp32 kernels — forward
@@ -512,7 +528,7 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
     bits_out = [] if (track and relu and USE_RELU_BITS) else None
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out,
-                      bool(pool_only and not track))
+                      bool(pool_only and not track), bool(track))
     if getattr(y, "_dh_already_pooled", False):
         return y
     if TRACE is not None and relu and wp is not None:
@@ -529,6 +545,7 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
             y._dh_pslot = yslot
     if pool_out:
         y._dh_pooled = pool_out[0]
+        y._dh_pool_arg = pool_out[1]                     # 2-bit arg-max codes of the fused pool (None when nothing is tracked)
         if bits_out and bits_out[1] is not None:
             y._dh_pooled_bits = bits_out[1]
     return y
@@ -538,14 +555,17 @@ class _MaxPool(torch.autograd.Function):
     """tf.layers.max_pooling2d([2,2],[2,2],'same') — net/sfd_net.py:132."""
 
     @staticmethod
-    def forward(ctx, x, xslot, yslot, pre=None):
+    def forward(ctx, x, xslot, yslot, pre=None, arg=None):
         N, H, W, C = x.shape
-        if pre is not None:                              # already computed by the producing conv's epilogue
+        if pre is not None:                              # already computed by the producing conv's epilogue (with its arg-max codes)
             y = pre
         else:
             y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=x.dtype, device=x.device)
-            call("danhip_maxpool2x2_fwd", ptr(x), ptr(y), N, H, W, C, stream())
-        ctx.save_for_backward(x)
+            arg = _pool_arg_buffer(y, x.requires_grad and C % 8 == 0)
+            call("danhip_maxpool2x2_fwd_arg", ptr(x), ptr(y), ptr(arg), N, H, W, C, stream())
+        ctx.arg = arg
+        ctx.save_for_backward(x if arg is None else None)
+        ctx.dims = (N, H, W, C)
         ctx.xslot, ctx.yslot = xslot, yslot
         ctx.set_materialize_grads(False)
         return y
@@ -553,22 +573,29 @@ class _MaxPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        N, H, W, C = x.shape
+        N, H, W, C = ctx.dims
         g = ctx.yslot.take() if ctx.yslot is not None else None
         if dy is not None:
             g = dy.contiguous() if g is None else g.add_(dy)
         if g is None:
-            return None, None, None, None
+            return None, None, None, None, None
+
+        def scatter(dst, acc):
+            if ctx.arg is not None:                      # through the forward pass's arg-max codes: the activation is not read again
+                call("danhip_maxpool2x2_bwd_arg", ptr(ctx.arg), ptr(g), ptr(dst), N, H, W, C, acc, stream())
+            else:
+                call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(dst), N, H, W, C, acc, stream())
+
         if ctx.xslot is not None:
             # the pooled maximum is > 0 exactly where its source is, so a gradient masked at the pooled level scatters to
             # an already ReLU-masked gradient; an unmasked one (autograd path) is masked by the producer's own backward
             buf, acc = ctx.xslot.target() if _pool_deliver_ok(ctx, dy) else (None, 0)
             if buf is not None:
-                call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(buf), N, H, W, C, acc, stream())
+                scatter(buf, acc)
                 return None, None, None, None, None
-        dx = torch.empty_like(x)
-        call("danhip_maxpool2x2_bwd", ptr(x), ptr(g), ptr(dx), N, H, W, C, 0, stream())
-        return dx, None, None, None
+        dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+        scatter(dx, 0)
+        return dx, None, None, None, None
 
 
 def _pool_deliver_ok(ctx, dy):
@@ -589,7 +616,7 @@ def max_pool_2x2(x):
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
     yslot = _new_slot(track)
-    y = _MaxPool.apply(x, xs, yslot, getattr(x, "_dh_pooled", None))
+    y = _MaxPool.apply(x, xs, yslot, getattr(x, "_dh_pooled", None), getattr(x, "_dh_pool_arg", None))
     pbits = getattr(x, "_dh_pooled_bits", None)
     if pbits is not None and getattr(x, "_dh_pooled", None) is not None:
         y._dh_bits = [pbits]                             # the fused conv + pool kernel also wrote the pooled map's ReLU bit mask

@@ -105,6 +105,15 @@ int danhip_conv2d_fwd(const danhip_conv_desc* d, const uint16_t* x, const uint16
  * 16-bit type.  3x3 kernels that own whole row pairs per wave pool in their epilogue; other shapes run the pool kernel. */
 int danhip_conv2d_fwd_pool(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
                            uint16_t* pool_y, void* stream);
+/* The same calls that ALSO write the pool's 2-bit arg-max codes (pool_arg: [N*ceil(Ho/2)*ceil(Wo/2)][Cout/4] bytes, channel c in bits
+ * 2(c%4).. of byte c/4, code = 2*dh + dw of the FIRST maximum of the window in row-major order - TF's MaxPoolGrad rule), from the epilogue
+ * registers where the kernel pools there, from the pool kernel otherwise.  danhip_maxpool2x2_bwd_arg scatters the pooled gradient through
+ * the codes: it reads a quarter-size gradient and 2 bits per element instead of the full-resolution activation (1.28 instead of 2.25
+ * map-sized HBM passes).  pool_arg == NULL: the plain calls. */
+int danhip_conv2d_fwd_pool_arg(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                               uint16_t* pool_y, uint8_t* pool_arg, void* stream);
+int danhip_conv2d_fwd_relu_bits_arg(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
+                                    uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, uint8_t* pool_arg, void* stream);
 /* 1 when danhip_conv2d_fwd_pool may be called with y == NULL for this descriptor: only the pooled map is produced and the full-resolution
  * activation is never written (inference: nothing but the pool reads conv1_2's / conv2_2's output - 839 + 419 MB of stores per batch of
  * 16 at 640 x 640).  0: the pool is a separate kernel for this shape, y is needed. */
@@ -185,6 +194,10 @@ const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d);
 int danhip_maxpool2x2_fwd(const uint16_t* x, uint16_t* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int danhip_maxpool2x2_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                           int accumulate, void* stream);
+/* The 2 x 2 max-pool with its arg-max codes (layout: danhip_conv2d_fwd_pool_arg) and the backward through them: dx (+)= scatter(dy, arg). */
+int danhip_maxpool2x2_fwd_arg(const uint16_t* x, uint16_t* y, uint8_t* arg, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int danhip_maxpool2x2_bwd_arg(const uint8_t* arg, const uint16_t* dy, uint16_t* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                              int accumulate, void* stream);
 /* VGG16Backbone.l2_normalize — net/sfd_net.py:68-79: y = x * rsqrt(max(sum_c x^2, 1e-10)) * gamma_c.
  * x,y bf16 [M,C], gamma fp32 [C], C in {64,128,256,512,1024}.  bwd: dgamma += (atomic fp32), dx (=|+= if accumulate);
  * relu_mask: x is a ReLU output, so dx is also multiplied by (x > 0) (the producer's ReLU backward folded in). */

@@ -53,8 +53,9 @@ def test_graph_gradients_match_the_oracle(which, H, W, dev):
     assert checked > 250 and not bad, (checked, bad[:10])
 
 
-@pytest.mark.parametrize("variant", ["default", "no_slots", "no_splitk"])
-@pytest.mark.parametrize("which,H,W", [("sfd", 96, 96)] + CASES)
+# (the two non-default routes on the S3FD and DAN graphs: together they cover every kernel family; PyramidBox / DAN-Deform run the default)
+@pytest.mark.parametrize("which,H,W,variant", [(w, h, ww, "default") for w, h, ww in [("sfd", 96, 96)] + CASES] +
+                         [(w, h, ww, v) for w, h, ww in (("sfd", 96, 96), ("dan", 64, 96)) for v in ("no_slots", "no_splitk")])
 def test_graph_gradients_with_the_forward_decisions_imposed_on_the_oracle(which, H, W, variant, dev, monkeypatch):
     """The same comparison with the DISCRETE decisions of the HIP forward pass (sign of every ReLU layer's output, the 2x2 max-pool arg-max
     positions) imposed on the oracle graph (oracle.nets.Params.impose): what remains is accumulation order and 16-bit rounding of the

@@ -122,3 +122,60 @@ def test_head_split_maxout(dev):
         (cls * dc.to(dev)).sum().backward()
         ((loc_ref.reshape(B, -1, 4) * dl[:, 3:3 + H * W]).sum() + (cls_ref.reshape(B, -1, 2) * dc[:, 3:3 + H * W]).sum()).backward()
         assert torch.allclose(hd.grad.cpu(), hr.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 16, 64), (1, 33, 47, 128), (3, 7, 9, 8), (2, 64, 64, 256)])
+def test_maxpool_backward_through_arg_max_codes(N, H, W, C, dev):
+    """Round 4: the 2 x 2 max-pool's backward scatters through 2-bit arg-max codes written by the forward pass instead of re-reading the
+    activation (danhip_maxpool2x2_fwd_arg / _bwd_arg).  Bit-identical to the round-3 backward (danhip_maxpool2x2_bwd, first maximum in
+    row-major window order = TF's MaxPoolGrad) on inputs with many exact ties (ReLU zeros, quantised values), odd sizes, accumulate."""
+    from dan_amd import _lib, ops
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.relu(torch.round(torch.randn((N, H, W, C), generator=g) * 4) / 4).to(ops.ACT).to(dev)      # ties and zeros
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn((N, Ho, Wo, C), generator=g).to(ops.ACT).to(dev)
+    y0 = torch.empty((N, Ho, Wo, C), dtype=ops.ACT, device=dev)
+    y1 = torch.empty_like(y0)
+    arg = torch.empty((N * Ho * Wo, C // 4), dtype=torch.uint8, device=dev)
+    _lib.call("danhip_maxpool2x2_fwd", _lib.ptr(x), _lib.ptr(y0), N, H, W, C, _lib.stream())
+    _lib.call("danhip_maxpool2x2_fwd_arg", _lib.ptr(x), _lib.ptr(y1), _lib.ptr(arg), N, H, W, C, _lib.stream())
+    assert torch.equal(y0, y1)
+    for acc in (0, 1):
+        old = torch.randn((N, H, W, C), generator=g).to(ops.ACT).to(dev)
+        d0, d1 = old.clone(), old.clone()
+        _lib.call("danhip_maxpool2x2_bwd", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(d0), N, H, W, C, acc, _lib.stream())
+        _lib.call("danhip_maxpool2x2_bwd_arg", _lib.ptr(arg), _lib.ptr(dy), _lib.ptr(d1), N, H, W, C, acc, _lib.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(d0, d1), acc
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 96, 64, 64), (2, 128, 128, 128, 128), (2, 66, 62, 128, 256), (1, 40, 40, 512, 512), (4, 160, 160, 256, 256)])
+def test_pooling_conv_epilogues_write_the_same_arg_max_codes_as_the_pool_kernel(N, H, W, Cin, Cout, dev):
+    """The fused conv + pool kernels (64 -> 64 kernel, the halo kernel's lean epilogue with and without the ReLU bit masks) derive the codes
+    from the packed outputs in their epilogue registers: they must equal the pool kernel's codes of the activation the conv wrote."""
+    import ctypes
+    from dan_amd import _lib, ops
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    d = ops._desc(N, H, W, Cin, Cout, 3, 3, 1)
+    wf, _ = ops.pack_conv_weight(d, w, need_bwd=False)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    y = torch.empty((N, H, W, Cout), dtype=ops.ACT, device=dev)
+    p = torch.empty((N, Ho, Wo, Cout), dtype=ops.ACT, device=dev)
+    arg = torch.full((N * Ho * Wo, Cout // 4), 255, dtype=torch.uint8, device=dev)
+    _lib.call("danhip_conv2d_fwd_pool_arg", ctypes.byref(d), _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), _lib.ptr(y), _lib.ptr(p), _lib.ptr(arg), _lib.stream())
+    p_ref = torch.empty_like(p)
+    arg_ref = torch.empty_like(arg)
+    _lib.call("danhip_maxpool2x2_fwd_arg", _lib.ptr(y), _lib.ptr(p_ref), _lib.ptr(arg_ref), N, H, W, Cout, _lib.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref) and torch.equal(arg, arg_ref)
+    if _lib.lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d), 1):
+        ybits = torch.empty((N * H * W, Cout // 8), dtype=torch.uint8, device=dev)
+        pbits = torch.empty((N * Ho * Wo, Cout // 8), dtype=torch.uint8, device=dev)
+        arg2 = torch.full_like(arg, 255)
+        _lib.call("danhip_conv2d_fwd_relu_bits_arg", ctypes.byref(d), _lib.ptr(x), _lib.ptr(wf), _lib.ptr(b), _lib.ptr(y), _lib.ptr(ybits), _lib.ptr(p), _lib.ptr(pbits),
+                  _lib.ptr(arg2), _lib.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(arg2, arg_ref)
