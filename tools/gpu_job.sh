@@ -1,4 +1,9 @@
-mkdir -p gpurun_out/j13
-python -m pytest tests/test_ops_gpu.py tests/test_conv_gpu.py tests/test_sfd_gpu.py -q -x 2>&1 | tail -n 6
-python -m pytest tests/test_grad_parity_gpu.py tests/test_models_gpu.py tests/test_train_models_gpu.py tests/test_full_size_gpu.py -q -x -k "not 1024" 2>&1 | tail -n 4
-for i in 1 2; do for v in 1 0; do DANHIP_POOL_ARG=$v python bench.py --steps 20 --no-cpu-baseline --no-eval --no-serialized-roofline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('pool_arg=$v', d['value'], d['ms_per_step'])"; done; done
+mkdir -p gpurun_out/j14
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/j14/trace -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > gpurun_out/j14/bench.log 2>&1
+f=$(find gpurun_out/j14/trace -name "*kernel_trace.csv" | head -n 1)
+python3 tools/step_breakdown.py $f > gpurun_out/j14/step_breakdown.txt 2>&1
+rm -rf gpurun_out/j14/trace
+
+(head -n 3 gpurun_out/j14/step_breakdown.txt; tail -n 18 gpurun_out/j14/step_breakdown.txt) | cut -c1-150
+
