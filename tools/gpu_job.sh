@@ -1,9 +1,4 @@
-mkdir -p gpurun_out/j14
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/j14/trace -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-serialized-roofline --no-eval > gpurun_out/j14/bench.log 2>&1
-f=$(find gpurun_out/j14/trace -name "*kernel_trace.csv" | head -n 1)
-python3 tools/step_breakdown.py $f > gpurun_out/j14/step_breakdown.txt 2>&1
-rm -rf gpurun_out/j14/trace
-
-(head -n 3 gpurun_out/j14/step_breakdown.txt; tail -n 18 gpurun_out/j14/step_breakdown.txt) | cut -c1-150
-
+mkdir -p gpurun_out/j16
+for i in 1 2; do for v in 1 0; do DANHIP_FUSED_CONTEXT=$v python bench.py --model dan --steps 10 --no-cpu-baseline --no-eval --no-serialized-roofline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('dan eager fused=$v', d['value'], d['ms_per_step'])"; done; done
+python __graft_entry__.py smoke 2>&1 | tail -n 2
+python bench.py > gpurun_out/j16/bench_sfd.json 2>gpurun_out/j16/bench_sfd.err; cut -c1-200 gpurun_out/j16/bench_sfd.json
