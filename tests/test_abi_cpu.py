@@ -283,3 +283,44 @@ runc:1:2 [0] NCCL INFO ncclCommInitRankConfig_impl comm 0x63 rank 0 nranks 1 cud
     assert info["version"].startswith("2.26.6") and info["nranks"] == 1 and info["channels"] == 128 and info["rings"] == 2
     empty = b.rccl_debug_parse("nothing here")
     assert empty["nranks"] is None and empty["algo"] == {}
+
+
+def test_fused_context_block_fires_its_gradient_hooks_in_flat_buffer_order():
+    """The data-parallel buckets need every variable's 'gradient ready' hook in non-increasing order of its offset in the flat buffer
+    (GradBuckets.ready).  The fused DAN context block (net/danet.py:842-918 as one autograd node) issues all of its gradients and then fires
+    the hooks itself; three of its 1x1 kernels live side by side in ONE segment (VariableStore.fuse) that stands where the first of them was
+    created.  Replays variable creation, the flat layout and the block's hook order on the CPU - no kernel runs."""
+    from dan_amd.net.variables import VariableStore
+    from dan_amd.trainer import FlatParams
+    vs = VariableStore(device="cpu", seed=1)
+    c = 256
+    order = [("branch1_conv_1x1", 1, 1, c, 64), ("branch2_conv_1x1", 1, 1, c, 64), ("branch3_conv_1x1", 1, 1, c, 64), ("branch3_conv_3x1", 3, 1, 64, 32),
+             ("branch3_conv_1x3", 1, 3, 64, 32), ("branch4_conv_1x1", 1, 1, c, 64), ("branch4_conv_3x3", 3, 3, 64, 64), ("branch4_conv_1x3", 3, 1, 64, 32),
+             ("branch4_conv_3x1", 1, 3, 64, 32), ("residual_conv", 1, 1, 256, c)]
+    vs.get("before/kernel", (3, 3, 8, 64), "glorot")
+    for blk in ("s1", "s2"):
+        for scope, kh, kw, ci, co in order:
+            vs.get("%s/%s/kernel" % (blk, scope), (kh, kw, ci, co), "glorot")
+            vs.get("%s/%s/bias" % (blk, scope), (co,), "zeros")
+        for suffix, axis in (("kernel", 3), ("bias", 0)):
+            assert vs.fuse(tuple("%s/%s/%s" % (blk, s, suffix) for s in ("branch3_conv_1x1", "branch4_conv_1x1", "branch2_conv_1x1")), axis=axis) is None
+    vs.get("after/kernel", (3, 3, 64, 64), "glorot")
+    flat = FlatParams(vs)
+    start = flat.start_of_member
+    # the block's hook order (dan_amd/net/danet.py::_se_inception_block_fused), blocks in reverse creation order as backward visits them
+    hook_scopes = ["residual_conv", "branch4_conv_3x1", "branch4_conv_1x3", "branch4_conv_3x3", "branch3_conv_1x3", "branch3_conv_3x1", "branch4_conv_1x1",
+                   "branch3_conv_1x1", "branch2_conv_1x1", "branch1_conv_1x1"]
+    seq = [start["after/kernel"]]
+    for blk in ("s2", "s1"):
+        seq += [start["%s/%s/kernel" % (blk, s)] for s in hook_scopes]
+    seq.append(start["before/kernel"])
+    assert all(a >= b for a, b in zip(seq, seq[1:])), seq
+    # firing a kernel's hook declares its bias final too: every bias sits at or above its kernel's segment
+    for blk in ("s1", "s2"):
+        for scope, *_ in order:
+            assert start["%s/%s/bias" % (blk, scope)] >= start["%s/%s/kernel" % (blk, scope)]
+    # the three fused 1x1 kernels are views of one block laid out [b3 | b4 | b2] along the output-channel axis
+    wcat = vs.fused[("s1/branch3_conv_1x1/kernel", "s1/branch4_conv_1x1/kernel", "s1/branch2_conv_1x1/kernel")]
+    assert tuple(wcat.shape) == (1, 1, c, 192) and wcat.is_contiguous()
+    w4 = dict(vs.named())["s1/branch4_conv_1x1/kernel"]
+    assert w4.data_ptr() == wcat[..., 64:128].data_ptr() and not w4.is_contiguous()
