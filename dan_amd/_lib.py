@@ -68,6 +68,7 @@ SIGNATURES = {
     "danhip_residual_bwd": [P, P, P, P, P, ctypes.c_int, I64, P],
     "danhip_conv2d_fwd_strided": [DESC, P, P, P, P, ctypes.c_int, I32, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
     "danhip_conv2d_bwd_data_strided": [DESC, P, P, P, P, ctypes.c_int, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
+    "danhip_conv2d_fwd_concat2": [DESC, P, P, I32, I32, P, P, P, ctypes.c_int, P],
     "danhip_conv2d_bwd_weight_strided": [DESC, P, P, P, P, I32, ctypes.POINTER(ConvPitch), P, ctypes.c_size_t, P],
     "danhip_relu_bwd_bias_grad": [P, P, P, I64, I32, P],
     "danhip_maxpool2x2_fwd": [P, P, I32, I32, I32, I32, P],
@@ -173,6 +174,8 @@ def lib():
         L.danhip_deform_sample_bwd_workspace_bytes.argtypes = [I32, I32, I32, I32]
         L.danhip_conv2d_fwd_pool_only.restype = ctypes.c_int
         L.danhip_conv2d_fwd_pool_only.argtypes = [DESC]
+        L.danhip_conv2d_fwd_concat2_supported.restype = ctypes.c_int
+        L.danhip_conv2d_fwd_concat2_supported.argtypes = [DESC, I32, I32]
         L.danhip_conv2d_fwd_emits_bits.restype = ctypes.c_int
         L.danhip_conv2d_fwd_emits_bits.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_data_takes_bits.restype = ctypes.c_int

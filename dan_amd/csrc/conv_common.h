@@ -32,6 +32,9 @@ struct ConvArgs {
   int ldx, ldy, ldm;
   int relu_co;   // forward: ReLU applies to output channels < relu_co only (fused 1x1 block whose last columns stay linear); default Co
   bool strided() const { return ldx != C || ldy != Co || (mask && ldm != Co) || (relu && relu_co < Co); }
+  // (appended last: the layout of everything above is what the tuned kernels were built against)
+  const bf16_t* x2;   // conv_pointwise.hip, forward 1x1: second source of the K axis (channels ksplit*64 .. C-1 of the virtual input [x | x2], same
+  int ksplit;         // pixel pitch ldx as x); null = one source.  Only danhip_conv2d_fwd_concat2 sets them.
 };
 
 // true when launch_conv's kernel for these args writes a.pool_y itself (conv_halo_c64.hip / conv_halo.hip forward tiles)

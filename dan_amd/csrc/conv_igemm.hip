@@ -758,6 +758,44 @@ extern "C" int danhip_conv2d_fwd_strided(const danhip_conv_desc* d, const uint16
   return launch_conv(a, (hipStream_t)stream);
 }
 
+// Forward 1x1 over the channel concatenation of two tensors, never materialised: y = relu([x1 | x2] . W + b), W packed for Cin = c1 + c2.
+// Only the streaming GEMM (conv_pointwise.hip) walks two sources: _supported() says whether this shape takes it (64-multiple channel
+// counts on both sides, at least 2048 output pixels); the host concatenates and calls danhip_conv2d_fwd otherwise.
+static int concat2_args(const danhip_conv_desc* d, int32_t c1, int32_t src_pitch, ConvArgs& a) {
+  if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (c1 <= 0 || c1 >= d->Cin || c1 % 64 != 0 || (d->Cin - c1) % 64 != 0 || d->Cout % 64 != 0) return 0;
+  if (src_pitch % 8 != 0 || src_pitch < c1 || src_pitch < d->Cin - c1) return 0;
+  if ((int64_t)d->N * d->H * d->W * src_pitch >= (1ll << 31)) return 0;
+  a = fwd_args(d);
+  a.ldx = src_pitch;
+  a.ksplit = c1 / 64;
+  return 1;
+}
+
+extern "C" int danhip_conv2d_fwd_concat2_supported(const danhip_conv_desc* d, int32_t c1, int32_t src_pitch) {
+  if (!d || check_desc(d) != DANHIP_OK) return 0;
+  ConvArgs a{};
+  if (!concat2_args(d, c1, src_pitch, a)) return 0;
+  static const float one = 1.f;
+  static bf16_t dummy = 0;
+  a.bias = &one; a.x2 = &dummy;
+  return danhip_conv_pointwise_label(a, false) != nullptr ? 1 : 0;
+}
+
+extern "C" int danhip_conv2d_fwd_concat2(const danhip_conv_desc* d, const uint16_t* x1, const uint16_t* x2, int32_t c1, int32_t src_pitch,
+                                         const uint16_t* wf_packed, const float* bias, uint16_t* y, int relu, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(x1 && x2 && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd_concat2: null pointer");
+  ConvArgs a{};
+  DH_REQUIRE(concat2_args(d, c1, src_pitch, a), DANHIP_EINVAL,
+             "conv2d_fwd_concat2: 1x1 / stride 1 with 64-multiple channel counts (c1, Cin - c1, Cout) and an 8-multiple source pitch only");
+  a.x = x1; a.x2 = x2; a.w = wf_packed; a.bias = bias; a.y = y; a.relu = relu ? 1 : 0;
+  rc = danhip_launch_conv_pointwise(a, (hipStream_t)stream);
+  DH_REQUIRE(rc <= 0, DANHIP_EINVAL, "conv2d_fwd_concat2: shape not taken by the streaming GEMM (ask danhip_conv2d_fwd_concat2_supported first)");
+  return rc;
+}
+
 extern "C" int danhip_conv2d_bwd_data_strided(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint16_t* relu_mask,
                                               uint16_t* dx, int accumulate, const danhip_conv_pitch* pitch, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_desc(d);

@@ -73,8 +73,11 @@ __device__ __forceinline__ int pw_floor_count(int n) {
 // K-step (tap, 64-channel chunk) gathers the tap's shifted pixel rows; padding pixels are out-of-range lanes (zero fill).  This is what
 // carries the 3x3 convolutions on maps too small for the halo tiles (40x40, 20x20: conv5_x, fc6, the CPM / context levels 2..5), the
 // stride-2 extra layers and DAN's 3x1 / 1x3 branches.
-template <int BN, int NST, bool DGRAD, bool LD, bool TAPS>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_pointwise_kernel(const ConvArgs a, const PwGeom g) {
+// TWO (round 4; forward, 1x1 only): the K axis is the concatenation of TWO source tensors of equal pitch - K-steps [0, a.ksplit) read a.x,
+// the rest a.x2 - i.e. Y = relu([X1 | X2] . W^T + b) without materialising the concatenation (DAN's stage-2 input mix: net/danet.py:944-950)
+template <int BN, int NST, bool DGRAD, bool LD, bool TAPS, bool TWO>
+__device__ __forceinline__ void pw_body(const ConvArgs a, const PwGeom g) {
+  static_assert(!TWO || (!TAPS && !DGRAD), "two-source K: plain forward 1x1 only");
   constexpr int BM = 128;
   constexpr int WN = BN / 64, WM = 8 / WN;            // waves along Co / along pixels
   constexpr int TP = BM / WM;                         // pixels per wave (64 / 32 / 16)
@@ -111,7 +114,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // (c>>1)*32 + (frow>>2)*8 + (c&1)*4 + (frow&3)), a ds_read_b128 group touches rows {0-3, 8-11 | 16-19, 24-27}: key = (r&3) | ((r>>3)&1)<<2.
   auto wkey = [](int r) __attribute__((always_inline)) -> int { return (r & 3) | (((r >> 3) & 1) << 2); };
   // (pitched view: the last pixel's row ends C elements after its start, whatever the pitch)
-  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + (unsigned)a.C) * 2u);      // rows >= M are out of range: zero fill
+  const unsigned c_first = TWO ? (unsigned)a.ksplit * 64u : (unsigned)a.C;         // channels the first source carries
+  const pw_u32x4 rsrc_x = pw_make_rsrc(a.x, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + c_first) * 2u);      // rows >= M are out of range: zero fill
+  [[maybe_unused]] const pw_u32x4 rsrc_x2 =
+      pw_make_rsrc(TWO ? a.x2 : a.x, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + ((unsigned)a.C - c_first)) * 2u);
   const pw_u32x4 rsrc_w = pw_make_rsrc(a.w, (unsigned)(g.NB * BN) * (unsigned)a.Kpad * 2u);
   unsigned avoff[APW], wvoff[WPW];
 #pragma unroll
@@ -169,9 +175,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         pw_dma16(rsrc_x, voff | inv, base + (wave * APW + k) * 1024);
       }
     } else {
-      const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.ldx * 2) + (unsigned)(d_k * 128);
+      unsigned kk = (unsigned)d_k;
+      pw_u32x4 rs = rsrc_x;
+      if constexpr (TWO) {
+        if (d_k >= a.ksplit) { kk = (unsigned)(d_k - a.ksplit); rs = rsrc_x2; }      // wave-uniform: four s_cselect
+      }
+      const unsigned sa = (unsigned)(d_mt * BM) * (unsigned)(a.ldx * 2) + kk * 128u;
 #pragma unroll
-      for (int k = 0; k < APW; ++k) pw_dma16(rsrc_x, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
+      for (int k = 0; k < APW; ++k) pw_dma16(rs, (avoff[k] + sa) | inv, base + (wave * APW + k) * 1024);
     }
 #pragma unroll
     for (int k = 0; k < WPW; ++k) pw_dma16(rsrc_w, (wvoff[k] + sw) | inv, base + ABYTES + (wave * WPW + k) * 1024);
@@ -275,12 +286,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       // ---- epilogue: lane owns channels cb + q*32 .. +7 of pixel m
       if constexpr (!LD) {
       } else if constexpr (DGRAD) {
-        if constexpr (NPT == 2)
+        if constexpr (NPT == 4)
+          asm volatile("s_waitcnt vmcnt(%16)" : "+v"(ld_m[0][0]), "+v"(ld_m[0][1]), "+v"(ld_m[1][0]), "+v"(ld_m[1][1]), "+v"(ld_m[2][0]), "+v"(ld_m[2][1]),
+                       "+v"(ld_m[3][0]), "+v"(ld_m[3][1]), "+v"(ld_o[0][0]), "+v"(ld_o[0][1]), "+v"(ld_o[1][0]), "+v"(ld_o[1][1]), "+v"(ld_o[2][0]),
+                       "+v"(ld_o[2][1]), "+v"(ld_o[3][0]), "+v"(ld_o[3][1]) : "n"(LDWAIT) : "memory");
+        else if constexpr (NPT == 2)
           asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ld_m[0][0]), "+v"(ld_m[0][1]), "+v"(ld_m[1][0]), "+v"(ld_m[1][1]), "+v"(ld_o[0][0]), "+v"(ld_o[0][1]),
                        "+v"(ld_o[1][0]), "+v"(ld_o[1][1]) : "n"(LDWAIT) : "memory");
         else
           asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ld_m[0][0]), "+v"(ld_m[0][1]), "+v"(ld_o[0][0]), "+v"(ld_o[0][1]) : "n"(LDWAIT) : "memory");
-        static_assert(NPT <= 2, "data-gradient tiles with epilogue inputs are at most 128 wide");
+        static_assert(NPT == 1 || NPT == 2 || NPT == 4, "one wait statement per wave-tile height");
       } else {
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ld_b[0][0]), "+v"(ld_b[0][1]), "+v"(ld_b[1][0]), "+v"(ld_b[1][1]) : "n"(LDWAIT) : "memory");
       }
@@ -368,6 +383,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   pw_wait_vmcnt<0>();                                  // zero-fill pieces of the steps beyond the stream may still be landing
 }
 
+template <int BN, int NST, bool DGRAD, bool LD, bool TAPS>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_pointwise_kernel(const ConvArgs a, const PwGeom g) {
+  pw_body<BN, NST, DGRAD, LD, TAPS, false>(a, g);
+}
+template <int BN, int NST>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_pointwise_concat2_kernel(const ConvArgs a, const PwGeom g) {
+  pw_body<BN, NST, false, true, false, true>(a, g);
+}
+
 int pw_cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -398,6 +422,26 @@ int launch_pw_t(const ConvArgs& a, hipStream_t s) {
   return DANHIP_OK;
 }
 
+template <int BN, int NST>
+int launch_pw_concat2(const ConvArgs& a, hipStream_t s) {
+  constexpr int LDS = NST * (128 * 128 + BN * 128);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pointwise_concat2_kernel<BN, NST>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+  (void)attr_ok;
+  PwGeom g{};
+  g.m_tiles = (a.M + 127) / 128;
+  g.NB = a.Co / BN;
+  g.items = g.m_tiles * g.NB;
+  g.ksteps = a.Kpad / 64;
+  g.div_nb = make_fastdiv(g.NB);
+  int G = pw_cu_count();
+  if (g.items < G) G = g.items;
+  g.grouped = (G % 8 == 0 && ((G >> 3) % g.NB) == 0 && g.items >= G) ? 1 : 0;
+  hipLaunchKernelGGL((conv_pointwise_concat2_kernel<BN, NST>), dim3(G), dim3(512), LDS, s, a, g);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
+
 template <int BN, int NST, bool DGRAD, bool LD>
 int launch_pw(const ConvArgs& a, hipStream_t s) {
   const bool plain = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
@@ -416,8 +460,12 @@ bool pw_eligible(const ConvArgs& a) {
 
 }  // namespace
 
-// tile width: the whole Co where it fits (X read once); a data gradient WITH epilogue inputs keeps them in registers: 128 at most
-static int pw_bn(const ConvArgs& a, bool dgrad_ld) { return (a.Co % 256 == 0 && !dgrad_ld) ? 256 : (a.Co % 128 == 0 ? 128 : 64); }
+// tile width: the whole Co where it fits (X read once).  A data gradient WITH epilogue inputs holds them in registers across its last
+// K-step: 128 wide by default; option pw_dgrad_ld_bn = 256 lets it take the 256-wide tile too (32 more registers; measured no faster)
+static int pw_bn(const ConvArgs& a, bool dgrad_ld) {
+  const int cap = dgrad_ld ? danhip_option("pw_dgrad_ld_bn") : 256;
+  return (a.Co % 256 == 0 && cap >= 256) ? 256 : (a.Co % 128 == 0 ? 128 : 64);
+}
 
 const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad) {
   if (!pw_eligible(a)) return nullptr;
@@ -439,12 +487,18 @@ const char* danhip_conv_pointwise_label(const ConvArgs& a, bool dgrad) {
 // DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to the flat-M kernel).
 int danhip_launch_conv_pointwise(const ConvArgs& a, hipStream_t s) {
   if (!pw_eligible(a)) return 1;
+  if (a.x2) {                                          // forward over the concatenation of two sources (danhip_conv2d_fwd_concat2)
+    const bool plain = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.H == a.Ho && a.W == a.Wo;
+    if (!plain || a.mask || a.accumulate || a.ksplit <= 0 || a.ksplit >= a.Kpad / 64) return 1;
+    const int bn2 = pw_bn(a, false);
+    return bn2 == 256 ? launch_pw_concat2<256, 3>(a, s) : bn2 == 128 ? launch_pw_concat2<128, 4>(a, s) : launch_pw_concat2<64, 4>(a, s);
+  }
   const bool dgrad = !a.bias && !a.relu;
   if (!dgrad && (a.mask || a.accumulate)) return 1;
   const bool ld = dgrad ? (a.mask || a.accumulate) : true;
   const int bn = pw_bn(a, dgrad && ld);
   if (dgrad) {
-    if (ld) return bn == 128 ? launch_pw<128, 4, true, true>(a, s) : launch_pw<64, 4, true, true>(a, s);
+    if (ld) return bn == 256 ? launch_pw<256, 3, true, true>(a, s) : bn == 128 ? launch_pw<128, 4, true, true>(a, s) : launch_pw<64, 4, true, true>(a, s);
     return bn == 256 ? launch_pw<256, 3, true, false>(a, s) : bn == 128 ? launch_pw<128, 4, true, false>(a, s) : launch_pw<64, 4, true, false>(a, s);
   }
   return bn == 256 ? launch_pw<256, 3, false, true>(a, s) : bn == 128 ? launch_pw<128, 4, false, true>(a, s) : launch_pw<64, 4, false, true>(a, s);

@@ -123,10 +123,37 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         outs = []
         for i, f in enumerate(feature_layers):
             c = f.shape[-1]
-            s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))      # (sic)
-            rs = self._cr(f, c - c // 3, (1, 1), "{}/residual_conv_1x1_{}".format(name, i))
-            outs.append(self.se_inception_block(ops.concat([s1, rs]), "{}/predict_stage2_{}".format(name, i)))
+            s1n, rsn = "{}/satge1_conv_1x1_{}".format(name, i), "{}/residual_conv_1x1_{}".format(name, i)      # (sic)
+            if self.FUSED_STAGE2_MIX and f.dtype == ops.ACT and c % 64 == 0 and f.is_contiguous() and feature_stage1[i].shape == f.shape:
+                mixed = self._stage2_mix_fused(feature_stage1[i], f, s1n, rsn)
+            else:
+                s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), s1n)
+                rs = self._cr(f, c - c // 3, (1, 1), rsn)
+                mixed = ops.concat([s1, rs])
+            outs.append(self.se_inception_block(mixed, "{}/predict_stage2_{}".format(name, i)))
         return outs
+
+    # False (or DANHIP_FUSED_STAGE2_MIX=0 at import): the two ragged 1x1 convolutions + concat (the form up to round 4; A/B and tests)
+    FUSED_STAGE2_MIX = os.environ.get("DANHIP_FUSED_STAGE2_MIX", "1") == "1"
+
+    def _stage2_mix_fused(self, stage1, f, s1n, rsn):
+        """concat([relu(conv1x1(stop_gradient(stage1), C // 3)), relu(conv1x1(f, C - C // 3))]) as ONE 1x1 over the (never written) channel
+        concatenation [stage1 | f] with the block-diagonal kernel diag(W1, W2) - ops._ConcatMix.  The two TF variables keep their names and
+        shapes: in the trainer's flat buffer they are the diagonal blocks of one [1, 1, 2C, C] block (VariableStore.fuse "blockdiag")."""
+        c = f.shape[-1]
+        c3 = c // 3
+        V = self.vs
+        w1 = V.get(s1n + "/kernel", (1, 1, c, c3), "glorot")
+        b1 = V.get(s1n + "/bias", (c3,), "zeros")
+        w2 = V.get(rsn + "/kernel", (1, 1, c, c - c3), "glorot")
+        b2 = V.get(rsn + "/bias", (c - c3,), "zeros")
+        wv = V.fuse((s1n + "/kernel", rsn + "/kernel"), axis="blockdiag")
+        bv = V.fuse((s1n + "/bias", rsn + "/bias"), axis=0)
+        if wv is None or bv is None:                   # no trainer laid the block out: build it (plain autograd slices its gradient apart again)
+            z1, z2 = w1.new_zeros((1, 1, c, c - c3)), w2.new_zeros((1, 1, c, c3))
+            wv = torch.cat([torch.cat([w1, z1], dim=3), torch.cat([z2, w2], dim=3)], dim=2).contiguous()
+            bv = torch.cat([b1, b2])
+        return ops.concat_conv1x1_relu(stage1, f, wv, bv, split=(c, c3), trace_params=(w1, w2))
 
     def get_predict_module(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name=None):
         """net/danet.py:469-532: shared 3x3 conv (ReLU) in front of the loc / cls convs of every level."""

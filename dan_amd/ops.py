@@ -5,6 +5,7 @@ Gradient sinks: when a parameter carries a `_danhip_grad` tensor (a view into th
 buffer) the backward kernels accumulate straight into it and return None to autograd; otherwise a fresh
 gradient tensor is returned as usual (used by the parity tests with torch.autograd.grad).
 """
+import contextlib
 import ctypes
 import os
 
@@ -1210,6 +1211,126 @@ def context_block(x, params, hook_order, trace_params=None):
         _CB_LAST.clear()
     if yslot is not None:
         yslot.__init__(out, False)
+        out._dh_slot = yslot
+    return out
+
+
+class _ConcatMix(torch.autograd.Function):
+    """out = relu([a | f] . Wv + bv) with a BLOCK-DIAGONAL Wv = diag(W1, W2): two 1x1 convolutions of two different maps written side by side
+    into one map, i.e. concat([relu(conv1x1(a, W1)), relu(conv1x1(f, W2))]) — DAN's stage-2 input mix (net/danet.py:944-950), whose
+    85 / 171 (170 / 342, 341 / 683) column counts fit no tile and went through the flat-M kernel plus torch.cat and, in backward, a slice
+    pass per part — as ONE streaming GEMM over the never-materialised concatenation (danhip_conv2d_fwd_concat2) — round 4.
+    `a` carries no gradient (the reference puts a stop_gradient on it).  Backward: the weight gradient of each input's [C, Co] row block by the
+    ordinary 1x1 kernel against the FULL output gradient, after which the off-diagonal blocks (columns of the other part) are cleared;
+    f's data gradient through the row block of f over all output columns (zeros where W1's columns are): dense 256-wide tiles, no ragged K."""
+
+    @staticmethod
+    def forward(ctx, a, f, fslot, yslot, handles, split, wv, bv):
+        N, H, W, C1 = a.shape
+        C2 = f.shape[-1]
+        Co = wv.shape[3]
+        dev = a.device
+        assert a.dtype == ACT and f.dtype == ACT and a.is_contiguous() and f.is_contiguous() and a.shape[:3] == f.shape[:3]
+        assert tuple(wv.shape[:3]) == (1, 1, C1 + C2) and wv.is_contiguous() and not a.requires_grad
+        wvp, bvp, lowp = handles
+        need_bwd = f.requires_grad or wv.requires_grad or bv.requires_grad or _sink_trainable(wv)
+        d = _desc(N, H, W, C1 + C2, Co, 1, 1, 1)
+        wf, _ = packed_weights(d, wv, wvp, False)
+        out = torch.empty((N, H, W, Co), dtype=ACT, device=dev)
+        e0 = _prof_begin()
+        if C1 == C2 and _lib.lib().danhip_conv2d_fwd_concat2_supported(ctypes.byref(d), C1, C1):
+            call("danhip_conv2d_fwd_concat2", ctypes.byref(d), ptr(a), ptr(f), C1, C1, ptr(wf), ptr(bv.detach()), ptr(out), 1, stream())
+        else:                                            # small maps (the 20^2 .. 5^2 levels): concatenate, then the split-K / flat-M kernels
+            x = torch.cat([a, f], dim=-1)
+            ws, nws = _conv_scratch(d, 0, dev)
+            call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(bv.detach()), ptr(out), BF16, 1, None, ptr(ws), nws, stream())
+        _prof_end(e0, d, 0)
+        ctx.dims = (N, H, W, C1, C2, Co)
+        ctx.fslot, ctx.yslot, ctx.handles, ctx.split = fslot, yslot, handles, split
+        ctx.set_materialize_grads(False)
+        ctx.trainable = _sink_trainable(wv), _sink_trainable(bv)
+        wb_low = None
+        if need_bwd and f.requires_grad:
+            d2 = _desc(N, H, W, C2, Co, 1, 1, 1)
+            low = lowp if lowp is not None else wv[:, :, C1:, :]
+            _, wb_low = packed_weights(d2, low, lowp, True)
+        ctx.save_for_backward(a, f, out, wb_low)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, f, out, wb_low = ctx.saved_tensors
+        N, H, W, C1, C2, Co = ctx.dims
+        dev = a.device
+        M = N * H * W
+        g = ctx.yslot.take() if ctx.yslot is not None else None          # slot deliveries are already multiplied by (out > 0)
+        if dy is not None:
+            dy = dy.contiguous().clone()
+            call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(out), None, M, Co, stream())
+            g = dy if g is None else g.add_(dy)
+        if g is None:
+            return (None,) * 8
+        wvp, bvp, lowp = ctx.handles
+        c1, o1 = ctx.split
+        need_dw = ctx.needs_input_grad[6] or ctx.trainable[0]
+        need_db = ctx.needs_input_grad[7] or ctx.trainable[1]
+        # ---- f's data gradient first (it heads the critical path): dF = g . W[C1:, :]^T, delivered into f's slot (+ its ReLU backward)
+        df = None
+        if ctx.needs_input_grad[1]:
+            d2 = _desc(N, H, W, C2, Co, 1, 1, 1)
+            ws, nws = _conv_scratch(d2, 1, dev)
+            e0 = _prof_begin()
+            xs = ctx.fslot
+            if xs is not None:
+                buf, acc = xs.target()
+                call("danhip_conv2d_bwd_data_ws", ctypes.byref(d2), ptr(g), ptr(wb_low), ptr(f) if xs.is_relu else None, ptr(buf), acc, ptr(ws), nws, stream())
+            else:
+                df = torch.empty_like(f)
+                call("danhip_conv2d_bwd_data_ws", ctypes.byref(d2), ptr(g), ptr(wb_low), None, ptr(df), 0, ptr(ws), nws, stream())
+            _prof_end(e0, d2, 5 if (xs is not None and xs.is_relu) else 1)
+        dwv = dbv = None
+        if need_dw:
+            sink = _grad_sink(wvp) if wvp is not None else None
+            dw = sink if sink is not None else torch.zeros((1, 1, C1 + C2, Co), dtype=torch.float32, device=dev)
+            db = None
+            if need_db:
+                bs = _grad_sink(bvp) if bvp is not None else None
+                db = bs if bs is not None else torch.zeros(Co, dtype=torch.float32, device=dev)
+                if bs is None:
+                    dbv = db
+            if sink is None:
+                dwv = dw
+            # row block of a (+ the bias gradient: column sums of g), row block of f; then the columns of the OTHER part go back to zero
+            _wgrad_launch(_desc(N, H, W, C1, Co, 1, 1, 1), a, g, dw[:, :, :C1, :], db, C1, (g,))
+            _wgrad_launch(_desc(N, H, W, C2, Co, 1, 1, 1), f, g, dw[:, :, C1:, :], None, C2, (g,))
+            if c1 is not None:
+                side = _WGRAD["side"] if _WGRAD["on"] else None
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    dw[:, :, :c1, o1:].zero_()
+                    dw[:, :, c1:, :o1].zero_()
+        elif need_db:
+            raise NotImplementedError("a trainable bias without its kernel (no reference graph has one)")
+        if GRAD_READY_HOOK is not None and wvp is not None:
+            GRAD_READY_HOOK(wvp)
+        return None, df, None, None, None, None, dwv, dbv
+
+
+def concat_conv1x1_relu(a, f, wv, bv, split=None, trace_params=None):
+    """relu(conv1x1(concat([a, f]), wv) + bv) without the concatenation; a is treated as a constant (stop_gradient).  wv: [1, 1, Ca + Cf, Co]
+    (a FlatParams block-diagonal block, or any tensor); split = (rows, columns) of its upper-left block when wv is block-diagonal - the
+    off-diagonal blocks of its gradient are then cleared.  trace_params: (w1, w2) kernel Parameters of the two parts (ops.TRACE: tests)."""
+    track = torch.is_grad_enabled() and (f.requires_grad or wv.requires_grad or _sink_trainable(wv))
+    wvp = wv if (isinstance(wv, torch.nn.Parameter) or hasattr(wv, "_danhip_grad")) else None
+    bvp = bv if (isinstance(bv, torch.nn.Parameter) or hasattr(bv, "_danhip_grad")) else None
+    lowp = getattr(wv, "_danhip_lower", None)
+    yslot = _new_slot(track)
+    out = _ConcatMix.apply(a.detach(), f, _slot_of(f) if (track and f.requires_grad) else None, yslot, (wvp, bvp, lowp),
+                           split if split is not None else (None, None), wv, bv)
+    if TRACE is not None and trace_params is not None and split is not None:
+        TRACE[id(trace_params[0])] = out.detach()[..., :split[1]].contiguous()
+        TRACE[id(trace_params[1])] = out.detach()[..., split[1]:].contiguous()
+    if yslot is not None:
+        yslot.__init__(out, True)
         out._dh_slot = yslot
     return out
 

@@ -43,7 +43,12 @@ class FlatParams(object):
                 continue
             if name in group_of:
                 key, axis = group_of[name]
-                units.append((name, list(key), axis, sum(byname[k].numel() for k in key)))
+                if axis == "blockdiag":              # two HWIO kernels of DIFFERENT inputs as one block-diagonal kernel over [x1 | x2]
+                    p1, p2 = byname[key[0]], byname[key[1]]
+                    numel = p1.shape[0] * p1.shape[1] * (p1.shape[2] + p2.shape[2]) * (p1.shape[3] + p2.shape[3])
+                else:
+                    numel = sum(byname[k].numel() for k in key)
+                units.append((name, list(key), axis, numel))
             else:
                 units.append((name, [name], None, p.numel()))
         sizes = [u[3] for u in units]
@@ -66,6 +71,26 @@ class FlatParams(object):
                 p.data = self.w[s:s + n].view(p.shape)
                 p.grad = self.g[s:s + n].view(p.shape)
                 p._danhip_grad = p.grad
+            elif axis == "blockdiag":
+                # [kh, kw, c1 + c2, o1 + o2] with the members on the diagonal and zeros elsewhere: the zeros get no gradient (ops._ConcatMix
+                # clears the off-diagonal blocks of the weight gradient), so weight decay and momentum keep them at exactly zero
+                p1, p2 = [byname[k] for k in members]
+                kh, kw, c1, o1 = p1.shape
+                shape = [kh, kw, c1 + p2.shape[2], o1 + p2.shape[3]]
+                wblock, gblock = self.w[s:s + n].view(shape), self.g[s:s + n].view(shape)
+                for q, (r0, r1, q0, q1) in ((p1, (0, c1, 0, o1)), (p2, (c1, shape[2], o1, shape[3]))):
+                    wblock[:, :, r0:r1, q0:q1].copy_(q.data)
+                    q.data = wblock[:, :, r0:r1, q0:q1]
+                    q.grad = gblock[:, :, r0:r1, q0:q1]
+                    q._danhip_grad = q.grad
+                wblock._danhip_grad = gblock
+                wblock._danhip_members = [p1, p2]
+                wblock._danhip_blockdiag = (c1, o1)
+                lower = wblock[:, :, c1:, :]                 # [kh, kw, c2, o1 + o2]: the second input's kernel over ALL output columns (its
+                lower._danhip_grad = gblock[:, :, c1:, :]    # data gradient reads the full output gradient: no ragged column slice)
+                lower._danhip_members = [p2]
+                wblock._danhip_lower = lower
+                vs.fused[tuple(members)] = wblock
             else:
                 ps = [byname[k] for k in members]
                 ax = axis % ps[0].dim()

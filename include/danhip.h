@@ -51,6 +51,7 @@ int danhip_version(void);
  *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 form by the offsets' statistics (on the device), 1 always the
  *                                           gather form with a +-2 px window, 2 always the fp32-atomics scatter form, 3 gather form, +-1 px
  *   "halo_general_epilogue" [DANHIP_HALO_GENERAL_EPILOGUE, 0]  1: csrc/conv_halo.hip always takes its general epilogue (A/B of the lean one)
+ *   "pw_dgrad_ld_bn" [DANHIP_PW_DGRAD_LD_BN, 128]  256: csrc/conv_pointwise.hip's data gradient with a ReLU mask / accumulation may take 256-wide tiles
  * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
 int danhip_set_option(const char* name, int value);
 int danhip_get_option(const char* name);
@@ -147,6 +148,17 @@ int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint16_t* x, co
 int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d);
 int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
                                 uint16_t* dx, int accumulate, void* stream);
+
+/* Forward 1x1 / stride-1 convolution over the CHANNEL CONCATENATION of two NHWC tensors that is never written:
+ *   y = relu([x1 | x2] . W + b),  d->Cin = c1 + c2,  wf_packed = the forward packing of the [1, 1, c1 + c2, Cout] kernel.
+ * Replaces tf.concat + conv2d where the reference feeds a 1x1 from two maps; with a block-diagonal kernel it is two 1x1 convolutions of
+ * different inputs written side by side into one map - DAN's stage-2 input mix (/root/reference/net/danet.py:944-950:
+ * concat([conv1x1(stop_gradient(stage1), C/3), conv1x1(feature, C - C/3)]), whose ragged 85 / 171 column counts no tile fits).
+ * x1 holds c1 channels, x2 holds Cin - c1, both with pixel pitch src_pitch elements; c1, Cin - c1 and Cout multiples of 64.
+ * _supported(): 1 when the streaming GEMM takes this shape (else concatenate on the host side and call danhip_conv2d_fwd). */
+int danhip_conv2d_fwd_concat2_supported(const danhip_conv_desc* d, int32_t c1, int32_t src_pitch);
+int danhip_conv2d_fwd_concat2(const danhip_conv_desc* d, const uint16_t* x1, const uint16_t* x2, int32_t c1, int32_t src_pitch,
+                              const uint16_t* wf_packed, const float* bias, uint16_t* y, int relu, void* stream);
 
 /* Channel-slice views (round 4; net/danet.py:842-918: every branch of the context block is a channel slice of a wider tensor - the fused
  * input 1x1's output, the concat buffer).  A slice [.., c0 : c0 + C] of an NHWC tensor whose pixels are `ld` elements apart is its base

@@ -174,6 +174,46 @@ def test_fused_head_blocks_in_the_flat_buffer():
     assert torch.equal(vs.export_tf_named()["h/loc_0/bias"], torch.zeros(4))
 
 
+def test_flat_params_block_diagonal_fuse():
+    """VariableStore.fuse(..., "blockdiag") (DAN's stage-2 input mix, dan_amd/net/danet.py::_stage2_mix_fused): the two 1x1 kernels become the
+    diagonal blocks of ONE [1, 1, 2C, C] segment of the flat buffers (zeros elsewhere), keep their TF names and shapes, their biases fuse
+    along axis 0 right behind, and the gradient-bucket offsets still descend in backward order."""
+    import torch
+    from dan_amd.net.variables import VariableStore
+    from dan_amd.trainer import FlatParams, GradBuckets
+    C, c3 = 64, 21
+    vs = VariableStore(device="cpu")
+    vs.get("before/kernel", (1, 1, 8, 8), "glorot")
+    w1 = vs.get("m/satge1_conv_1x1_0/kernel", (1, 1, C, c3), "glorot")
+    vs.get("m/satge1_conv_1x1_0/bias", (c3,), 0.25)
+    w2 = vs.get("m/residual_conv_1x1_0/kernel", (1, 1, C, C - c3), "glorot")
+    vs.get("m/residual_conv_1x1_0/bias", (C - c3,), 0.5)
+    vs.get("after/kernel", (1, 1, 8, 8), "glorot")
+    w10, w20 = w1.detach().clone(), w2.detach().clone()
+    kk = ("m/satge1_conv_1x1_0/kernel", "m/residual_conv_1x1_0/kernel")
+    bb = ("m/satge1_conv_1x1_0/bias", "m/residual_conv_1x1_0/bias")
+    assert vs.fuse(kk, "blockdiag") is None and vs.fuse(bb, 0) is None
+    flat = FlatParams(vs)
+    wv, bv = vs.fuse(kk, "blockdiag"), vs.fuse(bb, 0)
+    assert tuple(wv.shape) == (1, 1, 2 * C, C) and wv.is_contiguous() and tuple(bv.shape) == (C,)
+    assert torch.equal(wv[0, 0, :C, :c3], w10[0, 0]) and torch.equal(wv[0, 0, C:, c3:], w20[0, 0])
+    assert wv[0, 0, :C, c3:].eq(0).all() and wv[0, 0, C:, :c3].eq(0).all()
+    assert torch.equal(w1, w10) and torch.equal(w2, w20) and tuple(w1.shape) == (1, 1, C, c3) and tuple(w2.shape) == (1, 1, C, C - c3)
+    assert w1.data_ptr() == wv.data_ptr() and w2.data_ptr() == wv[0, 0, C:, c3:].data_ptr()
+    low = wv._danhip_lower                                  # the second input's rows over ALL columns: what its data gradient multiplies by
+    assert tuple(low.shape) == (1, 1, C, C) and low.is_contiguous() and low.data_ptr() == wv[0, 0, C:, :].data_ptr()
+    assert flat.names == ["before/kernel", "m/satge1_conv_1x1_0/kernel", "m/satge1_conv_1x1_0/bias", "after/kernel"]
+    assert flat.sizes[1:3] == [2 * C * C, C]
+    wv._danhip_grad[0, 0, C + 3, c3 + 2] = 7.0              # a gradient written into the block shows up in the member
+    assert w2.grad[0, 0, 3, 2].item() == 7.0 and w1.grad.eq(0).all()
+    st = GradBuckets(flat).start_of
+    assert st["m/residual_conv_1x1_0/kernel"] == st["m/satge1_conv_1x1_0/kernel"] == flat.starts[1]
+    assert st["after/kernel"] > st["m/satge1_conv_1x1_0/bias"] > st["m/satge1_conv_1x1_0/kernel"] > st["before/kernel"]
+    vs.load_tf_named({"m/residual_conv_1x1_0/kernel": torch.ones(1, 1, C, C - c3)})      # loading by TF name writes through the view
+    assert wv[0, 0, C:, c3:].eq(1).all() and wv[0, 0, C:, :c3].eq(0).all() and torch.equal(wv[0, 0, :C, :c3], w10[0, 0])
+    assert torch.equal(vs.export_tf_named()["m/satge1_conv_1x1_0/kernel"], w10)
+
+
 def test_bench_spawns_its_own_ranks_when_typed_without_a_launcher():
     """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py starts torch.distributed.run as a child before importing torch, the two ranks
     rendezvous on 127.0.0.1 and rank 0 prints the line (DANHIP_BENCH_DRY: the launch plumbing alone, gloo, no GPU)."""

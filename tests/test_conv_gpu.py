@@ -648,6 +648,52 @@ def test_one_barrier_per_step_is_bit_identical_to_the_two_barrier_form(N, H, W, 
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(16, 40, 40, 512, 512, 3), (3, 37, 40, 256, 128, 3), (2, 48, 48, 256, 256, 1), (4, 20, 40, 1024, 512, 1), (2, 40, 40, 256, 64, (3, 1))])
+def test_pointwise_data_gradient_256_wide_tiles_with_epilogue_inputs(N, H, W, Cin, Cout, k, dev):
+    """Round 4: conv_pointwise.hip's data gradient WITH a ReLU mask / accumulation can take 256-wide tiles too (option pw_dgrad_ld_bn = 256;
+    conv5_x, fc6, the 256-channel pyramid levels: dY is read once instead of Cin / 128 times - measured no faster, so 128 stays the default).
+    The K walk of every output is the same in both tilings, so the results must be bit-identical, in all three epilogue modes, and right
+    against the fp32 product."""
+    import ctypes
+    from dan_amd import _lib, ops
+    kh, kw = (k, k) if isinstance(k, int) else k
+    g = torch.Generator().manual_seed(Cin + Cout + kh)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT)
+    w = (torch.randn((kh, kw, Cin, Cout), generator=g) / (kh * kw * Cin) ** 0.5).to(ops.ACT).float()
+    dy = torch.randn((N, H, W, Cout), generator=g).to(ops.ACT)
+    old = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT)
+    d = ops._desc(N, H, W, Cin, Cout, kh, kw, 1)
+    _lib.lib().danhip_set_option(b"pw_dgrad_ld_bn", 256)
+    label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), 5 | 16).decode()
+    _lib.lib().danhip_set_option(b"pw_dgrad_ld_bn", 128)
+    assert label.startswith("conv_pointwise_kernel<256, 3, true, true"), label
+    _, wb = ops.pack_conv_weight(d, w.to(dev), need_bwd=True)
+    xd, dyd, oldd = x.to(dev), dy.to(dev), old.to(dev)
+    xr = x.float().requires_grad_(True)
+    T.conv2d_same(xr, w, None, stride=1, relu=False).backward(dy.float())
+    ref = xr.grad
+
+    def run(masked, acc):
+        dx = oldd.clone()
+        _lib.call("danhip_conv2d_bwd_data", ctypes.byref(d), _lib.ptr(dyd), _lib.ptr(wb), _lib.ptr(xd) if masked else None, _lib.ptr(dx), acc, _lib.stream())
+        torch.cuda.synchronize()
+        return dx
+
+    try:
+        for masked, acc in ((True, 0), (False, 1), (True, 1)):
+            _lib.lib().danhip_set_option(b"pw_dgrad_ld_bn", 128)
+            narrow = run(masked, acc)
+            _lib.lib().danhip_set_option(b"pw_dgrad_ld_bn", 256)
+            wide = run(masked, acc)
+            assert torch.equal(narrow, wide), (masked, acc)
+            want = torch.where(x.float() > 0, ref, torch.zeros_like(ref)) if masked else ref
+            want = want + (old.float() if acc else 0.0)
+            err = (wide.float().cpu() - want).abs().max().item()
+            assert err <= 2.0 ** -7 * want.abs().max().item() + 2e-2, (masked, acc, err)
+    finally:
+        _lib.lib().danhip_set_option(b"pw_dgrad_ld_bn", 128)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k", [(4, 160, 160, 128, 256, 3), (2, 96, 128, 256, 256, 3), (4, 160, 160, 256, 256, 1), (2, 80, 80, 2304, 256, 1)])
 def test_weight_gradient_one_barrier_form_is_bit_identical_in_the_slab_form(N, H, W, Cin, Cout, k, dev):
     """the default one-barrier K-step of conv_wgrad_rows.hip (3x3) / conv_wgrad_pw.hip (1x1) had no bit-identity check.  With
