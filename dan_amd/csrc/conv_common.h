@@ -144,7 +144,7 @@ int danhip_launch_wgrad_pw(const danhip_conv_desc* d, const bf16_t* x, const bf1
                            void* ws = nullptr, size_t ws_bytes = 0, int ldx = 0, int ldy = 0);      // ldx / ldy: pixel pitches (0 = dense)
 size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d);
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
-                             void* ws = nullptr, size_t ws_bytes = 0);
+                             void* ws = nullptr, size_t ws_bytes = 0, int ldx = 0, int ldy = 0);      // ldx / ldy: pixel pitches (0 = dense)
 size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d);
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).

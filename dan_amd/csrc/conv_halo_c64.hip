@@ -58,8 +58,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   };
 
   // ---- patch DMA (same layout as conv_halo.hip: row R = hy*PW + hx, chunk c at position c ^ (hx & 7))
-  const __amdgpu_buffer_rsrc_t rsrc_x =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+  // (channel-slice views, round 4: pixel pitches a.ldx / a.ldy / a.ldm instead of the dense 64 - DAN's 64 -> 64 branch convolutions read and
+  // write slices of wider tensors; the last pixel's row ends 64 channels after its start whatever the pitch)
+  const unsigned npix1 = (unsigned)(a.N * a.H * a.W) - 1u;
+  const unsigned px_x = (unsigned)a.ldx * 2u, px_y = (unsigned)a.ldy * 2u, px_m = (unsigned)a.ldm * 2u;      // bytes per pixel
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)(npix1 * px_x + 128u), 0x00020000);
   auto issue_patch = [&](int sp, int buf) __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(sp, n, y0, x0);
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       const int hy = row / PW, hx = row - hy * PW;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = row < PROWS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-      const unsigned off = ok ? (unsigned)((n * a.H + y) * a.W + x) * 128u + (unsigned)(((ln & 7) ^ (hx & 7)) << 4) : 0xFFFFFFFFu;
+      const unsigned off = ok ? (unsigned)((n * a.H + y) * a.W + x) * px_x + (unsigned)(((ln & 7) ^ (hx & 7)) << 4) : 0xFFFFFFFFu;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_AS void*)(smem + buf * PBYTES + piece * 1024), 16, off, 0, 0, 0);
     }
   };
@@ -85,9 +88,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // and are covered by the tile-end vmcnt(0).  No other wave touches the region: no barrier, no double buffer.
   constexpr int RWBASE = 2 * PBYTES;               // LDS map: [patch 0][patch 1][forward: bias | dgrad: 8 x 4 KiB mask, 8 x 4 KiB old]
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_m =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.mask ? a.mask : a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.mask ? a.mask : a.x), 0, (int)(npix1 * (a.mask ? px_m : px_x) + 128u), 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_o =
-      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.y), 0, (int)((unsigned)(a.N * a.H * a.W) * 128u), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.y), 0, (int)(npix1 * px_y + 128u), 0x00020000);
   // Bit-mask form (ConvArgs::mask_bits, danhip_relu_bits layout: 8 bytes per pixel): the tile's 256 pixels x 8 bytes = 2 KiB are fetched by
   // waves 0 and 1 (one 16-byte DMA per lane = two horizontally adjacent pixels) into one of two 2 KiB buffers — the hand-off barrier that
   // ends the tile publishes them to every wave's epilogue, and the buffer is refilled two tiles later, i.e. behind the NEXT hand-off
@@ -113,10 +116,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int k = 0; k < NPT; ++k) {
       const int t = wm * 64 + k * 16 + (ln >> 2);
       const int y = y0 + t / TW, x = x0 + t % TW;
-      const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * 128u + (unsigned)((wn * 4 + (ln & 3)) << 4) : 0xFFFFFFFFu;
-      if (a.mask) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (LDS_AS void*)(smem + RWBASE + wave * 4096 + k * 1024), 16, off, 0, 0, 0);
+      const bool ok = y < a.H && x < a.W;
+      const unsigned pix = (unsigned)((n * a.H + y) * a.W + x), ch = (unsigned)((wn * 4 + (ln & 3)) << 4);
+      if (a.mask)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_m, (LDS_AS void*)(smem + RWBASE + wave * 4096 + k * 1024), 16, ok ? pix * px_m + ch : 0xFFFFFFFFu, 0, 0, 0);
       if (a.accumulate)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_o, (LDS_AS void*)(smem + RWBASE + 32768 + wave * 4096 + k * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_o, (LDS_AS void*)(smem + RWBASE + 32768 + wave * 4096 + k * 1024), 16, ok ? pix * px_y + ch : 0xFFFFFFFFu,
+                                                 0, 0, 0);
     }
   };
   const int rwaddr = RWBASE + wave * 4096 + ((frow * 4 + fq) << 4);     // + p * 1024 (+ 32768: old value)
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int t = wm * 64 + p * 16 + frow;
         const int y = y0 + t / TW, x = x0 + t % TW;
         const bool ok = y < a.H && x < a.W;
-        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * 64 + cbase;
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * (size_t)a.ldy + cbase;      // (resid / pool_y: dense calls only, ldy = 64)
         if (ok) {
           float v[8] = {acc[0][p][0], acc[0][p][1], acc[0][p][2], acc[0][p][3], acc[1][p][0], acc[1][p][1], acc[1][p][2], acc[1][p][3]};
           if (!DGRAD) {
@@ -328,8 +334,12 @@ int c64_cu_count() {
 bool c64_eligible(const ConvArgs& a) {
   if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.dstride == 1 && a.pad_t == 1 && a.pad_l == 1)) return false;
   if (a.H != a.Ho || a.W != a.Wo || a.C != 64 || a.Co != 64 || a.out_f32 || a.Kpad != 576) return false;
+  if (a.relu && a.relu_co < a.Co) return false;                                    // partial ReLU: the streaming GEMM's epilogue only
+  if (a.strided() && (a.resid || a.pool_y || a.mask_bits || a.bits_out)) return false;      // views: plain conv / masked, accumulating data gradient
+  const int ldmax = a.ldx > a.ldy ? (a.ldx > a.ldm ? a.ldx : a.ldm) : (a.ldy > a.ldm ? a.ldy : a.ldm);
+  if ((a.ldx | a.ldy | a.ldm) & 7) return false;
   const double util = (double)a.H * a.W / ((double)((a.H + 7) / 8 * 8) * (double)((a.W + 31) / 32 * 32));
-  return util >= 0.78 && (int64_t)a.N * a.H * a.W * 128 < (1ll << 32);
+  return util >= 0.78 && (int64_t)a.N * a.H * a.W * ldmax * 2 < (1ll << 32);
 }
 
 template <bool DGRAD>

@@ -429,7 +429,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
   if (!view) {
     const int c8 = danhip_launch_conv_c8(a, s);        // conv1_1: 3 (padded to 8) -> 64 channels, bound by its output write
     if (c8 <= 0) return c8;
-    const int cr = danhip_launch_conv_c64(a, s);       // 3x3 / stride-1, 64 -> 64 channels: register-resident weights
+  }
+  {
+    const int cr = danhip_launch_conv_c64(a, s);       // 3x3 / stride-1, 64 -> 64 channels: register-resident weights (views too)
     if (cr <= 0) return cr;
   }
   const bool sk = prefer_splitk(a);                    // too few tiles for the persistent kernels: split K over workgroups instead

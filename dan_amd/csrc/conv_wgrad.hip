@@ -277,8 +277,8 @@ static int bwd_weight_impl(const danhip_conv_desc* d, const uint16_t* x, const u
     DH_REQUIRE(same || valid, DANHIP_EINVAL, "conv: Ho/Wo (%d,%d) is neither the 'same' nor the 'valid' output size", d->Ho, d->Wo);
   }
   {
-    if (!view) {                                    // (the row-streaming 3x3 kernel addresses dense tensors)
-      const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes);
+    {
+      const int hr = danhip_launch_wgrad_rows(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes, ldx, ldy);
       if (hr <= 0) return hr;
     }
     const int pr = danhip_launch_wgrad_pw(d, x, dy, dw_hwio, db, cin_real, (hipStream_t)stream, ws, ws_bytes, ldx, ldy);

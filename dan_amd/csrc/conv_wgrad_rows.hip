@@ -38,6 +38,7 @@ struct WgRowsArgs {
   float* dw;           // [3,3,cin_real,Cout]
   float* db;           // [Cout] or null
   int N, H, W, C, Co8, Cout, cin_real;
+  int ldx, ldy;        // pixel pitches of x / dy in elements (C / Co8 when dense; channel-slice views of wider tensors otherwise - round 4)
   int tiles_x, total_rows, rows_per_split;
   int ci_tiles, co_tiles, xcd_grouped;
   int ablate;          // timing experiments only (DANHIP_WGRAD_ABLATE=1): skip the epilogue's atomics
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const int steps = (k_end - k_begin) + 2 * (strip_last - strip_first + 1);
   const int V = (steps + DEPTH - 1) / DEPTH * DEPTH;
 
-  const wr_u32x4 rsrc_x = wr_make_rsrc(a.x, (unsigned)(a.N * a.H * a.W) * (unsigned)a.C * 2u);
-  const wr_u32x4 rsrc_y = wr_make_rsrc(a.dy, (unsigned)(a.N * a.H * a.W) * (unsigned)a.Co8 * 2u);
+  // (the last pixel's row ends C / Co8 channels after its start whatever the pitch)
+  const wr_u32x4 rsrc_x = wr_make_rsrc(a.x, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldx + (unsigned)a.C) * 2u);
+  const wr_u32x4 rsrc_y = wr_make_rsrc(a.dy, ((unsigned)(a.N * a.H * a.W - 1) * (unsigned)a.ldy + (unsigned)a.Co8) * 2u);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
 
   // ---- the K-step generator (wave-uniform scalars)
@@ -199,12 +201,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   {
     const int xA = (lane & 7) ^ (((l8 >> 1) & 1) << 1);
     const int chunk = xA ^ ((pc5 & 1) << 2);          // = (lane & 7) ^ (f128(pcol) << 1), pcol = pc5*8 + l8
-    vx = __umul24((unsigned)l8, (unsigned)(a.C * 2)) + (unsigned)(chunk << 4);
+    vx = __umul24((unsigned)l8, (unsigned)(a.ldx * 2)) + (unsigned)(chunk << 4);
     const int cpos = lane % CPP, pxb = ypiece * PXP;
     const int yB = COT == 128 ? (cpos ^ (lp << 1)) : (cpos ^ (((lp >> 1) & 1) << 1));
     const int sb = (pxb >> 3) & 1;
     const int ychunk = yB ^ (COT == 128 ? (sb << 3) : (sb << 2));       // = cpos ^ (f256 / f128 (pxb + lp) << 1)
-    vy = __umul24((unsigned)lp, (unsigned)(a.Co8 * 2)) + (unsigned)(ychunk << 4);
+    vy = __umul24((unsigned)lp, (unsigned)(a.ldy * 2)) + (unsigned)(ychunk << 4);
     if (!(co0 + ychunk * 8 < a.Co8)) vy = 0xFFFFFFFFu;                   // thin heads: channel chunks beyond Co8 are zero-filled
   }
   unsigned vxbad = 0, vybad = 0;                      // column validity of the current strip (all ones = zero fill)
@@ -220,14 +222,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     {
       const int xs = s.x0 - 1 + pc5 * 8;
       const unsigned bady = (s.xvalid && (unsigned)s.xrow < (unsigned)a.H) ? 0u : 0xFFFFFFFFu;
-      const unsigned sbase = (unsigned)(((s.n * a.H + s.xrow) * a.W + xs) * a.C + ci0) * 2u;      // may wrap; exact for valid lanes
+      const unsigned sbase = (unsigned)(((s.n * a.H + s.xrow) * a.W + xs) * a.ldx + ci0) * 2u;      // may wrap; exact for valid lanes
       const unsigned voff = (vx + sbase) | vxbad | bady;
       wr_dma16(rsrc_x, voff, lds0 + XBASE + SL * XS + pc5 * 1024);
     }
     {
       const int xs = s.x0 + ypiece * PXP;
       const unsigned bady = (s.yvalid && (unsigned)s.yrow < (unsigned)a.H) ? 0u : 0xFFFFFFFFu;
-      const unsigned sbase = (unsigned)(((s.n * a.H + s.yrow) * a.W + xs) * a.Co8 + co0) * 2u;
+      const unsigned sbase = (unsigned)(((s.n * a.H + s.yrow) * a.W + xs) * a.ldy + co0) * 2u;
       const unsigned voff = (vy + sbase) | vybad | bady;
       wr_dma16(rsrc_y, voff, lds0 + YBASE + SL * YS + ypiece * 1024);
     }
@@ -593,12 +595,14 @@ size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d) {
 
 // Returns DANHIP_OK when launched, 1 when the shape is not eligible (caller falls back to conv_wgrad.hip).
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
-                             void* ws, size_t ws_bytes) {
+                             void* ws, size_t ws_bytes, int ldx, int ldy) {
   if (!wg_rows_eligible(d)) return 1;
   const int co8 = (d->Cout + 7) / 8 * 8;
+  if (ldx > 0xFFFF || ldy > 0xFFFF) return 1;       // (the lane offsets are 24-bit products)
   WgRowsArgs a{};
   a.x = x; a.dy = dy; a.dw = dw; a.db = db;
   a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->Cin; a.Co8 = co8; a.Cout = d->Cout; a.cin_real = cin_real;
+  a.ldx = ldx ? ldx : d->Cin; a.ldy = ldy ? ldy : co8;
   a.tiles_x = (d->W + 31) / 32;
   a.total_rows = d->N * a.tiles_x * d->H;
   a.div_tx = make_fastdiv(a.tiles_x);

@@ -81,7 +81,8 @@ class VGG16Backbone(pb_net.VGG16Backbone):
     def _se_inception_block_fused(self, inputs, name):
         """The same block as ONE autograd node over channel-slice views (ops._ContextBlock): the three 1x1s of branches 3, 4 and 2 run as
         one convolution (their kernels side by side in the trainer's flat buffer: VariableStore.fuse), branch 2's average pool moves behind
-        its 1x1, every branch writes its slice of the concat buffer directly and reads its slice of the concat's gradient in place.
+        its 1x1, each 3x1 / 1x3 pair runs as one 3x3 ("plus" kernel), every branch writes its slice of the concat buffer directly and reads
+        its slice of the concat's gradient in place.
         Variables are created in the reference's order under the reference's names."""
         c = inputs.shape[-1]
         V = self.vs
@@ -105,7 +106,19 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         wcat, ccat = V.fuse(kn, axis=3), V.fuse(bn, axis=0)        # one block each in the trainer's flat buffer, or None (plain autograd)
         if wcat is None or ccat is None:
             wcat, ccat = torch.cat([w3, w4, w2], dim=3).contiguous(), torch.cat([c3, c4, c2])
-        params = [(w1, c1), (wcat, ccat), (w3a, c3a), (w3b, c3b), (w43, c43), (w4a, c4a), (w4b, c4b), (wr, cr)]
+
+        def plus(va, vb, ba, bb, ca, cb):
+            """The 3x1 and the 1x3 convolution of one input as ONE 3x3 kernel 64 -> 64: 3x1 taps in the middle column for outputs 0..31,
+            1x3 taps in the middle row for outputs 32..63 (a "plus" block of the flat buffers, or built here for plain autograd)."""
+            wp, cp = V.fuse((pre + va + "/kernel", pre + vb + "/kernel"), axis="plus"), V.fuse((pre + va + "/bias", pre + vb + "/bias"), axis=0)
+            if wp is None or cp is None:
+                wp = torch.cat([torch.nn.functional.pad(ba, (0, 0, 0, 0, 1, 1)), torch.nn.functional.pad(bb, (0, 0, 0, 0, 0, 0, 1, 1))], dim=3).contiguous()
+                cp = torch.cat([ca, cb])
+            return wp, cp
+
+        p3 = plus("branch3_conv_3x1", "branch3_conv_1x3", w3a, w3b, c3a, c3b)
+        p4 = plus("branch4_conv_1x3", "branch4_conv_3x1", w4a, w4b, c4a, c4b)
+        params = [(w1, c1), (wcat, ccat), p3, (w43, c43), p4, (wr, cr)]
         # gradient buckets: descending position in the flat buffer (the fused block stands where branch3_conv_1x1 stood)
         hooks = [wr, w4b, w4a, w43, w3b, w3a, w4, w3, w2, w1]
         trace = {"b1": w1, "b2": w2, "b3": w3, "b3a": w3a, "b3b": w3b, "b4": w4, "b43": w43, "b4a": w4a, "b4b": w4b, "res": wr}

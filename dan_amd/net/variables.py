@@ -47,7 +47,9 @@ class VariableStore(torch.nn.Module):
         """Declares that `names` are consumed concatenated along `axis` (one conv for loc_i | cls_i).  Returns the concatenated
         tensor once FlatParams has laid the members out as strided views of one block (no cat / split / re-packing per step), else
         None and the caller concatenates.  axis = "blockdiag" (two HWIO kernels): the members sit on the diagonal of one
-        [kh, kw, c1 + c2, o1 + o2] kernel over the channel concatenation of their two inputs (zeros elsewhere)."""
+        [kh, kw, c1 + c2, o1 + o2] kernel over the channel concatenation of their two inputs (zeros elsewhere).  axis = "plus"
+        (a k x 1 and a 1 x k kernel of the same input): one k x k kernel with the members in its middle column / middle row and their
+        outputs side by side."""
         key = tuple(names)
         if all(key != k for k, _ in self.fuse_groups):
             self.fuse_groups.append((key, axis))

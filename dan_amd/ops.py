@@ -1036,13 +1036,16 @@ def _wgrad_launch(d, xv, dyv, dw, db, cin_real, keep):
 class _ContextBlock(torch.autograd.Function):
     """DAN context module V1, se_inception_block (net/danet.py:842-918), as ONE autograd node over channel-slice views — round 4.
 
-    Forward (10 launches instead of 13 + torch.cat + torch add):
+    Forward (8 launches instead of 13 + torch.cat + torch add):
         hyper[.., 0:64]      = relu(conv1x1_b1(x))                                   written straight into the concat buffer
         T = [b3 | b4 | p2]   = conv1x1(x) with the three kernels side by side (192 columns; ReLU on the first 128 only)
         hyper[.., 64:128]    = relu(avg_pool_2x2_s1(p2))        branch 2's 1x1 commuted in front of the (linear) pool: conv(avg(x)) = avg(conv(x)),
                                                                 its bias included (the average of a constant is the constant)
-        hyper[.., 128:192]   = relu(conv3x1(b3)) | relu(conv1x3(b3))                 inputs are slices of T, outputs slices of hyper
-        U                    = relu(conv3x3(b4));  hyper[.., 192:256] = relu(conv3x1(U)) | relu(conv1x3(U))
+        hyper[.., 128:192]   = relu(conv3x1(b3)) | relu(conv1x3(b3))                 ONE 3x3 convolution 64 -> 64 whose kernel holds the 3x1 taps in its
+                                                                middle column for outputs 0..31 and the 1x3 taps in its middle row for outputs 32..63,
+                                                                zeros elsewhere ("plus" block of the flat buffers): the register-resident 64 -> 64 kernel
+                                                                (conv_halo_c64.hip) and the row-streaming weight gradient take it on the large levels
+        U                    = relu(conv3x3(b4));  hyper[.., 192:256] = relu(conv3x1(U)) | relu(conv1x3(U))       (the same way)
         out                  = relu(conv1x1_res(hyper)) + x
     Backward: d hyper comes out of the residual conv's data gradient already multiplied by (hyper > 0) = every branch's own ReLU mask;
     each branch convolution reads ITS slice of it in place (no slice copies), gradients meet in dT / dU by accumulation, and x receives
@@ -1054,7 +1057,7 @@ class _ContextBlock(torch.autograd.Function):
         N, H, W, C = x.shape
         dev = x.device
         assert x.dtype == ACT and x.is_contiguous() and C % 64 == 0
-        pairs = list(zip(wb[0::2], wb[1::2]))                       # b1, cat, b3a, b3b, b43, b4a, b4b, res
+        pairs = list(zip(wb[0::2], wb[1::2]))                       # b1, cat, b3 plus (3x1 | 1x3), b43, b4 plus, res
         need_bwd = any(t.requires_grad for t in wb) or x.requires_grad or any(_sink_trainable(t) for t in wb)
         T = torch.empty((N, H, W, 192), dtype=ACT, device=dev)
         hyper = torch.empty((N, H, W, 256), dtype=ACT, device=dev)
@@ -1079,12 +1082,10 @@ class _ContextBlock(torch.autograd.Function):
         conv(0, x, hyper[..., 0:64], 1, 1, 64)
         conv(1, x, T, 1, 1, 128)
         call("danhip_avgpool2x2s1_same_fwd_strided", _vptr(T[..., 128:192]), 192, _vptr(hyper[..., 64:128]), 256, N, H, W, 64, 1, stream())
-        conv(2, T[..., 0:64], hyper[..., 128:160], 3, 1, 32)
-        conv(3, T[..., 0:64], hyper[..., 160:192], 1, 3, 32)
-        conv(4, T[..., 64:128], U, 3, 3, 64)
-        conv(5, U, hyper[..., 192:224], 3, 1, 32)
-        conv(6, U, hyper[..., 224:256], 1, 3, 32)
-        conv(7, hyper, r, 1, 1, C)
+        conv(2, T[..., 0:64], hyper[..., 128:192], 3, 3, 64)
+        conv(3, T[..., 64:128], U, 3, 3, 64)
+        conv(4, U, hyper[..., 192:256], 3, 3, 64)
+        conv(5, hyper, r, 1, 1, C)
         call("danhip_add16", ptr(r), ptr(x), ptr(out), out.numel(), stream())
         ctx.descs, ctx.handles, ctx.hook_order = descs, handles, hook_order
         ctx.xslot, ctx.yslot = xslot, yslot
@@ -1127,7 +1128,6 @@ class _ContextBlock(torch.autograd.Function):
         dT = torch.empty_like(T)
         dU = torch.empty_like(U)
         grads = [None] * ctx.nw
-        dbs, dws = [None] * 8, [None] * 8
 
         def sinks(i):
             wp, bp = ctx.handles[i]
@@ -1163,19 +1163,17 @@ class _ContextBlock(torch.autograd.Function):
                 return
             _wgrad_launch(ctx.descs[i], xv, dyv, dw, db, ctx.cin_real[i], (gr, dhyper, dT, dU))
 
-        # residual conv: d hyper = (gr . W^T) * (hyper > 0); then every branch on its slice
-        dgrad(7, gr, hyper, dhyper, 0)
-        wgrad(7, hyper, gr)
-        dgrad(5, dhyper[..., 192:224], U, dU, 0)
-        wgrad(5, U, dhyper[..., 192:224])
-        dgrad(6, dhyper[..., 224:256], U, dU, 1)
-        wgrad(6, U, dhyper[..., 224:256])
-        dgrad(4, dU, T[..., 64:128], dT[..., 64:128], 0)
-        wgrad(4, T[..., 64:128], dU)
-        dgrad(2, dhyper[..., 128:160], T[..., 0:64], dT[..., 0:64], 0)
-        wgrad(2, T[..., 0:64], dhyper[..., 128:160])
-        dgrad(3, dhyper[..., 160:192], T[..., 0:64], dT[..., 0:64], 1)
-        wgrad(3, T[..., 0:64], dhyper[..., 160:192])
+        # residual conv: d hyper = (gr . W^T) * (hyper > 0); then every branch on its slice.  (The weight gradients of the two "plus" kernels
+        # also fill the taps / columns their zeros occupy: FlatParams.mask_structured clears those before the optimizer, plain autograd
+        # slices them away.)
+        dgrad(5, gr, hyper, dhyper, 0)
+        wgrad(5, hyper, gr)
+        dgrad(4, dhyper[..., 192:256], U, dU, 0)
+        wgrad(4, U, dhyper[..., 192:256])
+        dgrad(3, dU, T[..., 64:128], dT[..., 64:128], 0)
+        wgrad(3, T[..., 64:128], dU)
+        dgrad(2, dhyper[..., 128:192], T[..., 0:64], dT[..., 0:64], 0)
+        wgrad(2, T[..., 0:64], dhyper[..., 128:192])
         call("danhip_avgpool2x2s1_same_bwd_strided", _vptr(dhyper[..., 64:128]), 256, _vptr(dT[..., 128:192]), 192, N, H, W, 64, stream())
         if need_dx:
             dgrad(1, dT, xmask, xbuf, 1)
@@ -1193,7 +1191,7 @@ _CB_LAST = {}
 
 
 def context_block(x, params, hook_order, trace_params=None):
-    """params: eight (w, b) pairs in the order b1, cat(b3 | b4 | b2), b3a (3x1), b3b (1x3), b43 (3x3), b4a (3x1), b4b (1x3), res;
+    """params: six (w, b) pairs in the order b1, cat(b3 | b4 | b2), plus(b3a 3x1 | b3b 1x3) as a [3, 3, 64, 64] kernel, b43 (3x3), plus(b4a | b4b), res;
     hook_order: the block's kernel Parameters in reverse creation order (data-parallel gradient buckets); trace_params: {"b1", "b2", "b3",
     "b3a", "b3b", "b4", "b43", "b4a", "b4b", "res"} -> kernel Parameter (ops.TRACE: tests).  -> out (with a gradient slot)."""
     track = torch.is_grad_enabled()

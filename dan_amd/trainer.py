@@ -46,6 +46,9 @@ class FlatParams(object):
                 if axis == "blockdiag":              # two HWIO kernels of DIFFERENT inputs as one block-diagonal kernel over [x1 | x2]
                     p1, p2 = byname[key[0]], byname[key[1]]
                     numel = p1.shape[0] * p1.shape[1] * (p1.shape[2] + p2.shape[2]) * (p1.shape[3] + p2.shape[3])
+                elif axis == "plus":                 # a k x 1 and a 1 x k kernel of the SAME input as one k x k kernel (columns side by side)
+                    p1, p2 = byname[key[0]], byname[key[1]]
+                    numel = p1.shape[0] * p2.shape[1] * p1.shape[2] * (p1.shape[3] + p2.shape[3])
                 else:
                     numel = sum(byname[k].numel() for k in key)
                 units.append((name, list(key), axis, numel))
@@ -62,6 +65,7 @@ class FlatParams(object):
         self.g = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         gm, wd = [], []
+        self.struct_grads, self.struct_masks = [], []     # "plus" blocks: gradient views and their 0 / 1 patterns (mask_structured)
         self.names, self.starts, self.sizes = [], starts, sizes
         self.start_of_member = {}
         for (name, members, axis, n), s in zip(units, starts):
@@ -90,6 +94,29 @@ class FlatParams(object):
                 lower._danhip_grad = gblock[:, :, c1:, :]    # data gradient reads the full output gradient: no ragged column slice)
                 lower._danhip_members = [p2]
                 wblock._danhip_lower = lower
+                vs.fused[tuple(members)] = wblock
+            elif axis == "plus":
+                # [k, k, c, o1 + o2]: the k x 1 member in the middle column for outputs 0 .. o1-1, the 1 x k member in the middle row for the
+                # other outputs, zeros elsewhere.  A weight gradient computed for the whole block also fills the zeros' places:
+                # mask_structured() clears them before the optimizer (weight decay and momentum then keep the zeros exactly zero)
+                p1, p2 = [byname[k] for k in members]
+                k, one, c, o1 = p1.shape
+                assert one == 1 and tuple(p2.shape[:3]) == (1, k, c) and k % 2 == 1, (p1.shape, p2.shape)
+                mid = k // 2
+                shape = [k, k, c, o1 + p2.shape[3]]
+                wblock, gblock = self.w[s:s + n].view(shape), self.g[s:s + n].view(shape)
+                mask = torch.zeros(shape, dtype=torch.float32, device=dev)
+                for q, sl in ((p1, (slice(None), slice(mid, mid + 1), slice(None), slice(0, o1))),
+                              (p2, (slice(mid, mid + 1), slice(None), slice(None), slice(o1, shape[3])))):
+                    wblock[sl].copy_(q.data)
+                    q.data = wblock[sl]
+                    q.grad = gblock[sl]
+                    q._danhip_grad = q.grad
+                    mask[sl] = 1.0
+                wblock._danhip_grad = gblock
+                wblock._danhip_members = [p1, p2]
+                self.struct_grads.append(gblock)
+                self.struct_masks.append(mask)
                 vs.fused[tuple(members)] = wblock
             else:
                 ps = [byname[k] for k in members]
@@ -129,8 +156,15 @@ class FlatParams(object):
     def zero_grad(self):
         self.g.zero_()
 
+    def mask_structured(self):
+        """Clears the gradient entries that stand where a structured block ("plus") holds constant zeros - one multi-tensor launch for all
+        blocks.  Linear, so it commutes with the data-parallel sum: called once per step, after the all-reduce, before the optimizer."""
+        if self.struct_grads:
+            torch._foreach_mul_(self.struct_grads, self.struct_masks)
+
     def sgd_step(self, lr, momentum=0.9, grad_scale=1.0, dynamic_state=None):
         """dynamic_state: fp32[4] device tensor {loss scale, clean steps, growth interval, flag} (danhip_sgd_momentum_flat_dynamic)."""
+        self.mask_structured()
         self.l2.zero_()
         if dynamic_state is not None:
             call("danhip_sgd_momentum_flat_dynamic", ptr(self.w), ptr(self.g), ptr(self.v), ptr(self.seg), ptr(self.gmult), ptr(self.wdc),

@@ -344,6 +344,9 @@ def test_fused_context_block_fires_its_gradient_hooks_in_flat_buffer_order():
             vs.get("%s/%s/bias" % (blk, scope), (co,), "zeros")
         for suffix, axis in (("kernel", 3), ("bias", 0)):
             assert vs.fuse(tuple("%s/%s/%s" % (blk, s, suffix) for s in ("branch3_conv_1x1", "branch4_conv_1x1", "branch2_conv_1x1")), axis=axis) is None
+        for va, vb in (("branch3_conv_3x1", "branch3_conv_1x3"), ("branch4_conv_1x3", "branch4_conv_3x1")):      # the 3x1 | 1x3 pairs as "plus" kernels
+            assert vs.fuse(("%s/%s/kernel" % (blk, va), "%s/%s/kernel" % (blk, vb)), axis="plus") is None
+            assert vs.fuse(("%s/%s/bias" % (blk, va), "%s/%s/bias" % (blk, vb)), axis=0) is None
     vs.get("after/kernel", (3, 3, 64, 64), "glorot")
     flat = FlatParams(vs)
     start = flat.start_of_member
@@ -364,3 +367,23 @@ def test_fused_context_block_fires_its_gradient_hooks_in_flat_buffer_order():
     assert tuple(wcat.shape) == (1, 1, c, 192) and wcat.is_contiguous()
     w4 = dict(vs.named())["s1/branch4_conv_1x1/kernel"]
     assert w4.data_ptr() == wcat[..., 64:128].data_ptr() and not w4.is_contiguous()
+    # each 3x1 | 1x3 pair: one [3, 3, 64, 64] block, the 3x1 member in the middle column (outputs 0..31), the 1x3 member in the middle row
+    named = dict(vs.named())
+    for va, vb in (("s1/branch3_conv_3x1", "s1/branch3_conv_1x3"), ("s2/branch4_conv_1x3", "s2/branch4_conv_3x1")):
+        blkw = vs.fused[(va + "/kernel", vb + "/kernel")]
+        a3, b3 = named[va + "/kernel"], named[vb + "/kernel"]
+        assert tuple(blkw.shape) == (3, 3, 64, 64) and blkw.is_contiguous() and tuple(a3.shape) == (3, 1, 64, 32) and tuple(b3.shape) == (1, 3, 64, 32)
+        assert a3.data_ptr() == blkw[:, 1:2, :, 0:32].data_ptr() and b3.data_ptr() == blkw[1:2, :, :, 32:64].data_ptr()
+        assert torch.equal(blkw[:, 1:2, :, 0:32], a3) and torch.equal(blkw[1:2, :, :, 32:64], b3)
+        rest = blkw.clone()
+        rest[:, 1:2, :, 0:32] = 0
+        rest[1:2, :, :, 32:64] = 0
+        assert rest.eq(0).all()                                   # zeros everywhere else
+        assert tuple(vs.fused[(va + "/bias", vb + "/bias")].shape) == (64,)
+    # the gradient of a whole block also fills the zeros' places: mask_structured clears exactly those
+    assert len(flat.struct_grads) == 4
+    flat.g.fill_(1.0)
+    flat.mask_structured()
+    g3 = vs.fused[("s1/branch3_conv_3x1/kernel", "s1/branch3_conv_1x3/kernel")]._danhip_grad
+    assert g3.sum().item() == 2 * 3 * 64 * 32 and named["s1/branch3_conv_3x1/kernel"].grad.eq(1).all() and named["s1/branch3_conv_1x3/kernel"].grad.eq(1).all()
+    assert named["s1/branch4_conv_3x3/kernel"].grad.eq(1).all() and wcat._danhip_grad.eq(1).all()      # nothing else is touched

@@ -70,7 +70,7 @@ def test_fused_context_block_without_gradients_and_without_slots(dev):
 
 
 @pytest.mark.parametrize("kh,kw,cin,cout,H,W", [(1, 1, 256, 64, 40, 40), (3, 1, 64, 32, 40, 40), (1, 3, 64, 32, 33, 21), (3, 3, 64, 64, 40, 40), (1, 1, 256, 192, 40, 40),
-                                                 (3, 3, 64, 64, 6, 6)])
+                                                 (3, 3, 64, 64, 6, 6), (3, 3, 64, 64, 80, 80), (3, 3, 64, 64, 47, 93), (3, 3, 128, 64, 40, 64)])
 def test_strided_entry_points_equal_the_dense_calls(kh, kw, cin, cout, H, W, dev):
     """danhip_conv2d_{fwd,bwd_data,bwd_weight}_strided on channel slices of wider tensors against the dense calls on contiguous copies of the
     same slices: forward (incl. the partial ReLU), data gradient (mask + accumulate) and weight gradient."""
