@@ -106,6 +106,7 @@ SIGNATURES = {
     "danhip_deform_conv_fwd": [P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_deform_conv_bwd": [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_deform_conv_bwd_with_col": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, P, ctypes.c_size_t, P],
+    "danhip_deform_conv_bwd_deliver": [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_cast_pad_f32_to_bf16": [P, P, P, I64, I32, I32, P],
     "danhip_head_split_fwd": [P, P, P, I32, I32, I32, I32, I32, I32, I32, P],
     "danhip_head_split_bwd": [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P],

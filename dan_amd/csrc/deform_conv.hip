@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t*
 template <int R>
 __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                const float* __restrict__ far_dx, bf16_t* __restrict__ dx, const DeformGeom& g,
-                                                               int accumulate) {
+                                                               int accumulate, const bf16_t* __restrict__ relu_x) {
   constexpr int D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 63) / 64;
   const int offc = g.dg * 18;
   const int lane = threadIdx.x & 63;
@@ -526,6 +526,7 @@ __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __r
     }
     const long o = p * g.C + c;
     float out = acc + far_dx[o];
+    if (relu_x && !(bf2f(relu_x[o]) > 0.f)) out = 0.f;              // x is a ReLU output: its producer's ReLU backward, folded in here
     if (accumulate) out += bf2f(dx[o]);
     dx[o] = f2bf(out);
   }
@@ -533,17 +534,24 @@ __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __r
 
 __global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                         const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                        int accumulate, BwdGate gate) {
+                                                                        int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x) {
   const int form = gate_form(gate);
-  if (form == 0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate);
-  else if (form == 1) deform_bwd_dx_gather9_c64_body<2>(offs, dS, far_dx, dx, g, accumulate);
+  if (form == 0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, relu_x);
+  else if (form == 1) deform_bwd_dx_gather9_c64_body<2>(offs, dS, far_dx, dx, g, accumulate, relu_x);
 }
 
-__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate, BwdGate gate) {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate, BwdGate gate,
+                                   const bf16_t* __restrict__ relu_x) {
   if (gate.stat && !gate_runs(gate, 2)) return;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
     float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (relu_x) {
+      float m[8];
+      unpack8(*reinterpret_cast<const uint4*>(relu_x + i * 8), m);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (!(m[e] > 0.f)) f[e] = 0.f;
+    }
     if (accumulate) {
       float o[8];
       unpack8(*reinterpret_cast<const uint4*>(dst + i * 8), o);
@@ -620,9 +628,10 @@ extern "C" size_t danhip_deform_sample_bwd_workspace_bytes(int32_t N, int32_t H,
 
 /* dS [N*Ho*Wo, kh*kw*C] -> d_offsets bf16 [N,Ho,Wo,dg*2*kh*kw] (overwritten) and dx bf16 [N,H,W,C] (=|+= if accumulate).
  * workspace: N*H*W*C + 64 floats (fp32 scatter target + the far-corner statistic), zeroed inside. */
-extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
-                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
-                                        int32_t deformable_group, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
+                                  int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
+                                  int32_t deformable_group, int accumulate, int relu_x, float* workspace, size_t workspace_bytes, void* stream) {
+  const bf16_t* rx = relu_x ? x : nullptr;              // dx *= (x > 0): x is a ReLU output whose producer takes dx as delivered
   DH_REQUIRE(x && offsets && dS && dx && d_offsets && workspace, DANHIP_EINVAL, "deform_sample_bwd: null pointer");
   DH_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && workspace_bytes >= danhip_deform_sample_bwd_workspace_bytes(N, H, W, C), DANHIP_EWORKSPACE,
              "deform_sample_bwd: workspace of %zu bytes, needs %zu (N*H*W*C + 64 floats)", workspace_bytes,
@@ -646,12 +655,12 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
     hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs, stat);
     const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, 65536));
     hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate);
-    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate);
+    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate, rx);
     // the scatter form's two kernels on small grids (grid-stride loops): empty ~10 us each when a gather form runs
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 2048)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
                        gate);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8, 256, 2048)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, gate);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8, 256, 2048)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, gate, rx);
     DH_LAUNCH_CHECK();
     return DANHIP_OK;
   }
@@ -665,9 +674,16 @@ extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offse
     hipLaunchKernelGGL(deform_sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g);
   }
   DH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, none);
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(nx / 8)), dim3(256), 0, s, workspace, dx, nx / 8, accumulate, none, rx);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
+}
+
+extern "C" int danhip_deform_sample_bwd(const uint16_t* x, const uint16_t* offsets, const uint16_t* dS, uint16_t* dx, uint16_t* d_offsets,
+                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride, int32_t dilation,
+                                        int32_t deformable_group, int accumulate, float* workspace, size_t workspace_bytes, void* stream) {
+  return deform_sample_bwd_impl(x, offsets, dS, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate, 0, workspace,
+                                workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -730,11 +746,11 @@ extern "C" int danhip_deform_conv_fwd(const uint16_t* x, const uint16_t* wf_pack
 
 // `col_saved`: the im2col buffer danhip_deform_conv_fwd left in ITS workspace (same x / offsets), kept alive by the caller — the backward
 // then skips the reference's re-im2col (:744-748; 1.9 GB rewritten per call at 160x160x256, batch 16).  NULL: re-sample as the reference.
-extern "C" int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
-                                               const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
-                                               int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
-                                               int32_t dilation, int32_t deformable_group, int accumulate_dx, void* workspace,
-                                               size_t workspace_bytes, void* stream) {
+static int deform_conv_bwd_impl(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                int32_t dilation, int32_t deformable_group, int accumulate_dx, int relu_x, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   DH_REQUIRE(x && wb_packed && offsets && dy && dx && d_offsets && dw && workspace, DANHIP_EINVAL, "deform_conv_bwd: null pointer");
   const size_t need = danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1);
   DH_REQUIRE(workspace_bytes >= need && need > 0, DANHIP_EWORKSPACE, "deform_conv_bwd: workspace too small");
@@ -746,14 +762,34 @@ extern "C" int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t
   deform_gemm_desc(&d, N, H, W, C, Cout, kh, kw, stride);
   int rc = danhip_conv2d_bwd_data(&d, dy, wb_packed, nullptr, dcol, 0, stream);                       // col gradient = W^T dOut (:700-712)
   if (rc) return rc;
-  rc = danhip_deform_sample_bwd(x, offsets, dcol, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate_dx, scatter,
-                                workspace_bytes - 2 * colb, stream);                                                              // col2im_coord + col2im (:716-741)
+  rc = deform_sample_bwd_impl(x, offsets, dcol, dx, d_offsets, N, H, W, C, kh, kw, stride, dilation, deformable_group, accumulate_dx, relu_x, scatter,
+                              workspace_bytes - 2 * colb, stream);                                                                // col2im_coord + col2im (:716-741)
   if (rc) return rc;
   if (!col_saved) {
     rc = danhip_deform_sample_fwd(x, offsets, col, N, H, W, C, kh, kw, stride, dilation, deformable_group, stream);   // re-im2col (:744-748)
     if (rc) return rc;
   }
   return danhip_conv2d_bwd_weight(&d, col_saved ? col_saved : col, dy, dw, db, kh * kw * C, stream);  // dW += dOut col^T (:750-768)
+}
+
+extern "C" int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                               const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                               int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                               int32_t dilation, int32_t deformable_group, int accumulate_dx, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  return deform_conv_bwd_impl(x, wb_packed, offsets, dy, col_saved, dx, d_offsets, dw, db, N, H, W, C, Cout, kh, kw, stride, dilation, deformable_group,
+                              accumulate_dx, 0, workspace, workspace_bytes, stream);
+}
+
+// The same with the input gradient DELIVERED the way the convolutions hand theirs over (dan_amd.ops.GradSlot): relu_x != 0 multiplies it by
+// (x > 0) - x is then a ReLU output and its producer takes the gradient as final - before accumulate_dx adds what dx already holds.
+extern "C" int danhip_deform_conv_bwd_deliver(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                              const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                              int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                              int32_t dilation, int32_t deformable_group, int accumulate_dx, int relu_x, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  return deform_conv_bwd_impl(x, wb_packed, offsets, dy, col_saved, dx, d_offsets, dw, db, N, H, W, C, Cout, kh, kw, stride, dilation, deformable_group,
+                              accumulate_dx, relu_x, workspace, workspace_bytes, stream);
 }
 
 extern "C" int danhip_deform_conv_bwd(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy, uint16_t* dx,

@@ -1417,9 +1417,10 @@ class _DeformConv(torch.autograd.Function):
     x bf16 [N,H,W,C]; w fp32 [1,1,kh*kw*C,Cout] (the OIHW variable viewed as the GEMM operand); offsets bf16."""
 
     @staticmethod
-    def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot):
+    def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot, xslot=None):
         N, H, W, C = x.shape
         cout = w.shape[-1]
+        ctx.xslot = xslot
         assert x.dtype == ACT and offsets.dtype == ACT and x.is_contiguous() and offsets.is_contiguous()
         assert w.shape == (1, 1, kh * kw * C, cout) and cout % 8 == 0
         Ho, Wo = -(-H // stride), -(-W // stride)
@@ -1458,22 +1459,29 @@ class _DeformConv(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, dy.numel() // cout, cout, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:
-            return (None,) * 12
+            return (None,) * 13
         bp = ctx.b_param
         db_sink = _grad_sink(bp) if bp is not None else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = db_sink if db_sink is not None else torch.zeros(cout, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
+        # x's gradient goes straight into its producer's slot - times (x > 0) when x is a ReLU output, added to what other consumers (the
+        # offset convolution) delivered - instead of through an autograd tensor the producer would clone, mask and add (three map-sized passes)
+        xs = ctx.xslot if ctx.needs_input_grad[0] else None
+        if xs is not None:
+            dx, acc = xs.target()
+            relu_x = 1 if xs.is_relu else 0
+        else:
+            dx, acc, relu_x = torch.empty_like(x), 0, 0
         doff = torch.empty_like(offsets)
         dw = torch.zeros((1, 1, kh * kw * C, cout), dtype=torch.float32, device=x.device)
         nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
-        call("danhip_deform_conv_bwd_with_col", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(col), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout,
-             kh, kw, stride, dilation, dg, 0, ptr(ws), nws, stream())
+        call("danhip_deform_conv_bwd_deliver", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(col), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout,
+             kh, kw, stride, dilation, dg, acc, relu_x, ptr(ws), nws, stream())
         if GRAD_READY_HOOK is not None and bp is not None:
             GRAD_READY_HOOK(bp)
-        return dx, dw, (None if db_sink is not None else db), doff, None, None, None, None, None, None, None, None
+        return (None if xs is not None else dx), dw, (None if db_sink is not None else db), doff, None, None, None, None, None, None, None, None, None
 
 
 def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_group=1, relu=False):
@@ -1488,7 +1496,8 @@ def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_gr
     bp = b if isinstance(b, torch.nn.Parameter) else None
     track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad)
     yslot = _new_slot(track)
-    y = _DeformConv.apply(x, w1x1, b, offsets, kh, kw, stride, dilation, deformable_group, relu, bp, yslot)
+    y = _DeformConv.apply(x, w1x1, b, offsets, kh, kw, stride, dilation, deformable_group, relu, bp, yslot,
+                          _slot_of(x) if (track and x.requires_grad) else None)
     if yslot is not None:
         yslot.__init__(y, relu)
         y._dh_slot = yslot

@@ -403,6 +403,14 @@ int danhip_deform_conv_bwd_with_col(const uint16_t* x, const uint16_t* wb_packed
                                     int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
                                     int32_t dilation, int32_t deformable_group, int accumulate_dx, void* workspace,
                                     size_t workspace_bytes, void* stream);
+/* Same, with the input gradient handed over the way the convolutions hand theirs to the layer below: relu_x != 0 multiplies it by (x > 0)
+ * - x is then a ReLU output (DAN-Deform: the 1x1 'down' convolution, /root/reference/net/danet_deform.py:267-290) and its ReLU backward is
+ * folded into this call - before accumulate_dx adds what dx already holds (the offset convolution's contribution). */
+int danhip_deform_conv_bwd_deliver(const uint16_t* x, const uint16_t* wb_packed, const uint16_t* offsets, const uint16_t* dy,
+                                   const uint16_t* col_saved, uint16_t* dx, uint16_t* d_offsets, float* dw, float* db, int32_t N,
+                                   int32_t H, int32_t W, int32_t C, int32_t Cout, int32_t kh, int32_t kw, int32_t stride,
+                                   int32_t dilation, int32_t deformable_group, int accumulate_dx, int relu_x, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DynamicAnchorRouting custom op (cpp/ExtraLib/dynamic_anchor_routing.cc:32-65 op def, :188-518 kernel; Python name

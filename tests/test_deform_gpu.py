@@ -153,3 +153,49 @@ def test_single_call_entry_points_equal_the_two_halves(dev):
     with pytest.raises(DanhipError):
         call("danhip_deform_conv_fwd", ptr(x.to(dev)), ptr(x.to(dev)), None, ptr(off.to(dev)), ptr(dy), 2, 11, 13, 128, 64, 3, 3, 1, 1, 2, 0, ptr(ws), 16,
              stream())
+
+
+def _deform_block_outputs(use_slots, x, dy, off_std, dev):
+    """The DAN-Deform context module (net/danet_deform.py:267-290: 1x1 down + ReLU -> offset conv | deformable 3x3 + ReLU -> 1x1 up + ReLU,
+    + residual) on random variables with offsets of spread off_std: -> out, d input, {variable: gradient}."""
+    from dan_amd import ops
+    from dan_amd.net import danet_deform
+    from dan_amd.net.variables import VariableStore
+    vs = VariableStore(device=dev, seed=21)
+    bb = danet_deform.VGG16Backbone("channels_last", variables=vs)
+    with torch.no_grad():
+        bb.se_inception_block(x, "blk")
+        g = torch.Generator().manual_seed(22)
+        for n, p in vs.named():
+            if n.endswith("/bias"):
+                p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(dev))
+            if n.endswith("deform_conv/conv2d/kernel"):          # the offset convolution (zero-initialised in the reference)
+                p.copy_((off_std / 48.0 * torch.randn(p.shape, generator=g)).to(dev))
+    ops.USE_SLOTS = use_slots
+    try:
+        xin = x.clone().requires_grad_(True)
+        out = bb.se_inception_block(xin, "blk")
+        out.backward(dy)
+        torch.cuda.synchronize()
+    finally:
+        ops.USE_SLOTS = True
+    return out.detach().float().cpu(), xin.grad.float().cpu(), {n: p.grad.detach().float().cpu() for n, p in vs.named()}
+
+
+@pytest.mark.parametrize("N,H,W,off_std", [(2, 24, 24, 0.5), (1, 19, 33, 2.5)])
+def test_deformable_backward_delivers_into_the_producers_slot(N, H, W, off_std, dev):
+    """Round 4: the deformable convolution's input gradient goes straight into the slot of the layer below (danhip_deform_conv_bwd_deliver:
+    times (x > 0) of the 1x1 'down' convolution's ReLU, added to the offset convolution's contribution) instead of through an autograd tensor
+    that the producer clones, masks and adds.  Against the all-autograd route (ops.USE_SLOTS = False) through the same kernels - gather form
+    (small offsets) and scatter form (large ones)."""
+    from dan_amd import ops
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn((N, H, W, 256), generator=g).to(ops.ACT).to(dev)
+    dy = torch.randn((N, H, W, 256), generator=g).to(ops.ACT).to(dev)
+    y0, dx0, g0 = _deform_block_outputs(False, x, dy, off_std, dev)
+    y1, dx1, g1 = _deform_block_outputs(True, x, dy, off_std, dev)
+    assert torch.equal(y0, y1)
+    assert (dx1 - dx0).norm().item() <= 0.01 * dx0.norm().item()
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert (g1[n] - g0[n]).norm().item() <= 0.01 * g0[n].norm().item() + 1e-6, n
