@@ -105,19 +105,19 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         bn = (pre + "branch3_conv_1x1/bias", pre + "branch4_conv_1x1/bias", pre + "branch2_conv_1x1/bias")
         wcat, ccat = V.fuse(kn, axis=3), V.fuse(bn, axis=0)        # one block each in the trainer's flat buffer, or None (plain autograd)
         if wcat is None or ccat is None:
-            wcat, ccat = torch.cat([w3, w4, w2], dim=3).contiguous(), torch.cat([c3, c4, c2])
+            wcat, ccat = V.build(kn, 3), V.build(bn, 0)
 
-        def plus(va, vb, ba, bb, ca, cb):
+        def plus(va, vb):
             """The 3x1 and the 1x3 convolution of one input as ONE 3x3 kernel 64 -> 64: 3x1 taps in the middle column for outputs 0..31,
-            1x3 taps in the middle row for outputs 32..63 (a "plus" block of the flat buffers, or built here for plain autograd)."""
-            wp, cp = V.fuse((pre + va + "/kernel", pre + vb + "/kernel"), axis="plus"), V.fuse((pre + va + "/bias", pre + vb + "/bias"), axis=0)
+            1x3 taps in the middle row for outputs 32..63 (a "plus" block of the flat buffers, or built by torch ops for plain autograd)."""
+            kk, bk = (pre + va + "/kernel", pre + vb + "/kernel"), (pre + va + "/bias", pre + vb + "/bias")
+            wp, cp = V.fuse(kk, axis="plus"), V.fuse(bk, axis=0)
             if wp is None or cp is None:
-                wp = torch.cat([torch.nn.functional.pad(ba, (0, 0, 0, 0, 1, 1)), torch.nn.functional.pad(bb, (0, 0, 0, 0, 0, 0, 1, 1))], dim=3).contiguous()
-                cp = torch.cat([ca, cb])
+                wp, cp = V.build(kk, "plus"), V.build(bk, 0)
             return wp, cp
 
-        p3 = plus("branch3_conv_3x1", "branch3_conv_1x3", w3a, w3b, c3a, c3b)
-        p4 = plus("branch4_conv_1x3", "branch4_conv_3x1", w4a, w4b, c4a, c4b)
+        p3 = plus("branch3_conv_3x1", "branch3_conv_1x3")
+        p4 = plus("branch4_conv_1x3", "branch4_conv_3x1")
         params = [(w1, c1), (wcat, ccat), p3, (w43, c43), p4, (wr, cr)]
         # gradient buckets: descending position in the flat buffer (the fused block stands where branch3_conv_1x1 stood)
         hooks = [wr, w4b, w4a, w43, w3b, w3a, w4, w3, w2, w1]
@@ -160,12 +160,10 @@ class VGG16Backbone(pb_net.VGG16Backbone):
         b1 = V.get(s1n + "/bias", (c3,), "zeros")
         w2 = V.get(rsn + "/kernel", (1, 1, c, c - c3), "glorot")
         b2 = V.get(rsn + "/bias", (c - c3,), "zeros")
-        wv = V.fuse((s1n + "/kernel", rsn + "/kernel"), axis="blockdiag")
-        bv = V.fuse((s1n + "/bias", rsn + "/bias"), axis=0)
+        kk, bk = (s1n + "/kernel", rsn + "/kernel"), (s1n + "/bias", rsn + "/bias")
+        wv, bv = V.fuse(kk, axis="blockdiag"), V.fuse(bk, axis=0)
         if wv is None or bv is None:                   # no trainer laid the block out: build it (plain autograd slices its gradient apart again)
-            z1, z2 = w1.new_zeros((1, 1, c, c - c3)), w2.new_zeros((1, 1, c, c3))
-            wv = torch.cat([torch.cat([w1, z1], dim=3), torch.cat([z2, w2], dim=3)], dim=2).contiguous()
-            bv = torch.cat([b1, b2])
+            wv, bv = V.build(kk, "blockdiag"), V.build(bk, 0)
         return ops.concat_conv1x1_relu(stage1, f, wv, bv, split=(c, c3), trace_params=(w1, w2))
 
     def get_predict_module(self, feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, name=None):

@@ -53,7 +53,45 @@ class VariableStore(torch.nn.Module):
         key = tuple(names)
         if all(key != k for k, _ in self.fuse_groups):
             self.fuse_groups.append((key, axis))
-        return self.fused.get(key)
+        t = self.fused.get(key)
+        if t is None and not torch.is_grad_enabled() and all(self._key(k) in self.vars for k in key):
+            t = self._inference_block(key, axis)
+        return t
+
+    def build(self, names, axis):
+        """The fused tensor of `names` built with differentiable torch ops (plain autograd without a trainer: its gradient is sliced apart
+        again by autograd; zeros' places receive nothing)."""
+        ps = [self.vars[self._key(k)] for k in names]
+        if axis == "blockdiag":
+            (p1, p2) = ps
+            z1 = p1.new_zeros(tuple(p1.shape[:3]) + (p2.shape[3],))
+            z2 = p2.new_zeros(tuple(p2.shape[:3]) + (p1.shape[3],))
+            return torch.cat([torch.cat([p1, z1], dim=3), torch.cat([z2, p2], dim=3)], dim=2).contiguous()
+        if axis == "plus":
+            (p1, p2) = ps                            # [k, 1, c, o1] in the middle column, [1, k, c, o2] in the middle row
+            h = p1.shape[0] // 2
+            pad = torch.nn.functional.pad
+            return torch.cat([pad(p1, (0, 0, 0, 0, h, h)), pad(p2, (0, 0, 0, 0, 0, 0, h, h))], dim=3).contiguous()
+        return torch.cat(ps, dim=axis).contiguous()
+
+    def _inference_block(self, key, axis):
+        """No trainer has laid the block out and no gradient is being tracked (evaluation scripts): the fused tensor is built once and kept
+        while its members are unchanged; `_danhip_grad = None` marks it for ops' packed-weight cache (packed once, not per call)."""
+        ps = [self.vars[self._key(k)] for k in key]
+        stamp = tuple((p._version, p.data_ptr()) for p in ps)
+        cache = self.__dict__.setdefault("_infer_blocks", {})
+        hit = cache.get((key, axis))
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            t = self.build(key, axis)
+        t._danhip_grad = None
+        if axis == "blockdiag":
+            low = t[:, :, ps[0].shape[2]:, :]
+            low._danhip_grad = None
+            t._danhip_lower = low
+        cache[(key, axis)] = (stamp, t)
+        return t
 
     def buffer(self, name, shape, init):
         """Non-trainable state (batch-norm moving averages): a plain device tensor kept under its TF name."""

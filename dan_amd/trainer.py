@@ -31,6 +31,7 @@ class FlatParams(object):
         named = vs.named()
         dev = named[0][1].device
         byname = dict(named)
+        vs.__dict__.pop("_infer_blocks", None)       # blocks cached for gradient-free passes (VariableStore.fuse): the members move below
         # fused blocks (VariableStore.fuse): the members become strided views of ONE segment, placed where the first member stood
         group_of, members_done = {}, set()
         for key, axis in getattr(vs, "fuse_groups", []):
