@@ -43,5 +43,10 @@ for m in sfd dan dan_deform pb; do
   python3 tools/prof_db.py $OUT/serial_$m/s_results.db 7 60 > $OUT/${m}_b16_serialized_kernels.txt
   rm -rf $OUT/serial_$m
 done
+# event-bracketed per-layer convolution times of one eager DAN step (one stream) and the torch-native launches left on it
+DANHIP_WGRAD_STREAM=0 python3 tools/host_time.py dan layers 2>/dev/null | grep -v "^dan:" > $OUT/dan_b16_layer_times.txt
+python3 tools/host_time.py dan aten 2>/dev/null | grep " x aten\|per step\| x danhip" > $OUT/dan_b16_torch_native_launches.txt
+# the test-time pipeline at 1024 x 768 (eval scripts without a trainer: fused blocks cached per weight version)
+timeout 900 python3 tools/bench_eval.py 2>/dev/null > $OUT/eval_pipeline_1024x768.txt
 rm -rf $OUT/prof
 ls -la $OUT
