@@ -532,7 +532,10 @@ __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __r
   }
 }
 
-__global__ __launch_bounds__(256) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+// (8 waves per SIMD: the gather is two dependent global-load phases per item - offsets, then the dS rows they select - so it lives on
+// occupancy; capping it at 64 VGPRs (4 spilled in the +-2 px body) measured 2.02 -> 1.96 ms at zero offsets, 3.20 -> 3.02 at sigma = 0.3 px
+// (160 x 160 x 256, batch 16).  The opposite trade - prefetching the next item's offsets, 90 VGPRs, 5 waves - was 7-13 % SLOWER.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                         const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
                                                                         int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x) {
   const int form = gate_form(gate);
