@@ -454,7 +454,7 @@ __device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restri
 // dX: one wave per (input pixel, group), lane = candidate during the enumeration, lane = channel during the accumulation
 // ONE launch for both gather windows (the window is picked from the statistics at run time): a form that does not run must not cost a
 // launch of its own on a 65536-block grid (~150 us to retire empty; DAN-Deform has 12 of these calls per step).
-__global__ __launch_bounds__(256) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
                                                                    const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
                                                                    bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
   const int form = gate_form(gate);
