@@ -260,7 +260,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if B < 8 and not args.eager:                      # the per-rank shape of a strong-scaling run: host-bound in eager mode
+    # the per-rank shape of a strong-scaling run is host-bound in eager mode: replay the step as a hipGraph there.  S3FD (≈ 180 launches per
+    # step) stops being host-bound at 4 images per GPU (eager 4.57 ms against 4.77-4.92 replayed: profiles/r4/README.md); the other graphs
+    # (≈ 1000 launches) below 8
+    if B < (4 if args.model == "sfd" else 8) and not args.eager:
         args.graph = True
     if args.graph:                                    # (data-parallel steps are captured too: RCCL collectives are device-side)
         trainer.enable_graph(*step_args)
