@@ -26,8 +26,10 @@ for b in 2 4 8; do
 done
 # BASELINE.json configs[3] / [4] at their input size: per-GPU shards (batch 8 at 1024 x 1024) of DAN (bf16) and DAN-Deform (fp16 build)
 : > $OUT/size1024_lines.jsonl
-python3 bench.py --model dan --size 1024 --batch-per-gpu 8 --steps 5 --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
-DANHIP_DTYPE=fp16 python3 bench.py --model dan_deform --size 1024 --batch-per-gpu 8 --steps 5 --graph --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
+for mode in --eager --graph; do
+  python3 bench.py --model dan --size 1024 --batch-per-gpu 8 --steps 5 $mode --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
+  DANHIP_DTYPE=fp16 python3 bench.py --model dan_deform --size 1024 --batch-per-gpu 8 --steps 5 $mode --no-cpu-baseline --no-serialized-roofline --no-eval 2>/dev/null | tail -1 >> $OUT/size1024_lines.jsonl
+done
 DANHIP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats -d $OUT/serial_dan1024 -o s -- python3 bench.py --eager --model dan --size 1024 --batch-per-gpu 8 --steps 3 --warmup 1 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/serial_dan1024.log 2>&1
 python3 tools/prof_db.py $OUT/serial_dan1024/s_results.db 5 40 > $OUT/dan_1024_b8_serialized_kernels.txt
 rm -rf $OUT/serial_dan1024
