@@ -27,8 +27,8 @@ struct ConvArgs {
   int dstride;   // >1: strided data gradient — a source tap exists only where (h,w) are multiples of dstride (power of two)
   // Channel-slice views (round 4: the DAN context block writes its branches straight into the concat buffer and reads branch inputs
   // out of a wider tensor): pixel pitches in ELEMENTS of x, y and of the mask tensor of a data gradient (a slice [.., c0:c0+C] of an NHWC
-  // tensor of width ld is its base pointer + c0 and pitch ld).  fwd_args / bwd_args set them to the dense values C / Co / Co; only
-  // conv_pointwise.hip and conv_igemm.hip (+ split-K finish) honour other values - strided() sends the call there.
+  // tensor of width ld is its base pointer + c0 and pitch ld).  fwd_args / bwd_args set them to the dense values C / Co / Co;
+  // conv_pointwise.hip, conv_igemm.hip (+ split-K finish) and conv_halo_c64.hip honour other values - strided() keeps the call off the rest.
   int ldx, ldy, ldm;
   int relu_co;   // forward: ReLU applies to output channels < relu_co only (fused 1x1 block whose last columns stay linear); default Co
   bool strided() const { return ldx != C || ldy != Co || (mask && ldm != Co) || (relu && relu_co < Co); }

@@ -730,8 +730,8 @@ extern "C" int danhip_conv2d_fwd_ws(const danhip_conv_desc* d, const uint16_t* x
 }
 
 // ---- channel-slice views (round 4).  x / y (and the data gradient's mask) may be channel slices of wider NHWC tensors: pointer = base + c0,
-// pitch = the wider tensor's channel count.  These calls run on the streaming GEMM / flat-M kernels only (the halo and 64 -> 64 kernels
-// address dense tensors), 16-bit output, no residual.
+// pitch = the wider tensor's channel count.  These calls run on the streaming GEMM / flat-M kernels and, since the second half of round 4,
+// on the register-resident 64 -> 64 kernel (the halo kernel addresses dense tensors); 16-bit output, no residual.
 static int check_pitch(const danhip_conv_pitch* p, int cx, int cy, const char* what) {
   DH_REQUIRE(p != nullptr, DANHIP_EINVAL, "%s: null pitch", what);
   DH_REQUIRE(p->x_pitch >= cx && p->y_pitch >= cy && (p->aux_pitch == 0 || p->aux_pitch >= cy), DANHIP_EINVAL,

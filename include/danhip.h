@@ -164,7 +164,9 @@ int danhip_conv2d_fwd_concat2(const danhip_conv_desc* d, const uint16_t* x1, con
  * input 1x1's output, the concat buffer).  A slice [.., c0 : c0 + C] of an NHWC tensor whose pixels are `ld` elements apart is its base
  * pointer + c0 and pitch ld: x_pitch / y_pitch are the pitches of the call's input / output operand (forward: x, y; data gradient: dy,
  * dx; weight gradient: x, dy), aux_pitch that of the data gradient's relu_mask (0 = dx's channel count).  Multiples of 8 elements.
- * These calls run on the streaming GEMM / flat-M kernels (the halo and 64 -> 64 kernels address dense tensors); 16-bit output, no residual.
+ * These calls run on the streaming GEMM / flat-M kernels and, for 3x3 / stride-1 64 -> 64 on maps the 8 x 32 tiles cover well, on the
+ * register-resident 64 -> 64 kernel (the halo kernel addresses dense tensors); the weight gradient also on the row-streaming kernel;
+ * 16-bit output, no residual.
  * relu_channels (forward): ReLU applies to output channels < relu_channels only (a fused block of 1x1 convolutions whose last columns
  * stay linear); pass Cout for a plain conv_relu, anything with relu = 0 for none. */
 typedef struct { int32_t x_pitch, y_pitch, aux_pitch; } danhip_conv_pitch;
