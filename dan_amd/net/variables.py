@@ -49,7 +49,8 @@ class VariableStore(torch.nn.Module):
         None and the caller concatenates.  axis = "blockdiag" (two HWIO kernels): the members sit on the diagonal of one
         [kh, kw, c1 + c2, o1 + o2] kernel over the channel concatenation of their two inputs (zeros elsewhere).  axis = "plus"
         (a k x 1 and a 1 x k kernel of the same input): one k x k kernel with the members in its middle column / middle row and their
-        outputs side by side."""
+        outputs side by side.  axis = "hwio" (ONE OIHW kernel, the deformable convolution's): stored as the HWIO GEMM operand, the
+        variable being the permuted view."""
         key = tuple(names)
         if all(key != k for k, _ in self.fuse_groups):
             self.fuse_groups.append((key, axis))
@@ -72,6 +73,10 @@ class VariableStore(torch.nn.Module):
             h = p1.shape[0] // 2
             pad = torch.nn.functional.pad
             return torch.cat([pad(p1, (0, 0, 0, 0, h, h)), pad(p2, (0, 0, 0, 0, 0, 0, h, h))], dim=3).contiguous()
+        if axis == "hwio":                           # one OIHW kernel as the [1, 1, kh * kw * C, Cout] GEMM operand (k = tap * C + c)
+            (p1,) = ps
+            co, ci, kh, kw = p1.shape
+            return p1.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * ci, co).contiguous()
         return torch.cat(ps, dim=axis).contiguous()
 
     def _inference_block(self, key, axis):

@@ -1417,17 +1417,19 @@ class _DeformConv(torch.autograd.Function):
     x bf16 [N,H,W,C]; w fp32 [1,1,kh*kw*C,Cout] (the OIHW variable viewed as the GEMM operand); offsets bf16."""
 
     @staticmethod
-    def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot, xslot=None):
+    def forward(ctx, x, w, b, offsets, kh, kw, stride, dilation, dg, relu, b_param, yslot, xslot=None, w_param=None):
         N, H, W, C = x.shape
         cout = w.shape[-1]
         ctx.xslot = xslot
+        ctx.w_param, ctx.block_w = w_param, _sink_trainable(w)
         assert x.dtype == ACT and offsets.dtype == ACT and x.is_contiguous() and offsets.is_contiguous()
         assert w.shape == (1, 1, kh * kw * C, cout) and cout % 8 == 0
         Ho, Wo = -(-H // stride), -(-W // stride)
         assert offsets.shape == (N, Ho, Wo, dg * 2 * kh * kw), (offsets.shape, (N, Ho, Wo, dg * 2 * kh * kw))
         d = _desc(N, Ho, Wo, kh * kw * C, cout, 1, 1, 1)
-        need_bwd = w.requires_grad or x.requires_grad or offsets.requires_grad
-        wf, wb = pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
+        need_bwd = w.requires_grad or x.requires_grad or offsets.requires_grad or ctx.block_w
+        # (w_param: the GEMM operand is a block of the trainer's flat buffers or a cached gradient-free copy: packed once per weight version)
+        wf, wb = packed_weights(d, w, w_param, need_bwd) if w_param is not None else pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
         y = torch.empty((N, Ho, Wo, cout), dtype=ACT, device=x.device)
         keep = KEEP_DEFORM_COL and need_bwd
         if not keep and _lib.lib().danhip_deform_conv_fused(N, H, W, C, cout, kh, kw, stride, dg):
@@ -1459,7 +1461,7 @@ class _DeformConv(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, dy.numel() // cout, cout, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:
-            return (None,) * 13
+            return (None,) * 14
         bp = ctx.b_param
         db_sink = _grad_sink(bp) if bp is not None else None
         db = None
@@ -1474,14 +1476,18 @@ class _DeformConv(torch.autograd.Function):
         else:
             dx, acc, relu_x = torch.empty_like(x), 0, 0
         doff = torch.empty_like(offsets)
-        dw = torch.zeros((1, 1, kh * kw * C, cout), dtype=torch.float32, device=x.device)
+        dw_sink = _grad_sink(ctx.w_param) if ctx.w_param is not None else None       # the flat gradient buffer's block: accumulated in place
+        dw = dw_sink if dw_sink is not None else torch.zeros((1, 1, kh * kw * C, cout), dtype=torch.float32, device=x.device)
         nws = _lib.lib().danhip_deform_conv_workspace_bytes(N, H, W, C, kh, kw, stride, 1)
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         call("danhip_deform_conv_bwd_deliver", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(col), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout,
              kh, kw, stride, dilation, dg, acc, relu_x, ptr(ws), nws, stream())
         if GRAD_READY_HOOK is not None and bp is not None:
             GRAD_READY_HOOK(bp)
-        return (None if xs is not None else dx), dw, (None if db_sink is not None else db), doff, None, None, None, None, None, None, None, None, None
+        if GRAD_READY_HOOK is not None and dw_sink is not None:
+            GRAD_READY_HOOK(ctx.w_param)
+        return ((None if xs is not None else dx), (None if dw_sink is not None else dw), (None if db_sink is not None else db), doff, None, None, None, None,
+                None, None, None, None, None, None)
 
 
 def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_group=1, relu=False):
@@ -1494,10 +1500,11 @@ def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_gr
              stream())
         return _conv2d_f32(S, w1x1, b, 1, relu, None, "same")
     bp = b if isinstance(b, torch.nn.Parameter) else None
-    track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad)
+    wp = w1x1 if hasattr(w1x1, "_danhip_grad") else None
+    track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad or _sink_trainable(w1x1))
     yslot = _new_slot(track)
     y = _DeformConv.apply(x, w1x1, b, offsets, kh, kw, stride, dilation, deformable_group, relu, bp, yslot,
-                          _slot_of(x) if (track and x.requires_grad) else None)
+                          _slot_of(x) if (track and x.requires_grad) else None, wp)
     if yslot is not None:
         yslot.__init__(y, relu)
         y._dh_slot = yslot

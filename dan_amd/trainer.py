@@ -96,6 +96,21 @@ class FlatParams(object):
                 lower._danhip_members = [p2]
                 wblock._danhip_lower = lower
                 vs.fused[tuple(members)] = wblock
+            elif axis == "hwio":
+                # ONE member stored transposed: the deformable convolution's OIHW variable (utility/custom_op.py:134) lives in the flat
+                # buffers as the HWIO GEMM operand [kh * kw * C, Cout] its kernels consume (cached packing, weight gradient written in
+                # place); the TF variable is the permuted VIEW of it - no transposing copy per step in either direction
+                (p1,) = [byname[k] for k in members]
+                co, ci, kh, kw = p1.shape
+                wblock, gblock = self.w[s:s + n].view(kh, kw, ci, co), self.g[s:s + n].view(kh, kw, ci, co)
+                wblock.copy_(p1.data.permute(2, 3, 1, 0))
+                p1.data = wblock.permute(3, 2, 0, 1)
+                p1.grad = gblock.permute(3, 2, 0, 1)
+                p1._danhip_grad = p1.grad
+                w1 = wblock.view(1, 1, kh * kw * ci, co)
+                w1._danhip_grad = gblock.view(1, 1, kh * kw * ci, co)
+                w1._danhip_members = [p1]
+                vs.fused[tuple(members)] = w1
             elif axis == "plus":
                 # [k, k, c, o1 + o2]: the k x 1 member in the middle column for outputs 0 .. o1-1, the 1 x k member in the middle row for the
                 # other outputs, zeros elsewhere.  A weight gradient computed for the whole block also fills the zeros' places:

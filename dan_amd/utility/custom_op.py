@@ -105,7 +105,9 @@ def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, defor
             outs.append(deform_conv_op(xs, fg, offs, rates, "SAME", strides, 1, dl, bias=bg, relu=relu))
         return torch.cat(outs, dim=-1)
     cin = cin_g
-    w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
+    w1x1 = getattr(filter, "_danhip_hwio", None)       # (deform_conv_2d: the variable's GEMM operand where the store keeps one)
+    if w1x1 is None or tuple(w1x1.shape) != (1, 1, kh * kw * cin, cout):
+        w1x1 = filter.permute(2, 3, 1, 0).reshape(1, 1, kh * kw * cin, cout).contiguous()      # OIHW -> HWIO over k = tap*C + c
     if cout % 8 == 0:
         # DeformConvOp / DeformConvBackpropOp as single library calls (danhip_deform_conv_{fwd,bwd})
         y = ops.deform_conv(x, w1x1, bias, offset, kh, kw, stride=int(strides[2]), dilation=int(rates[2]), deformable_group=deformable_group,
@@ -134,6 +136,9 @@ def deform_conv_2d(inputs, num_outputs, kernel_size_h=3, kernel_size_w=3, stride
     if ops.TRACE is not None:                          # tests: the sampling positions of this pass (imposed on the oracle graph)
         ops.TRACE.setdefault("offsets", {})[id(ow)] = offset.detach()
     kernel = variables.get(name + "/kernel", (num_outputs, cin, kernel_size_h, kernel_size_w), kernel_initializer)
+    # the GEMM operand of the OIHW variable: a block of the trainer's flat buffers (the variable is then its permuted view), or the copy
+    # cached per weight version for gradient-free passes, or None (deform_conv_op transposes per call: plain autograd)
+    kernel._danhip_hwio = variables.fuse((name + "/kernel",), axis="hwio")
     bias = None if no_bias else variables.get(name + "/bias", (num_outputs,), "zeros")
     return deform_conv_op(inputs, kernel, offset, [1, 1, dilate_rate, dilate_rate], "SAME", [1, 1, stride, stride], 1, deformable_group, bias=bias, relu=relu)
 

@@ -230,6 +230,36 @@ def test_flat_params_block_diagonal_fuse():
     assert torch.equal(vs.export_tf_named()["m/satge1_conv_1x1_0/kernel"], w10)
 
 
+def test_flat_params_deformable_kernel_as_its_gemm_operand():
+    """VariableStore.fuse((name,), "hwio") (dan_amd/utility/custom_op.py::deform_conv_2d): the deformable convolution's OIHW variable is stored
+    in the flat buffers as the [1, 1, kh * kw * C, Cout] GEMM operand its kernels consume; the TF variable is the permuted view (same name,
+    shape and values; loading / exporting by TF name goes through the view; a gradient written into the block shows up in the variable)."""
+    import torch
+    from dan_amd.net.variables import VariableStore
+    from dan_amd.trainer import FlatParams
+    vs = VariableStore(device="cpu")
+    vs.get("a/kernel", (1, 1, 8, 8), "glorot")
+    k = vs.get("blk/deform_conv/kernel", (16, 8, 3, 3), "glorot_oihw")
+    vs.get("blk/deform_conv/bias", (16,), "zeros")
+    k0 = k.detach().clone()
+    key = ("blk/deform_conv/kernel",)
+    assert vs.fuse(key, "hwio") is None
+    with torch.no_grad():                                # gradient-free pass without a trainer: built once, kept per weight version
+        t = vs.fuse(key, "hwio")
+        assert t is vs.fuse(key, "hwio") and tuple(t.shape) == (1, 1, 72, 16) and t._danhip_grad is None
+        assert torch.equal(t.reshape(3, 3, 8, 16), k0.permute(2, 3, 1, 0))
+    flat = FlatParams(vs)
+    w1 = vs.fuse(key, "hwio")
+    assert tuple(w1.shape) == (1, 1, 72, 16) and w1.is_contiguous() and torch.equal(w1.reshape(3, 3, 8, 16), k0.permute(2, 3, 1, 0))
+    assert tuple(k.shape) == (16, 8, 3, 3) and torch.equal(k, k0) and not k.is_contiguous() and k.data_ptr() == w1.data_ptr()
+    assert flat.names == ["a/kernel", "blk/deform_conv/kernel", "blk/deform_conv/bias"] and flat.sizes[1] == 16 * 8 * 9
+    w1._danhip_grad[0, 0, 2 * 8 + 5, 7] = 3.0             # tap (0, 2), input channel 5, output channel 7
+    assert k.grad[7, 5, 0, 2].item() == 3.0 and k.grad.abs().sum().item() == 3.0
+    vs.load_tf_named({"blk/deform_conv/kernel": torch.full((16, 8, 3, 3), 2.0)})
+    assert w1.eq(2).all()
+    assert torch.equal(vs.export_tf_named()["blk/deform_conv/kernel"], torch.full((16, 8, 3, 3), 2.0))
+
+
 def test_bench_spawns_its_own_ranks_when_typed_without_a_launcher():
     """`python bench.py --gpus 2` (no WORLD_SIZE): bench.py starts torch.distributed.run as a child before importing torch, the two ranks
     rendezvous on 127.0.0.1 and rank 0 prints the line (DANHIP_BENCH_DRY: the launch plumbing alone, gloo, no GPU)."""
