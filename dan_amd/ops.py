@@ -806,8 +806,10 @@ class _ResizeAdd(torch.autograd.Function):
     net/pb_net.py:209-217 / net/danet.py:363-371.  lateral may be None (plain resize to `size`)."""
 
     @staticmethod
-    def forward(ctx, up, lateral, size):
+    def forward(ctx, up, lateral, size, yslot=None):
         N, Hi, Wi, C = up.shape
+        ctx.yslot = yslot
+        ctx.set_materialize_grads(False)
         Ho, Wo = (lateral.shape[1], lateral.shape[2]) if lateral is not None else size
         assert up.dtype == ACT and up.is_contiguous() and C % 8 == 0
         out = torch.empty((N, Ho, Wo, C), dtype=ACT, device=up.device)
@@ -819,12 +821,18 @@ class _ResizeAdd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         N, Hi, Wi, Ho, Wo, C = ctx.dims
-        dout = dout.contiguous()
+        # the merged map feeds two convolutions in the LFPN (this level's fused 3x3 and the next level's upsample 1x1): both deliver into its
+        # slot (write, then accumulate in the kernel epilogue) instead of returning two tensors for the autograd engine to add
+        g = ctx.yslot.take() if ctx.yslot is not None else None
+        if dout is not None:
+            g = dout.contiguous() if g is None else g.add_(dout)
+        if g is None:
+            return None, None, None, None
         dup = None
         if ctx.needs_input_grad[0]:
-            dup = torch.empty((N, Hi, Wi, C), dtype=ACT, device=dout.device)
-            call("danhip_resize_bilinear_add_bwd", ptr(dout), ptr(dup), N, Hi, Wi, Ho, Wo, C, 0, stream())
-        return dup, (dout if ctx.has_lat else None), None
+            dup = torch.empty((N, Hi, Wi, C), dtype=ACT, device=g.device)
+            call("danhip_resize_bilinear_add_bwd", ptr(g), ptr(dup), N, Hi, Wi, Ho, Wo, C, 0, stream())
+        return dup, (g if ctx.has_lat else None), None, None
 
 
 def resize_bilinear_add(up, lateral=None, size=None):
@@ -835,7 +843,13 @@ def resize_bilinear_add(up, lateral=None, size=None):
         call("danhip_resize_bilinear_add_fwd_f32", ptr(up.contiguous()), ptr(lateral.contiguous()) if lateral is not None else None, ptr(out), N, Hi, Wi,
              Ho, Wo, C, stream())
         return out
-    return _ResizeAdd.apply(up, lateral, size)
+    track = torch.is_grad_enabled() and (up.requires_grad or (lateral is not None and lateral.requires_grad))
+    yslot = _new_slot(track)
+    out = _ResizeAdd.apply(up, lateral, size, yslot)
+    if yslot is not None:
+        yslot.__init__(out, False)
+        out._dh_slot = yslot
+    return out
 
 
 class _AvgPool2x2S1(torch.autograd.Function):

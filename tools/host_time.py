@@ -43,9 +43,12 @@ for rep in range(4):
     print("%s: host issue %.2f ms, until GPU done %.2f ms" % (which, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
 if len(sys.argv) > 2 and sys.argv[2] == "aten":
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         tr.train_step(*args)
         torch.cuda.synchronize()
+    for e in prof.key_averages(group_by_input_shape=True):       # which tensors the engine's own adds / copies work on
+        if e.key in ("aten::add_", "aten::add", "aten::copy_", "aten::clone") and e.self_device_time_total > 0:
+            print("%4d x %-12s %8.1f us GPU   shapes %s" % (e.count, e.key, e.self_device_time_total, e.input_shapes))
     rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key.startswith("aten::") and e.self_device_time_total > 0]
     rows.sort(key=lambda e: -e.count)
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,11 +72,34 @@ if len(sys.argv) > 2 and sys.argv[2] == "aten":
         return real_call(name, *a)
 
     ops.call = counting_call
+    # ... and who calls the torch-native in-place adds / clones / fills / copies of 16-bit activations (the profiler gives no Python stacks here)
+    tsites = collections.Counter()
+    patched = {}
+
+    def wrap(name):
+        real = getattr(torch.Tensor, name)
+
+        def f(self, *a, **k):
+            if self.is_cuda and self.numel() >= 1 << 16:
+                fr = [x for x in traceback.extract_stack()[:-1] if here in x.filename and "host_time.py" not in x.filename]
+                tsites[(name, tuple(self.shape), str(self.dtype).replace("torch.", ""),
+                        " <- ".join("%s:%d" % (x.filename.replace(here + "/", ""), x.lineno) for x in fr[-3:][::-1]))] += 1
+            return real(self, *a, **k)
+
+        patched[name] = real
+        setattr(torch.Tensor, name, f)
+
+    for nm in ("add_", "clone", "zero_", "copy_", "contiguous"):
+        wrap(nm)
     tr.train_step(*args)
     torch.cuda.synchronize()
+    for nm, real in patched.items():
+        setattr(torch.Tensor, nm, real)
     ops.call = real_call
     for k, v in sites.most_common():
         print("%4d x danhip_pack_conv_weight   %s" % (v, k))
+    for (name, shp, dt, site), v in sorted(tsites.items(), key=lambda kv: -kv[1]):
+        print("%4d x Tensor.%-10s %-22s %-9s %s" % (v, name, shp, dt, site))
 elif len(sys.argv) > 2 and sys.argv[2] == "layers":
     import collections
     from dan_amd import ops
