@@ -8,9 +8,11 @@
 
 One "step" = one optimisation step on a synthetic batch of 16 images per GPU (BASELINE.json configs[1]); inputs
 (uint8 images, encoded anchor targets) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
-Regions, in order: W warm-up steps | the TIMED region (exactly K steps between barrier + synchronize pairs: `value`, `ms_per_step`) | the
-roofline region (the same K steps again with two HIP events per convolution launch: `roofline`, `kernels`, `event_recording`) | two steps
-with the weight-gradient stream off (`roofline.serialized`) | inference / target-encoder / CPU-baseline legs.
+Regions, in order: W warm-up steps | the TIMED region (exactly K steps between barrier + synchronize pairs: `value`, `ms_per_step`) | two
+more regions of the same K steps (`repeats`: min / median over the three, so a 2-3 % change is told from noise) | the strong-scaling leg
+(`strong`: BASELINE.json configs[2]'s global batch of 128 on these N GPUs, 16-image towers) | the roofline region (the same K steps with
+two HIP events per convolution launch: `roofline`, `kernels`, `event_recording`) | two steps with the weight-gradient stream off
+(`roofline.serialized`) | inference / target-encoder / CPU-baseline legs.
 """
 import argparse
 import json
@@ -94,6 +96,18 @@ def rccl_debug_parse(text):
     return out
 
 
+def strong_plan(global_batch, world, tower_batch=16):
+    """The strong-scaling leg's shape on `world` ranks: (images per rank, towers per rank, images per tower) or None when the fixed global
+    batch does not split (tf_replicate_model_fn.py:461-466: the batch must divide by the number of towers)."""
+    if not global_batch or global_batch % world:
+        return None
+    per_rank = global_batch // world
+    tb = min(tower_batch, per_rank)
+    if per_rank % tb:
+        return None
+    return per_rank, per_rank // tb, tb
+
+
 def csrc_hash():
     """sha256 over the kernel sources (the stamp tools/pmc_traffic.py writes into the PMC traffic file)."""
     import glob
@@ -164,12 +178,16 @@ def cpu_baseline(seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=80, help="steps of the timed region (default 80: about 1 s at batch 16)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong-scaling series (SURVEY 8d): fix the GLOBAL batch; each of the N ranks takes global/N images (default: weak, "
                          "--batch-per-gpu images per rank)")
+    ap.add_argument("--strong-global-batch", type=int, default=128,
+                    help="global batch of the strong-scaling leg printed beside the weak line (BASELINE.json configs[2]: 128 = 16 images per GPU "
+                         "at 8 GPUs); each rank takes global/N images as 16-image towers (train_step_towers); 0 = skip the leg")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each (the first one is `value`; all of them are in `repeats`)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the training step (incl. the bucketed RCCL all-reduce when N > 1) in a hipGraph; off by default")
@@ -194,7 +212,7 @@ def main():
     import torch
     import torch.distributed as dist
     from dan_amd import _lib, ops, synthetic
-    from dan_amd.trainer import init_distributed
+    from dan_amd.trainer import init_distributed, shutdown_distributed
     from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
 
     rccl_log = None
@@ -209,9 +227,10 @@ def main():
             n = int(t.item())
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry": True, "n_gpus": world, "rccl_ranks": n}), flush=True)
+            print(json.dumps({"dry": True, "n_gpus": world, "rccl_ranks": n, "scaling": "weak",
+                              "strong_plan": strong_plan(args.strong_global_batch, world)}), flush=True)
         return
-    multi = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())   # DANHIP_FORCE_DIST: 1-rank group
+    multi = world > 1                                  # a control-plane process group exists (gloo: barriers, scalar statistics)
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was started inside a %d-rank job (WORLD_SIZE): launch it as `python bench.py --gpus %d` (it spawns its "
                          "own ranks) or with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus))
@@ -225,27 +244,29 @@ def main():
     # synthetic shard of this rank (contiguous split of the global batch, tf_replicate_model_fn.py:458-498)
     imgs = synthetic.make_images(B, S, S, dev, seed=synthetic.SEED + rank)
     gts = synthetic.make_gt_boxes(B, S, S, seed=synthetic.SEED + 100 * rank)
+    # args_of(images, gt boxes) -> train_step arguments: the input pipeline's work (anchor encoding), not part of the step
     if args.model == "sfd":
         model = SFDModel(device=dev)
         trainer = SFDTrainer(model, world=world)
         anchors = AnchorConfig(S, S, dev)
-        loc_t, cls_t, _ = anchors.encode_batch(gts)     # input pipeline work (anchor encoding) — not part of the step
-        step_args = (imgs, loc_t, cls_t)
+        args_of = lambda im, gt: (im,) + tuple(anchors.encode_batch(gt)[:2])
         workload = "S3FD VGG-16 backbone + 6 detection heads"
     elif args.model == "pb":
         from dan_amd.train_pb import PBAnchorTargets, PBModel, PBTrainer
         model = PBModel(device=dev)
         trainer = PBTrainer(model, world=world)
-        anchors = PBAnchorTargets(S, S, dev).face
-        step_args = (imgs, PBAnchorTargets(S, S, dev).encode_batch(gts))
+        pbt = PBAnchorTargets(S, S, dev)
+        anchors = pbt.face
+        args_of = lambda im, gt: (im, pbt.encode_batch(gt))
         workload = "PyramidBox (LFPN + CPM + face/head/body heads)"
     else:
         from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
         model = DANModel(device=dev, deform=args.model == "dan_deform")
         anchors = dan_anchor_config(S, S, dev)
         trainer = DANTrainer(model, anchors, world=world)
-        step_args = (imgs,) + encode_batch_dan(anchors, gts)
+        args_of = lambda im, gt: (im,) + tuple(encode_batch_dan(anchors, gt))
         workload = "DAN-Deform (deformable context module)" if args.model == "dan_deform" else "DAN (two-stage heads, dynamic anchor routing)"
+    step_args = args_of(imgs, gts)
     if args.deform_offsets > 0 and args.model == "dan_deform":
         g = torch.Generator().manual_seed(synthetic.SEED + 7)
         with torch.no_grad():
@@ -256,14 +277,23 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
+        """device drained on this rank -> every rank arrived (gloo, host side) -> nothing of the next region has been issued"""
+        torch.cuda.synchronize()
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+
+    def max_over_ranks(*vals):
+        if not multi:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t.tolist())
 
     # the per-rank shape of a strong-scaling run is host-bound in eager mode: replay the step as a hipGraph there.  S3FD (≈ 180 launches per
     # step) stops being host-bound at 4 images per GPU (eager 4.57 ms against 4.77-4.92 replayed: profiles/r4/README.md); the other graphs
-    # (≈ 1000 launches) below 8
-    if B < (4 if args.model == "sfd" else 8) and not args.eager:
+    # (≈ 1000 launches) below 8.  With more than one rank the captured step holds the library's RCCL calls (trainer.RcclComm): that form
+    # has only ever run on a ONE-rank communicator (one-GPU boxes), so it is taken only when --graph asks for it.
+    if B < (4 if args.model == "sfd" else 8) and not args.eager and world == 1:
         args.graph = True
     if args.graph:                                    # (data-parallel steps are captured too: RCCL collectives are device-side)
         trainer.enable_graph(*step_args)
@@ -279,6 +309,44 @@ def main():
         trainer.train_step(*step_args)
     barrier()
     dt = time.perf_counter() - t0
+    # ---- the same region again (--repeats - 1 times): `value` stays the FIRST region's; min / median over all of them say how much of a
+    # difference between two lines is noise
+    region_dts = [dt]
+    for _ in range(max(1, args.repeats) - 1):
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(*step_args)
+        barrier()
+        region_dts.append(time.perf_counter() - r0)
+    # ---- the strong-scaling leg (north_star: ">= 6x strong scaling at 8 GPUs"): a FIXED global batch — BASELINE.json configs[2]'s 128, i.e.
+    # 16 images per GPU at N = 8 — on these N ranks.  Each rank takes its contiguous 128 / N images as 16-image towers, the way the
+    # reference places more towers than devices (tf_replicate_model_fn.py:504-560): every tower's loss carries 1 / (number of towers), the
+    # backward kernels accumulate into the one flat gradient buffer, ONE bucketed all-reduce and ONE optimizer step per global batch.
+    # The driver's per-N lines then hold both series: `value` (weak, 16 images per GPU) and `strong.value` (128 images whatever N is).
+    strong = None
+    G = args.strong_global_batch
+    plan = strong_plan(G, world) if (not args.global_batch and not args.graph) else None
+    if plan:
+        per_rank, T, tb = plan
+        if True:
+            towers = []
+            for t in range(T):                            # rank r owns images [r * per_rank, (r + 1) * per_rank) of the global batch
+                seed_t = synthetic.SEED + 1000 + rank * T + t
+                towers.append(args_of(synthetic.make_images(tb, S, S, dev, seed=seed_t), synthetic.make_gt_boxes(tb, S, S, seed=seed_t + 50000)))
+            ks = max(2, min(args.steps, -(-args.steps * B // per_rank)))       # about as many images as the weak region saw
+            trainer.train_step_towers(towers)
+            barrier()
+            s0 = time.perf_counter()
+            for _ in range(ks):
+                trainer.train_step_towers(towers)
+            barrier()
+            (sdt,) = max_over_ranks(time.perf_counter() - s0)
+            strong = {"scaling": "strong", "global_batch": G, "n_gpus": world, "batch_per_gpu": per_rank, "towers_per_gpu": T, "tower_batch": tb,
+                      "steps": ks, "ms_per_step": round(sdt / ks * 1e3, 3), "value": round(G * ks / sdt, 3), "unit": "images/sec",
+                      "what": "fixed global batch (BASELINE.json configs[2]: 128 = 16 images per GPU at 8 GPUs): every rank runs its share as "
+                              "16-image towers into one gradient buffer (tf_replicate_model_fn.py:504-560), one bucketed all-reduce + one "
+                              "optimizer step per global batch; speed-up over N = value(N) / value(1) of THIS field"}
+            del towers
     # ---- the roofline region: the same steps again, every convolution launch bracketed by HIP events on its launch stream (eager launches
     # only: events cannot be recorded inside a replayed graph, so a graph run records them over two eager steps)
     saved_graph0 = trainer._graph
@@ -311,10 +379,8 @@ def main():
         prof_serial, ops.PROFILE = ops.PROFILE, None
         trainer._graph = saved_graph
         ops.WGRAD_STREAM = True
-    if multi:
-        t = torch.tensor([dt, dt_prof], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_prof = float(t[0].item()), float(t[1].item())
+    dt, dt_prof = max_over_ranks(dt, dt_prof)
+    region_dts = list(max_over_ranks(*region_dts))
 
     # ---- inference leg ("eval FPS"): eval_sfd.py / eval_dan.py single-scale graph (forward + softmax + decode [+ routing]) on the same
     # resident images, outside the timed training region; every rank runs it, the slowest rank's time counts
@@ -326,11 +392,7 @@ def main():
             for _ in range(n):
                 fn()
             barrier()
-            et = time.perf_counter() - e0
-            if multi:
-                t = torch.tensor([et], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                et = float(t.item())
+            (et,) = max_over_ranks(time.perf_counter() - e0)
             return et
         n_eval = max(3, args.steps)
         for _ in range(2):
@@ -365,7 +427,7 @@ def main():
                        "what": "IoU + small-mining match + target encode for the batch, one call (danhip_encode_anchors_batched), bit-exact index work"}
 
     rccl_info = None
-    if rank == 0 and multi and rccl_log and os.path.exists(rccl_log):
+    if rank == 0 and trainer.buckets.rccl is not None and rccl_log and os.path.exists(rccl_log):
         try:
             rccl_info = rccl_debug_parse(open(rccl_log, errors="replace").read())
             rccl_info["bucket_bytes"] = int(getattr(trainer.buckets, "bucket_bytes", 0)) or None
@@ -446,13 +508,20 @@ def main():
             "config": {"workload": "%s, %dx%d %s training (fwd+bwd+SGD), batch %d per GPU" % (workload, S, S, _lib.ACT_NAME, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "anchors_per_image": anchors.num_anchors,
                        "step_launch": "hipGraph replay" if args.graph else "eager",
-                       "rccl_ranks": dist.get_world_size() if multi else 1,
+                       "rccl_ranks": trainer.buckets.rccl.world if trainer.buckets.rccl is not None else 1,
                        "rccl": rccl_info,
-                       "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if multi else None,
+                       "dp_transport": (("rccl %d called by libdanhip (danhip_comm_*), control plane %s" % (trainer.buckets.rccl.version, dist.get_backend() if multi else "none"))
+                                        if trainer.buckets.rccl is not None else (trainer.buckets.transport if trainer.buckets.enabled else None)),
+                       "dp_comm": (os.environ.get("DANHIP_DP_COMM", "allreduce") + "/" + os.environ.get("DANHIP_DP_BUCKET_DTYPE", "f32")) if trainer.buckets.enabled else None,
                        "weight_gradient_stream": bool((not trainer.buckets.enabled or trainer.buckets.device_collectives) and ops.WGRAD_STREAM)},
             "event_recording": {"steps": prof_steps, "ms_per_step": round(dt_prof / prof_steps * 1e3, 3), "launch": "eager",
                                 "what": "the roofline region: the same steps repeated right after the timed region with two HIP events per convolution launch "
                                         "(the timed region records none); its own wall time per step shows what the events cost"},
+            "repeats": {"regions": len(region_dts), "steps_each": args.steps, "ms_per_step": [round(d / args.steps * 1e3, 3) for d in region_dts],
+                        "min_ms_per_step": round(min(region_dts) / args.steps * 1e3, 3),
+                        "median_ms_per_step": round(sorted(region_dts)[len(region_dts) // 2] / args.steps * 1e3, 3),
+                        "value_at_median": round(world * B * args.steps / sorted(region_dts)[len(region_dts) // 2], 3)},
+            "strong": strong,
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],
@@ -464,9 +533,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+    shutdown_distributed(trainer)       # captured graph -> device drained -> RCCL communicator -> control-plane group
 
 
 if __name__ == "__main__":

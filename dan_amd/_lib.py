@@ -122,6 +122,15 @@ SIGNATURES = {
     "danhip_encode_anchors": [P, P, P, P, P, P, P, P, P, I32, FL, FL, FL, FL, FL, P],
     "danhip_decode_anchors": [P, P, P, P, P, P, I32, I32, FL, FL, FL, FL, P],
     "danhip_face_scores": [P, P, P, FL, I64, P],
+    "danhip_comm_load": [ctypes.c_char_p],
+    "danhip_comm_rccl_version": [ctypes.POINTER(ctypes.c_int)],
+    "danhip_comm_unique_id": [P],
+    "danhip_comm_create": [P, I32, I32, I32, ctypes.POINTER(ctypes.c_void_p)],
+    "danhip_comm_destroy": [P],
+    "danhip_comm_info": [P, ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32)],
+    "danhip_comm_allreduce_sum": [P, P, I64, ctypes.c_int, P],
+    "danhip_comm_reduce_scatter_sum": [P, P, P, I64, ctypes.c_int, P],
+    "danhip_comm_allgather": [P, P, P, I64, ctypes.c_int, P],
     "danhip_encode_anchors_batched": [P] * 11 + [I32, I32, I32, I32, I32, FL, FL, FL, I32, FL, FL, FL, FL, FL, FL, P, P, P, P, P,
                                                  ctypes.c_size_t, P],
 }

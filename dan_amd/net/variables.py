@@ -83,7 +83,12 @@ class VariableStore(torch.nn.Module):
         """No trainer has laid the block out and no gradient is being tracked (evaluation scripts): the fused tensor is built once and kept
         while its members are unchanged; `_danhip_grad = None` marks it for ops' packed-weight cache (packed once, not per call)."""
         ps = [self.vars[self._key(k)] for k in key]
-        stamp = tuple((p._version, p.data_ptr()) for p in ps)
+        # What can change the members: an in-place torch op on the Parameter (its version counter), a re-pointed storage (FlatParams),
+        # and writers that neither bumps — `p.data.copy_()` (`.data` carries its own counter) and the optimizer / checkpoint kernels that
+        # write through raw pointers.  Those all advance ops.WEIGHT_EPOCH (FlatParams.sgd_step, checkpoint._bump_weight_epoch,
+        # load_tf_named), so the epoch is part of the stamp (ADVICE r4, high: a restore after a gradient-free forward kept the old block).
+        from .. import ops
+        stamp = (ops.WEIGHT_EPOCH,) + tuple((p._version, p.data_ptr()) for p in ps)
         cache = self.__dict__.setdefault("_infer_blocks", {})
         hit = cache.get((key, axis))
         if hit is not None and hit[0] == stamp:
@@ -117,9 +122,8 @@ class VariableStore(torch.nn.Module):
             if k in self.vars:
                 with torch.no_grad():
                     self.vars[k].copy_(t.to(self.device))
-                if self.fused:                       # members of a fused block are views: cached bf16 packings key on the block
-                    from .. import ops
-                    ops.WEIGHT_EPOCH += 1
+                from .. import ops                    # members of a fused block are views: cached blocks / 16-bit packings key on the epoch
+                ops.WEIGHT_EPOCH += 1
             else:
                 self.vars[k] = torch.nn.Parameter(t.to(self.device).clone())
                 self.order.append(n)

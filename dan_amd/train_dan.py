@@ -119,8 +119,8 @@ class DANTrainer(DetectorTrainer):
                                                    self.routing_seed, 0, counter_dev=self._routing_ctr)
             self._routing_ctr.add_(B * A)
             final_loc = final_loc * self._loc_scale2                                                   # :452
-        acc1 = ops.detection_loss(cls1, loc1, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=True, scale=self.loss_scale / self.world)
-        acc2 = ops.detection_loss(cls2, loc2, final_mask, final_loc, ratio=self.negative_ratio, at_least_one=True, scale=self.loss_scale / self.world)
+        acc1 = ops.detection_loss(cls1, loc1, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=True, scale=self.loss_scale / self.num_towers)
+        acc2 = ops.detection_loss(cls2, loc2, final_mask, final_loc, ratio=self.negative_ratio, at_least_one=True, scale=self.loss_scale / self.num_towers)
         self.last_routing = (final_mask, final_loc)
         return [("stage1", 1.0, acc1), ("stage2", 1.0, acc2)]
 

@@ -72,6 +72,6 @@ class PBTrainer(DetectorTrainer):
         for k in ("face", "head", "body"):
             loc, cls = out[k]
             loc_t, cls_t, _ = targets[k]
-            acc = ops.detection_loss(cls, loc, cls_t, loc_t, ratio=self.negative_ratio, at_least_one=False, scale=self.loss_scale * self.WEIGHTS[k] / self.world)
+            acc = ops.detection_loss(cls, loc, cls_t, loc_t, ratio=self.negative_ratio, at_least_one=False, scale=self.loss_scale * self.WEIGHTS[k] / self.num_towers)
             terms.append((k, self.WEIGHTS[k], acc))
         return terms

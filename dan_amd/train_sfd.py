@@ -119,6 +119,7 @@ class DetectorTrainer(object):
             self.ls_state = torch.tensor([self.loss_scale, 0.0, float(loss_scale_growth_interval), 0.0], dtype=torch.float32, device=model.vs.device)
             self.loss_scale = 1.0                             # host-side factor of the loss terms; the device scalar carries the scale
         self.world = world
+        self.towers = 1                                       # towers of THIS rank inside one step (train_step_towers)
         self.negative_ratio = negative_ratio
         self.momentum = momentum
         self.base_lr = base_lr
@@ -133,6 +134,11 @@ class DetectorTrainer(object):
         self.step_no = 0
         self.last = None
         self._graph = None
+
+    @property
+    def num_towers(self):
+        """number_of_towers of tf_replicate_model_fn.py:615-631 (_scale_loss): every tower's loss carries 1 / (ranks x towers per rank)."""
+        return self.world * self.towers
 
     def _hook(self, p):
         n = self.param_name.get(id(p))
@@ -152,26 +158,48 @@ class DetectorTrainer(object):
             return self._graph_step(images_u8, *targets)
         return self._eager_step(images_u8, *targets)
 
+    def train_step_towers(self, towers):
+        """One optimisation step over SEVERAL towers on this rank, the way the reference places more towers than it has devices
+        (tf_replicate_model_fn.py:504-560 _get_loss_towers loops over the shards; :297-343 sums their gradients): `towers` is a list of
+        train_step argument tuples (contiguous shards of this rank's part of the global batch); every tower differentiates
+        loss_tower / (ranks x len(towers)) into the SAME flat gradient buffer (the backward kernels accumulate), the bucketed all-reduce
+        follows the LAST tower's backward, then one optimizer step.  Eager launches only.  Used by bench.py's strong-scaling series
+        (a fixed global batch on fewer GPUs than it has 16-image shards)."""
+        if self._graph is not None:
+            raise RuntimeError("train_step_towers runs eager steps: build the trainer without enable_graph()")
+        self.towers = len(towers)
+        try:
+            return self._eager_towers(towers)
+        finally:
+            self.towers = 1
+
     def _eager_step(self, images_u8, *targets):
+        return self._eager_towers([(images_u8,) + tuple(targets)])
+
+    def _eager_towers(self, towers):
         self.flat.zero_grad()
         self.buckets.begin_step()
-        ops.GRAD_READY_HOOK = self._hook if self.buckets.enabled else None
-        terms = self.loss_terms(images_u8, *targets)
-        accs = [t[2] for t in terms]
-        # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
-        # collectives are device-side (RCCL; checked on hardware with a one-rank group, tests/test_ddp_gpu.py).  gloo's host-staged
-        # all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
-        if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
-            ops.wgrad_overlap_begin()
-        ops.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
-        try:
-            torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
-        except BaseException:
-            ops.wgrad_overlap_join()                          # never leave the second stream armed behind a failed step
-            raise
-        finally:
-            ops.GRAD_READY_HOOK = None
-            ops.LOSS_SCALE_DEV = None
+        for t, args in enumerate(towers):
+            # gradients become final in the last tower's backward: only then may a bucket leave
+            ops.GRAD_READY_HOOK = self._hook if (self.buckets.enabled and t == len(towers) - 1) else None
+            terms = self.loss_terms(*args)
+            accs = [a[2] for a in terms]
+            # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
+            # collectives are device-side (RCCL; checked on hardware with a one-rank communicator, tests/test_zz_ddp_gpu.py).  gloo's
+            # host-staged all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
+            if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
+                ops.wgrad_overlap_begin()
+            ops.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
+            try:
+                torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
+            except BaseException:
+                ops.wgrad_overlap_join()                      # never leave the second stream armed behind a failed step
+                raise
+            finally:
+                ops.GRAD_READY_HOOK = None
+                ops.LOSS_SCALE_DEV = None
+            if t < len(towers) - 1:
+                ops.wgrad_overlap_join()                      # (the next tower's forward reuses this one's activation buffers)
         self.buckets.finish()
         ops.wgrad_overlap_join()
         lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
@@ -189,7 +217,7 @@ class DetectorTrainer(object):
     # The learning rate is a kernel argument, so the graph is re-captured when the schedule moves.
     def enable_graph(self, images_u8, *targets, warmup=2):
         if self.buckets.enabled and not self.buckets.device_collectives:
-            raise RuntimeError("graph capture of the data-parallel step needs device-side collectives (backend nccl = RCCL), not gloo")
+            raise RuntimeError("graph capture of the data-parallel step needs device-side collectives (DANHIP_DP_TRANSPORT=rccl), not gloo")
         if self.buckets.enabled and self.buckets.check:
             raise RuntimeError("DANHIP_DP_CHECK compares on the host: not capturable")
         self._graph = None
@@ -206,7 +234,9 @@ class DetectorTrainer(object):
         self._graph_lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         g = torch.cuda.CUDAGraph()
         step_no = self.step_no
-        # a process group's watchdog thread polls its events while this thread captures: restrict the capture-safety check to this thread
+        # The collectives are the library's own RCCL calls on the buckets' stream (trainer.RcclComm): recorded like kernels, no framework
+        # thread polls events meanwhile.  RCCL itself may keep helper threads that touch the HIP runtime (proxy / progress), so the
+        # capture-safety check is restricted to this thread when a communicator exists.
         mode = "thread_local" if self.buckets.enabled else "global"
         with torch.cuda.graph(g, capture_error_mode=mode):
             terms = self._eager_step(*self._static)
@@ -221,6 +251,15 @@ class DetectorTrainer(object):
         self.step_no += 1
         self.last = self._graph_terms
         return self._graph_terms
+
+    def close(self):
+        """Drops the captured step (its nodes reference the communicator and the static buffers) and waits for the device: call before
+        the RCCL communicator or the process group is destroyed (trainer.shutdown_distributed does)."""
+        self._graph = None
+        self._graph_terms = None
+        self._recapture = False
+        if self.flat.w.is_cuda:
+            torch.cuda.synchronize()
 
     # ---- checkpoint / resume (the Estimator's save_checkpoints_steps + resume-from-model_dir behaviour, train_dan.py:549-556)
     def save(self, prefix, model_scope, checksums=False):
@@ -252,7 +291,7 @@ class SFDTrainer(DetectorTrainer):
 
     def loss_terms(self, images_u8, loc_targets, cls_targets):
         loc, cls = self.model.forward(images_u8)
-        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=self.loss_scale / self.world)
+        acc = ops.detection_loss(cls, loc, cls_targets, loc_targets, ratio=self.negative_ratio, at_least_one=False, scale=self.loss_scale / self.num_towers)
         return [("face", 1.0, acc)]
 
     def losses(self):

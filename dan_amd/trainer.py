@@ -6,13 +6,84 @@ gradient of loss_rank / N on its contiguous shard of the global batch; gradients
 all-reduce per bucket of the flat gradient buffer, launched on a side stream as soon as the bucket's last gradient
 has been produced so it overlaps the remaining backward kernels); the update is applied identically on every rank.
 """
+import atexit
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
 
 from ._lib import call, ptr, stream
+
+
+class RcclComm(object):
+    """This rank's RCCL communicator behind include/danhip.h's danhip_comm_* (csrc/comm.cpp): collectives are plain asynchronous calls on
+    the CURRENT torch stream — no process-group work objects, no watchdog thread, capturable into a hipGraph like a kernel launch.
+
+    torch.distributed (any backend; gloo by default, see init_distributed) is the CONTROL plane only: it carries the 128-byte unique id
+    from rank 0 to the others.  One communicator per process is shared by every trainer (RcclComm.shared)."""
+    _shared = None
+    _live = weakref.WeakSet()
+
+    def __init__(self, rank, world, device_index):
+        # the RCCL copy PyTorch ships is (or will be) in this process: bind that file rather than a second copy from the loader path
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        call("danhip_comm_load", cand.encode() if os.path.exists(cand) else None)
+        ident = ctypes.create_string_buffer(128)
+        if rank == 0:
+            call("danhip_comm_unique_id", ident)
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        call("danhip_comm_create", ident, world, rank, int(device_index), ctypes.byref(h))
+        self.handle, self.rank, self.world = h, rank, world
+        v = ctypes.c_int(0)
+        call("danhip_comm_rccl_version", ctypes.byref(v))
+        self.version = v.value
+        RcclComm._live.add(self)
+
+    @classmethod
+    def shared(cls, device):
+        if cls._shared is None or cls._shared.handle is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            cls._shared = cls(rank, world, device.index if device.index is not None else torch.cuda.current_device())
+        return cls._shared
+
+    @staticmethod
+    def _dtype(t):
+        return {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
+
+    def all_reduce(self, t):
+        call("danhip_comm_allreduce_sum", self.handle, ptr(t), t.numel(), self._dtype(t), stream())
+
+    def reduce_scatter(self, shard, full):
+        call("danhip_comm_reduce_scatter_sum", self.handle, ptr(full), ptr(shard), shard.numel(), self._dtype(full), stream())
+
+    def all_gather(self, full, shard):
+        call("danhip_comm_allgather", self.handle, ptr(shard), ptr(full), shard.numel(), self._dtype(full), stream())
+
+    def close(self):
+        """Every stream that carries this communicator's collectives must have drained, and every hipGraph holding them must be gone."""
+        if self.handle is not None:
+            h, self.handle = self.handle, None
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            call("danhip_comm_destroy", h)
+        if RcclComm._shared is self:
+            RcclComm._shared = None
+
+
+@atexit.register
+def _close_comms():          # a communicator must not outlive the HIP runtime: close what the program left open, before interpreter teardown
+    for c in list(RcclComm._live):
+        try:
+            c.close()
+        except Exception:
+            pass
 
 
 def lr_schedule(step, base_lr=1e-3, boundaries=(1000, 80000, 100000), factors=(0.1, 1.0, 0.1, 0.01), end_lr=1e-6):
@@ -67,6 +138,7 @@ class FlatParams(object):
         self.v = torch.zeros(self.total, dtype=torch.float32, device=dev)
         gm, wd = [], []
         self.struct_grads, self.struct_masks = [], []     # "plus" blocks: gradient views and their 0 / 1 patterns (mask_structured)
+        self.struct_zero_idx = []                         # ... and the flat-buffer offsets of their constant-zero places
         self.names, self.starts, self.sizes = [], starts, sizes
         self.start_of_member = {}
         for (name, members, axis, n), s in zip(units, starts):
@@ -133,6 +205,7 @@ class FlatParams(object):
                 wblock._danhip_members = [p1, p2]
                 self.struct_grads.append(gblock)
                 self.struct_masks.append(mask)
+                self.struct_zero_idx.append((mask.reshape(-1) == 0).nonzero().reshape(-1) + s)
                 vs.fused[tuple(members)] = wblock
             else:
                 ps = [byname[k] for k in members]
@@ -168,15 +241,19 @@ class FlatParams(object):
         self.gmult = torch.tensor(gm, dtype=torch.float32, device=dev)
         self.wdc = torch.tensor(wd, dtype=torch.float32, device=dev)
         self.l2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.struct_zero_idx = torch.cat(self.struct_zero_idx) if self.struct_zero_idx else None
 
     def zero_grad(self):
         self.g.zero_()
 
     def mask_structured(self):
-        """Clears the gradient entries that stand where a structured block ("plus") holds constant zeros - one multi-tensor launch for all
-        blocks.  Linear, so it commutes with the data-parallel sum: called once per step, after the all-reduce, before the optimizer."""
-        if self.struct_grads:
-            torch._foreach_mul_(self.struct_grads, self.struct_masks)
+        """Clears the gradient entries that stand where a structured block ("plus") holds constant zeros - ONE launch for all blocks, by
+        SELECTION (index_fill_ over the precomputed flat offsets), not by multiplying with a 0 / 1 pattern: 0 * inf is NaN, and in the fp16
+        build with a static loss scale an overflowed weight gradient at such a place would reach momentum and weight of an entry that must
+        stay exactly 0.  Linear, so it commutes with the data-parallel sum: once per step, after the all-reduce, before the
+        optimizer."""
+        if self.struct_zero_idx is not None:
+            self.g.index_fill_(0, self.struct_zero_idx, 0.0)
 
     def sgd_step(self, lr, momentum=0.9, grad_scale=1.0, dynamic_state=None):
         """dynamic_state: fp32[4] device tensor {loss scale, clean steps, growth interval, flag} (danhip_sgd_momentum_flat_dynamic)."""
@@ -202,7 +279,7 @@ class GradBuckets(object):
 
     def __init__(self, flat, bucket_bytes=32 << 20):
         self.flat = flat
-        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("DANHIP_FORCE_DIST") == "1")
+        self.enabled = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or (os.environ.get("DANHIP_FORCE_DIST") == "1" and flat.g.is_cuda)
         # DANHIP_FAKE_ALLREDUCE=1 (diagnosis, single process): run the bucket machinery with a device-only stand-in for the collective
         self.fake = (not self.enabled) and os.environ.get("DANHIP_FAKE_ALLREDUCE") == "1" and flat.g.is_cuda
         self.enabled = self.enabled or self.fake
@@ -219,8 +296,12 @@ class GradBuckets(object):
         if cur_end > 0:
             self.bounds.append((0, cur_end))
         self.on_gpu = flat.g.is_cuda
-        # device-side collectives (RCCL) coexist with the weight-gradient stream; gloo's host-staged ones stalled with it
-        self.device_collectives = self.enabled and (getattr(self, "fake", False) or dist.get_backend() == "nccl")
+        # Data plane: RCCL called directly through the library (RcclComm) for GPU buffers — DANHIP_DP_TRANSPORT=gloo keeps the process
+        # group's host-staged collectives instead (the test hook that runs several ranks on ONE GPU: RCCL refuses duplicate devices).
+        # Device-side collectives coexist with the weight-gradient stream; gloo's host-staged ones stalled with it.
+        self.transport = dp_transport() if (self.enabled and not self.fake and self.on_gpu) else ("fake" if self.fake else "gloo")
+        self.rccl = RcclComm.shared(flat.g.device) if self.transport == "rccl" else None
+        self.device_collectives = self.enabled and (self.fake or self.rccl is not None)
         self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self.pending = []
         self.next_bucket = 0
@@ -241,9 +322,9 @@ class GradBuckets(object):
             raise ValueError("DANHIP_DP_COMM must be allreduce or rs_ag")
         self.stage = None
         if self.enabled and (self.comm != "allreduce" or self.wire_bf16):
-            if not self.device_collectives or self.fake:
-                raise RuntimeError("DANHIP_DP_COMM / DANHIP_DP_BUCKET_DTYPE need device collectives (the RCCL backend)")
-            w = dist.get_world_size()
+            if self.rccl is None:
+                raise RuntimeError("DANHIP_DP_COMM / DANHIP_DP_BUCKET_DTYPE need device collectives (DANHIP_DP_TRANSPORT=rccl)")
+            w = self.rccl.world
             longest = max(-(-(e - s) // w) * w for s, e in self.bounds)
             self.stage = [torch.zeros(longest, dtype=torch.bfloat16 if self.wire_bf16 else torch.float32, device=flat.g.device)
                           for _ in self.bounds]      # one staging buffer per bucket: several reductions are in flight at once
@@ -251,9 +332,12 @@ class GradBuckets(object):
     def _reduce(self, b, s, e):
         """Sum flat.g[s:e] over the ranks on the current (communication) stream; -> work handle or None."""
         g = self.flat.g[s:e]
-        if self.stage is None:
+        if self.rccl is None:                           # gloo (host-staged): a work handle the caller waits for
             return dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
-        w, r = dist.get_world_size(), dist.get_rank()
+        if self.stage is None:
+            self.rccl.all_reduce(g)                     # in place on the flat gradient buffer, asynchronous on the communication stream
+            return None
+        w, r = self.rccl.world, self.rccl.rank
         n = e - s
         padded = -(-n // w) * w
         st = self.stage[b][:padded]
@@ -261,10 +345,10 @@ class GradBuckets(object):
         if self.comm == "rs_ag":
             per = padded // w
             shard = st[r * per:(r + 1) * per]
-            dist.reduce_scatter_tensor(shard, st, op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(st, shard)
+            self.rccl.reduce_scatter(shard, st)         # (in place: the shard is this rank's slice of the staging buffer)
+            self.rccl.all_gather(st, shard)
         else:
-            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            self.rccl.all_reduce(st)
         g.copy_(st[:n])
         return None
 
@@ -348,25 +432,46 @@ class GradBuckets(object):
             self.snapshots = []
 
 
+def dp_transport():
+    """'rccl' (default on a GPU: RcclComm, the library's own RCCL calls) or 'gloo' (the process group's host-staged collectives:
+    DANHIP_DP_TRANSPORT=gloo — several ranks on ONE GPU in tests/test_zz_ddp_gpu.py — and every CPU run)."""
+    t = os.environ.get("DANHIP_DP_TRANSPORT", "rccl" if torch.cuda.is_available() else "gloo").lower()
+    if t not in ("rccl", "gloo"):
+        raise ValueError("DANHIP_DP_TRANSPORT must be rccl or gloo, got %r" % t)
+    return t
+
+
 def init_distributed():
-    """One process per GPU (torchrun); backend 'nccl' is RCCL on ROCm.  Returns (rank, world, local_rank)."""
+    """One process per GPU (torchrun).  Returns (rank, world, local_rank).
+
+    The process group is the CONTROL plane (rendezvous, barriers, the unique id of the RCCL communicator, scalar statistics): backend
+    gloo by default (DANHIP_DIST_BACKEND overrides), so no ProcessGroupNCCL watchdog / heartbeat thread exists in the process.  The
+    gradients travel on RCCL through the library's own communicator (RcclComm / danhip_comm_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # DANHIP_FORCE_DIST=1: initialise the process group (and run the bucketed all-reduce) even for ONE rank — the only way to put the
-    # RCCL code path on a single-GPU box (tests/test_ddp_gpu.py)
-    force = os.environ.get("DANHIP_FORCE_DIST") == "1"
-    if (world > 1 or force) and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # DANHIP_DIST_BACKEND=gloo: the test hook that runs several ranks on ONE GPU (RCCL refuses duplicate devices; gloo stages
-        # CUDA tensors through the host), tests/test_ddp_gpu.py
-        backend = os.environ.get("DANHIP_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local = local % torch.cuda.device_count()
-            torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
+    # DANHIP_FORCE_DIST=1: run the bucketed all-reduce even for ONE rank — the only way to put the RCCL code path on a single-GPU box
+    # (tests/test_zz_ddp_gpu.py); a one-rank job needs no process group for it
+    if torch.cuda.is_available():
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=os.environ.get("DANHIP_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
     return rank, world, local
+
+
+def shutdown_distributed(*trainers):
+    """Orderly end of a data-parallel job: captured graphs (they hold the collectives' kernel nodes) first, then the streams drain, then
+    the RCCL communicator, then the control-plane process group."""
+    for tr in trainers:
+        if tr is not None:
+            tr.close()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if RcclComm._shared is not None:
+        RcclComm._shared.close()
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

@@ -503,7 +503,7 @@ def restore_checkpoint(variables, checkpoint_path, model_scope, trainer=None, st
         restored.append(ck_name)
 
     for n, p in variables.named():
-        load(model_scope + "/" + n, p.data)
+        load(model_scope + "/" + n, p)           # (under no_grad, on the Parameter itself: its version counter moves, as init_from_checkpoint does)
     for n, b in getattr(variables, "bufs", {}).items():
         load(model_scope + "/" + n, b)
     if trainer is not None:

@@ -496,6 +496,36 @@ int danhip_augment_preprocess(const uint8_t* src, int32_t H, int32_t W, int32_t 
                               int32_t win_y, int32_t win_x, int32_t win_h, int32_t win_w, int32_t flip, uint16_t* dst, int32_t out_h,
                               int32_t out_w, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (csrc/comm.cpp): the all-reduce(sum) of tf_replicate_model_fn.py:633-645
+ * (_compute_sum_on_device: add_n over the towers' gradients, after _scale_loss :615-631 put 1/N into every tower's loss) issued
+ * straight on RCCL (rccl.h: ncclCommInitRank / ncclAllReduce / ncclReduceScatter / ncclAllGather) from this library, on the caller's
+ * stream — no framework process group, no watchdog / heartbeat thread, so the calls can be recorded into a hipGraph like any kernel
+ * (RCCL's collectives are stream-ordered device work; SURVEY 8b: "directly via rccl.h from C++ for the overlapped bucket path").
+ * librccl is NOT a link-time dependency: it is dlopen'ed at the first danhip_comm_* call (danhip_comm_load names the file, e.g. the
+ * copy PyTorch ships; NULL = the copy already in the process, else librccl.so[.1] on the loader path).  One communicator = one rank =
+ * one GPU (the device current at danhip_comm_create); the 128-byte unique id is produced by rank 0 and carried to the other ranks by
+ * the caller (any host channel: a TCP store, a file, MPI).  A communicator must be used by one thread at a time (RCCL's rule).
+ * dtype: DANHIP_F32 | DANHIP_BF16 | DANHIP_F16 (here DANHIP_BF16 means bf16 whatever the build's activation type is).
+ * ------------------------------------------------------------------------------------------------ */
+#define DANHIP_ECOMM (-4)      /* RCCL missing / an RCCL call failed (danhip_last_error carries ncclGetErrorString) */
+#define DANHIP_COMM_ID_BYTES 128
+int danhip_comm_load(const char* librccl_path);                        /* optional; idempotent once a copy is bound */
+int danhip_comm_rccl_version(int* version);                            /* ncclGetVersion: e.g. 22606 */
+int danhip_comm_unique_id(void* id128);                                /* host buffer of DANHIP_COMM_ID_BYTES (rank 0) */
+/* collective over the nranks callers; device >= 0: hipSetDevice(device) first (RCCL binds a communicator to the calling thread's
+ * current device), -1: the current device */
+int danhip_comm_create(const void* id128, int32_t nranks, int32_t rank, int32_t device, void** comm_out);
+int danhip_comm_destroy(void* comm);                                   /* after the streams that carry its collectives have drained */
+int danhip_comm_info(void* comm, int32_t* nranks, int32_t* rank, int32_t* device);
+/* buf[i] = sum over ranks of buf[i], in place, asynchronous on stream */
+int danhip_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, void* stream);
+/* recv[0:recvcount] = sum over ranks of send[rank*recvcount : (rank+1)*recvcount]   (send holds nranks*recvcount elements; recv may be
+ * the caller's own slice of send: in place) */
+int danhip_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recvcount, int dtype, void* stream);
+/* recv[r*sendcount : (r+1)*sendcount] = rank r's send   (send may be the caller's slice of recv: in place) */
+int danhip_comm_allgather(void* comm, const void* send, void* recv, int64_t sendcount, int dtype, void* stream);
+
 /* ---- fp32 inference path (csrc/f32_infer.hip): the evaluation graphs of eval_sfd.py:232-283 / eval_pb.py / eval_dan.py:299-404 with fp32
  * storage and arithmetic end to end, for the north-star tolerance "eval box outputs within 1e-4 of the reference".  NHWC fp32
  * activations, the TF variables as they are (HWIO fp32 kernel, no packing; Cin need not be padded), forward only.  Same semantics as

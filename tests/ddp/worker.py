@@ -1,6 +1,6 @@
 """Rank body of tests/test_ddp_gpu.py.
 
-mode "dp" (default): WORLD_SIZE ranks (all on cuda:0, gloo backend; or one forced RCCL rank) train data-parallel on contiguous shards
+mode "dp" (default): WORLD_SIZE ranks (all on cuda:0, DANHIP_DP_TRANSPORT=gloo; or one forced RCCL rank) train data-parallel on contiguous shards
 of one global batch; rank 0 saves the all-reduced gradient and the parameters after step 1 and after step 2.
 mode "graph": as "dp", with the step captured as one hipGraph (bucketed all-reduce included; RCCL groups only) after one eager warm-up step.
 mode "shards" (DDP_MODE=shards, one plain process): the same global batch cut into DDP_SHARDS contiguous shards; for each shard the
@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 from dan_amd import ops, synthetic
-from dan_amd.trainer import init_distributed
+from dan_amd.trainer import init_distributed, shutdown_distributed
 
 out = sys.argv[1]
 mode = os.environ.get("DDP_MODE", "dp")
@@ -77,7 +77,7 @@ tr, args_of = build(world)
 forced = os.environ.get("DANHIP_FORCE_DIST") == "1"
 assert tr.buckets.enabled == (world > 1 or forced)
 if forced:
-    assert tr.buckets.device_collectives                 # RCCL group: the weight-gradient stream stays on beside the buckets
+    assert tr.buckets.device_collectives and tr.buckets.rccl is not None    # the library's own RCCL communicator: the weight-gradient stream stays on beside the buckets
 w0 = tr.flat.w.clone()
 if mode == "graph":                                      # the data-parallel step (bucketed all-reduce included) replayed as ONE hipGraph
     tr.enable_graph(*args_of(sl), warmup=1)
@@ -86,9 +86,7 @@ if mode == "graph":                                      # the data-parallel ste
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({"w": tr.flat.w.cpu(), "g": tr.flat.g.cpu(), "step": tr.step_no, "buckets": len(tr.buckets.bounds)}, out)
-    if torch.distributed.is_initialized():
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    shutdown_distributed(tr)                             # graph first, then the communicator, then the process group
     sys.exit(0)
 tr.train_step(*args_of(sl))
 torch.cuda.synchronize()
@@ -100,6 +98,4 @@ torch.cuda.synchronize()
 if rank == 0:
     torch.save({"w": tr.flat.w.cpu(), "g": tr.flat.g.cpu(), "w0": w0.cpu(), "g1": g1.cpu(), "w1": w1.cpu(), "loss1": loss1,
                 "buckets": len(tr.buckets.bounds), "step": tr.step_no}, out)
-if torch.distributed.is_initialized():
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+shutdown_distributed(tr)

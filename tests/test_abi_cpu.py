@@ -136,10 +136,17 @@ print("ok", rank)
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_gradient_buckets_allreduce_gloo_world2(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -272,6 +279,39 @@ def test_bench_spawns_its_own_ranks_when_typed_without_a_launcher():
     import json
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2
+    # the line carries BOTH series: `scaling` = "weak" for `value`, and a strong-scaling leg on the fixed global batch
+    # of BASELINE.json configs[2] (128): 64 images per rank at N = 2, as four 16-image towers
+    assert out["scaling"] == "weak" and out["strong_plan"] == [64, 4, 16]
+
+
+def test_strong_scaling_plan_of_the_bench_line():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod_plan", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.strong_plan(128, 1) == (128, 8, 16) and b.strong_plan(128, 8) == (16, 1, 16) and b.strong_plan(128, 4) == (32, 2, 16)
+    assert b.strong_plan(16, 8) == (2, 1, 2)             # a global batch of 16: 2-image towers
+    assert b.strong_plan(128, 3) is None and b.strong_plan(0, 2) is None and b.strong_plan(48, 2) is None    # 24 per rank is not whole towers
+
+
+def test_comm_entry_points_fail_with_a_message_when_rccl_or_the_communicator_is_missing():
+    """include/danhip.h danhip_comm_*: librccl is bound at run time — a wrong path is DANHIP_ECOMM (-4) with dlopen's message, a call without
+    a communicator is DANHIP_EINVAL; nothing throws, nothing needs a GPU."""
+    code = r"""
+import ctypes, sys
+sys.path.insert(0, %r)
+from dan_amd import _lib
+L = _lib.lib()
+assert L.danhip_comm_load(b"/nonexistent/librccl.so") == -4 and b"dlopen" in L.danhip_last_error()
+assert L.danhip_comm_allreduce_sum(None, None, 4, 0, None) == -1 and b"communicator" in L.danhip_last_error()
+assert L.danhip_comm_reduce_scatter_sum(None, None, None, 4, 0, None) == -1
+assert L.danhip_comm_allgather(None, None, None, 4, 0, None) == -1
+assert L.danhip_comm_destroy(None) == 0
+assert L.danhip_comm_unique_id(None) == -1
+print("OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout, r.stderr[-2000:])
 
 
 def _replay_pointwise_waits(NST, DPW, ksteps, n_items, stores_per_item, late):
@@ -435,3 +475,9 @@ def test_fused_context_block_fires_its_gradient_hooks_in_flat_buffer_order():
     g3 = vs.fused[("s1/branch3_conv_3x1/kernel", "s1/branch3_conv_1x3/kernel")]._danhip_grad
     assert g3.sum().item() == 2 * 3 * 64 * 32 and named["s1/branch3_conv_3x1/kernel"].grad.eq(1).all() and named["s1/branch3_conv_1x3/kernel"].grad.eq(1).all()
     assert named["s1/branch4_conv_3x3/kernel"].grad.eq(1).all() and wcat._danhip_grad.eq(1).all()      # nothing else is touched
+    # cleared by selection, not by a 0 / 1 multiply: an overflowed gradient (fp16 build, static loss scale) at a constant-zero place must not
+    # become 0 * inf = NaN in momentum and weight
+    g3[0, 0, 5, 7] = float("inf")
+    g3[2, 2, 1, 40] = float("nan")
+    flat.mask_structured()
+    assert torch.isfinite(g3).all() and g3.sum().item() == 2 * 3 * 64 * 32

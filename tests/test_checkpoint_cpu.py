@@ -169,3 +169,46 @@ def test_full_state_round_trip_with_momenta_moving_statistics_and_global_step(tm
     epoch = ops.WEIGHT_EPOCH
     C.init_from_checkpoint(b.model.vs, inf, "dan", None)
     assert ops.WEIGHT_EPOCH > epoch                                   # warm start also invalidates the cached packings
+
+
+def test_fused_inference_blocks_follow_a_restore_and_raw_pointer_writers(tmp_path):
+    """the trainer-less evaluation flow — a gradient-free forward creates and fuses the variables, THEN the checkpoint is
+    restored — must see the restored weights in every fused block (heads, context 'plus' / block-diagonal kernels, the deformable HWIO
+    operand).  Also the writers that bump no version counter: `p.data.copy_()` and anything that advances ops.WEIGHT_EPOCH."""
+    from dan_amd import ops
+    from dan_amd.net.variables import VariableStore
+
+    def make(seed):
+        vs = VariableStore(device="cpu", seed=seed)
+        vs.get("h/loc_0/kernel", (3, 3, 8, 4), "glorot")
+        vs.get("h/cls_0/kernel", (3, 3, 8, 2), "glorot")
+        vs.get("b/c31/kernel", (3, 1, 8, 4), "glorot")
+        vs.get("b/c13/kernel", (1, 3, 8, 4), "glorot")
+        vs.get("d/deform_conv/kernel", (8, 4, 3, 3), "glorot_oihw")
+        return vs
+
+    groups = [(("h/loc_0/kernel", "h/cls_0/kernel"), 3), (("b/c31/kernel", "b/c13/kernel"), "plus"), (("d/deform_conv/kernel",), "hwio")]
+    src = make(11)
+    prefix = str(tmp_path / "m" / "model.ckpt-7")
+    C.save_checkpoint(src, prefix, "dan")
+    dst = make(12)
+    with torch.no_grad():                                    # the forward that precedes the restore
+        before = [dst.fuse(k, a) for k, a in groups]
+    assert all(t is not None for t in before)
+    C.restore_checkpoint(dst, prefix, "dan", trainer=None, strict=False)
+    with torch.no_grad():
+        after = [dst.fuse(k, a) for k, a in groups]
+        want = [src.build(k, a) for k, a in groups]
+    for (k, _), t0, t1, w in zip(groups, before, after, want):
+        assert t1 is not t0, k                               # a new block, not the pre-restore one
+        assert torch.equal(t1, w), k                         # ... that matches its (restored) members
+    # a write through .data (its own version counter) is invisible to p._version: the epoch is what the cache keys on
+    with torch.no_grad():
+        t_old = dst.fuse(*groups[0])
+        p = dst.vars[dst._key("h/cls_0/kernel")]
+        v0 = p._version
+        p.data.mul_(2.0)
+        assert p._version == v0 and dst.fuse(*groups[0]) is t_old          # (documented blind spot of the version counter ...)
+        ops.WEIGHT_EPOCH += 1                                              # ... which every raw-pointer writer closes this way
+        t_new = dst.fuse(*groups[0])
+        assert t_new is not t_old and torch.equal(t_new[..., 4:], p)

@@ -276,3 +276,63 @@ def test_resume_from_own_checkpoint_continues_the_trajectory(dev, tmp_path):
     assert (a.flat.w - b.flat.w).abs().max().item() <= 1e-5 * scale
     assert (a.flat.v - b.flat.v).abs().max().item() <= 1e-4 * a.flat.v.abs().max().item()
     assert a.step_no == b.step_no == 3
+
+
+@pytest.mark.parametrize("which", ["sfd", "dan_deform"])
+def test_towers_step_sums_the_towers_gradients_like_the_reference_places_towers_on_one_device(which, dev):
+    """DetectorTrainer.train_step_towers (tf_replicate_model_fn.py:504-560 loops the towers, :297-343 sums their gradients, :615-631 puts
+    1 / number_of_towers into every tower's loss): the flat gradient after a 2-tower step equals add_n (oracle.train.dp_step) over the
+    gradients one tower at a time produces with world = 2 from the same parameters — every backward kernel ACCUMULATES into the sink —
+    and the weights equal the Momentum update of that sum.  bench.py's strong-scaling leg runs on this entry."""
+    from dan_amd import ops, synthetic
+    S, n = 64, 2
+    imgs = synthetic.make_images(2 * n, S, S, dev, seed=41)
+    gts = synthetic.make_gt_boxes(2 * n, S, S, seed=42, max_faces=4)
+    if which == "sfd":
+        from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+        anchors = AnchorConfig(S, S, dev)
+        loc_t, cls_t, _ = anchors.encode_batch(gts)
+        make = lambda world: SFDTrainer(SFDModel(device=dev, seed=9), world=world)
+        args_of = lambda sl: (imgs[sl].contiguous(), loc_t[sl].contiguous(), cls_t[sl].contiguous())
+    else:
+        from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
+        anchors = dan_anchor_config(S, S, dev)
+        loc_t, cls_t, mgt = encode_batch_dan(anchors, gts)
+        make = lambda world: DANTrainer(DANModel(device=dev, seed=9, deform=True), anchors, world=world)
+        args_of = lambda sl: (imgs[sl].contiguous(), loc_t[sl].contiguous(), cls_t[sl].contiguous(), mgt[sl].contiguous())
+    shards = [slice(0, n), slice(n, 2 * n)]
+    one = make(2)                                             # one tower at a time, each scaled by 1 / 2
+    w0 = one.flat.w.clone()
+    gs = []
+    for sl in shards:
+        one.flat.w.copy_(w0)
+        one.flat.v.zero_()
+        ops.WEIGHT_EPOCH += 1
+        ops.repack_all()
+        one.step_no = 0
+        if hasattr(one, "_routing_ctr"):
+            one._routing_ctr.zero_()
+        one.train_step(*args_of(sl))
+        torch.cuda.synchronize()
+        gs.append(one.flat.g.clone())
+    agg, _ = OT.dp_step(lambda i, scale: (0.0, {"flat": gs[i]}), [0, 1])
+    want = agg["flat"]
+    tw = make(1)
+    assert torch.equal(tw.flat.w, w0)
+    tw.train_step_towers([args_of(sl) for sl in shards])
+    torch.cuda.synchronize()
+    assert tw.towers == 1 and tw.step_no == 1
+    scale = want.abs().max().item()
+    if which == "sfd":
+        assert (tw.flat.g - want).abs().max().item() <= 1e-4 * scale
+        seg = tw.flat.seg.tolist()
+        mult, wd = torch.ones_like(want), torch.zeros_like(want)
+        for k in range(len(seg) - 1):
+            mult[seg[k]:seg[k + 1]] = tw.flat.gmult[k]
+            wd[seg[k]:seg[k + 1]] = tw.flat.wdc[k]
+        upd = w0 - 1e-4 * mult * (tw.flat.g + wd * w0)
+        assert torch.allclose(tw.flat.w, upd, rtol=1e-5, atol=1e-7)
+    else:
+        # DAN's train-mode routing draws from a counter-based stream that the second tower continues: whole-gradient agreement in direction
+        cos = torch.nn.functional.cosine_similarity(tw.flat.g, want, dim=0).item()
+        assert cos >= 0.98 and torch.isfinite(tw.flat.g).all(), cos

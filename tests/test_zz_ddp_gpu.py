@@ -1,0 +1,176 @@
+"""Data-parallel semantics of the trainer on the real kernels (contiguous split, gradients of loss_rank / N summed over
+ranks, bucketed all-reduce overlapped with backward): 2 ranks sharing the one GPU (DANHIP_DP_TRANSPORT=gloo: RCCL refuses two ranks on
+one device) must reach the same parameters as one process on the whole batch — except that the loss normalisation is per shard, as in
+the reference (tf_replicate_model_fn averages tower losses that are each normalised by their own positives).  The RCCL data plane
+(include/danhip.h danhip_comm_*, called directly by the library: no ProcessGroupNCCL) is covered with a one-rank communicator.
+
+The file sorts LAST on purpose: these tests start child processes (rendezvous, RCCL), i.e. infrastructure that can fail for reasons that
+are not numerical — under `pytest -x` they must not stand in front of the oracle comparisons."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "ddp", "worker.py")
+
+
+def _free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _child(cmd, env, what):
+    """One child, once: a crashed child fails the test (head AND tail of its stderr: `terminate called ...` is at the head)."""
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (what, r.returncode, r.stdout[-1500:], r.stderr[:3000], r.stderr[-3000:])
+
+
+def _run(world, out, **extra):
+    env = dict(os.environ, DANHIP_DP_TRANSPORT="gloo", MASTER_ADDR="127.0.0.1", **extra)
+    if world == 1:
+        cmd = [sys.executable, WORKER, out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), WORKER, out]
+    _child(cmd, env, "world %d" % world)
+    return torch.load(out)
+
+
+def _forced_rccl_env(**extra):
+    env = dict(os.environ, DANHIP_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", **extra)
+    env.pop("DANHIP_DP_TRANSPORT", None)
+    return env
+
+
+def test_two_ranks_follow_the_same_trajectory_twice_and_differ_from_one_rank_only_by_shard_normalisation(dev, tmp_path):
+    a = _run(2, str(tmp_path / "w2a.pt"))
+    b = _run(2, str(tmp_path / "w2b.pt"))
+    one = _run(1, str(tmp_path / "w1.pt"))
+    scale = a["w"].abs().max().item()
+    # determinism of the DP path (bucket order, all-reduce, 1/N scaling): two launches agree to fp32-atomics noise
+    assert (a["w"] - b["w"]).abs().max().item() <= 1e-4 * scale
+    # the all-reduced gradient is NOT the single-process gradient in general (per-shard normalisers), but it is close and finite
+    assert torch.isfinite(a["w"]).all() and torch.isfinite(a["g"]).all()
+    rel = (a["w"] - one["w"]).abs().max().item() / scale
+    assert rel < 5e-3, rel
+    assert a["g"].abs().max().item() > 0
+
+
+@pytest.mark.parametrize("comm,wire,tol", [("allreduce", "f32", 1e-4), ("rs_ag", "f32", 1e-4), ("allreduce", "bf16", 2e-3), ("rs_ag", "bf16", 2e-3)])
+def test_rccl_code_path_with_a_one_rank_group(comm, wire, tol, dev, tmp_path):
+    """The only RCCL coverage a one-GPU box allows: DANHIP_FORCE_DIST=1 makes the process create a 1-rank RCCL communicator
+    (danhip_comm_create) and run the bucketed all-reduce on its communication stream, with the weight-gradient stream beside it — same
+    parameters as the plain process.
+    Also the two alternative wire forms (trainer.GradBuckets): reduce-scatter + all-gather per bucket, and bf16 buckets (each gradient
+    rounded to bf16 once: 2^-9 relative per element, the parameters after three lr = 1e-4 steps stay within 2e-3 of their scale)."""
+    env = _forced_rccl_env(DANHIP_DP_COMM=comm, DANHIP_DP_BUCKET_DTYPE=wire)
+    out = str(tmp_path / "rccl1.pt")
+    _child([sys.executable, WORKER, out], env, "forced one-rank RCCL communicator")
+    a = torch.load(out)
+    one = _run(1, str(tmp_path / "plain.pt"))
+    scale = one["w"].abs().max().item()
+    assert (a["w"] - one["w"]).abs().max().item() <= tol * scale
+    assert torch.isfinite(a["g"]).all() and a["g"].abs().max().item() > 0
+    if wire == "bf16":                                 # the reduced gradient is bf16-representable: it really travelled as bf16
+        assert torch.equal(a["g"], a["g"].to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("model", ["sfd", "pb", "dan", "dan_deform"])
+def test_two_rank_step_equals_the_oracle_dp_step_over_shard_gradients(model, dev, tmp_path):
+    """SURVEY a35 against oracle.train.dp_step (tf_replicate_model_fn.py:297-343, 458-498, 615-645): the gradient buffer a 2-rank
+    run holds after its bucketed, overlapped all-reduce equals add_n over the towers of grad(loss_shard / N), each tower computed by
+    ONE plain process from the same parameters — for all four graphs, with DANHIP_DP_CHECK=1 (no gradient may be written after its
+    bucket was reduced).  Tolerance 1e-4 of the gradient's max-norm (fp32 atomics order in the weight-gradient kernels); the weights
+    after the step equal the Momentum update of the aggregated gradient (oracle.train.momentum_sgd_step semantics: x2 on biases,
+    L2 term once) at 1e-5."""
+    from oracle import train as OT
+    dp = _run(2, str(tmp_path / "dp.pt"), DDP_MODEL=model, DANHIP_DP_CHECK="1")
+    sh = _run(1, str(tmp_path / "sh.pt"), DDP_MODEL=model, DDP_MODE="shards", DDP_SHARDS="2")
+    assert torch.equal(dp["w0"], sh["w0"])
+
+    def tower(i, loss_scale):
+        assert loss_scale == 0.5                       # the shard gradients were produced with world = 2
+        return sh["loss"][i], {"flat": sh["g"][i]}
+
+    agg, reported = OT.dp_step(tower, [0, 1])
+    g = agg["flat"]
+    scale = g.abs().max().item()
+    assert scale > 0 and torch.isfinite(dp["g1"]).all()
+    err = (dp["g1"] - g).abs().max().item()
+    assert err <= 1e-4 * scale, (model, err, scale)
+    assert abs(dp["loss1"] - sh["loss"][0]) <= 1e-3 * abs(sh["loss"][0]) + 1e-4          # rank 0 reports its own tower's loss
+    assert dp["buckets"] >= 2
+    # Momentum step 0 (v = 0): w1 = w0 - lr * mult * (g + wd * w0), lr = 1e-3 * 0.1 (train_sfd.py:429-447)
+    seg = sh["seg"].tolist()
+    mult = torch.ones_like(g)
+    wd = torch.zeros_like(g)
+    for k in range(len(seg) - 1):
+        mult[seg[k]:seg[k + 1]] = sh["gmult"][k]
+        wd[seg[k]:seg[k + 1]] = sh["wdc"][k]
+    want = sh["w0"] - 1e-4 * mult * (dp["g1"] + wd * sh["w0"])
+    assert torch.allclose(dp["w1"], want, rtol=1e-5, atol=1e-7), (dp["w1"] - want).abs().max().item()
+
+
+def test_data_parallel_step_replayed_as_one_hipgraph(dev, tmp_path):
+    """DetectorTrainer.enable_graph on a data-parallel trainer: forward, backward, the bucketed RCCL all-reduce on its side stream and the
+    fused optimizer captured as ONE hipGraph (the buckets' stream forks from / joins the capturing stream through events; the
+    collectives are the library's own RCCL calls, recorded like kernels).  The only RCCL communicator a one-GPU box allows has one rank;
+    its captured run must land on the eager forced-rank run's parameters after the same three steps (fp32-atomics noise), with more than
+    one bucket in flight.  The worker ends in the prescribed order: graph dropped, device drained, communicator destroyed."""
+    outs = {}
+    for mode in ("dp", "graph"):
+        out = str(tmp_path / (mode + ".pt"))
+        _child([sys.executable, WORKER, out], _forced_rccl_env(DDP_MODE=mode), mode)
+        outs[mode] = torch.load(out)
+    a, b = outs["dp"], outs["graph"]
+    assert a["step"] == b["step"] == 3 and b["buckets"] >= 2
+    scale = a["w"].abs().max().item()
+    assert (a["w"] - b["w"]).abs().max().item() <= 1e-4 * scale
+    assert torch.isfinite(b["g"]).all() and b["g"].abs().max().item() > 0
+
+
+def test_comm_entry_points_on_a_one_rank_communicator(dev, tmp_path):
+    """include/danhip.h danhip_comm_*: unique id -> communicator -> all-reduce / reduce-scatter / all-gather in every wire dtype on a
+    one-rank communicator are the identity (sum over one rank), asynchronous on the caller's stream; info / version answer; bad
+    arguments return DANHIP_EINVAL with a message instead of reaching RCCL.  Child process: RCCL's helper threads stay out of pytest."""
+    code = r"""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from dan_amd import _lib
+from dan_amd.trainer import RcclComm
+torch.cuda.set_device(0)
+c = RcclComm(0, 1, 0)
+assert c.version >= 20000, c.version
+n, r, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+_lib.call("danhip_comm_info", c.handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d))
+assert (n.value, r.value, d.value) == (1, 0, 0)
+side = torch.cuda.Stream()
+for dt in (torch.float32, torch.bfloat16, torch.float16):
+    x = torch.randn(1 << 20, device="cuda").to(dt)
+    want = x.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c.all_reduce(x)
+        y = torch.empty_like(x)
+        c.reduce_scatter(y, x)
+        z = torch.empty_like(x)
+        c.all_gather(z, y)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(x, want) and torch.equal(y, want) and torch.equal(z, want), dt
+L = _lib.lib()
+bad = L.danhip_comm_allreduce_sum(c.handle, _lib.ptr(x), 16, 7, _lib.stream())
+assert bad == -1 and b"dtype" in L.danhip_last_error()
+assert L.danhip_comm_allreduce_sum(None, _lib.ptr(x), 16, 0, _lib.stream()) == -1
+assert L.danhip_comm_create(None, 1, 0, 0, None) == -1
+c.close()
+c.close()                      # idempotent
+print("COMM_OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "COMM_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[:3000], r.stderr[-3000:])
