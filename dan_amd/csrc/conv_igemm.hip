@@ -885,7 +885,11 @@ extern "C" int danhip_conv2d_fwd_relu_bits_arg(const danhip_conv_desc* d, const 
                                                uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, uint8_t* pool_arg, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  DH_REQUIRE(x && wf_packed && bias && y && y_bits && (!pool_y == !pool_bits), DANHIP_EINVAL, "conv2d_fwd_relu_bits: null pointer");
+  // y == NULL (with pool_y): only the pooled map, the bit masks and the arg-max codes are wanted - the halo kernel's lean epilogue drops the
+  // full-resolution stores (training: nothing but the pool reads conv2_2's output; ask danhip_conv2d_fwd_pool_only(d) first)
+  DH_REQUIRE(x && wf_packed && bias && y_bits && (!pool_y == !pool_bits), DANHIP_EINVAL, "conv2d_fwd_relu_bits: null pointer");
+  DH_REQUIRE(y || (pool_y && danhip_conv2d_fwd_pool_only(d)), DANHIP_EINVAL,
+             "conv2d_fwd_relu_bits: y == NULL needs a kernel that pools in its epilogue (danhip_conv2d_fwd_pool_only)");
   DH_REQUIRE(danhip_conv2d_fwd_emits_bits(d, pool_y != nullptr), DANHIP_EINVAL,
              "conv2d_fwd_relu_bits: this shape's forward kernel does not write bit masks (ask danhip_conv2d_fwd_emits_bits)");
   ConvArgs a = fwd_args(d);

@@ -319,6 +319,10 @@ def _wgrad_scratch(d, dev):
 USE_POOL_ARG = os.environ.get("DANHIP_POOL_ARG", "1") == "1"
 
 
+# DANHIP_POOL_ONLY_TRAIN=0: conv1_2 / conv2_2 write their full-resolution outputs in training too (A/B; round 4's behaviour)
+POOL_ONLY_TRAIN = os.environ.get("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
+
+
 def _pool_arg_buffer(pooled, need_bwd):
     if not (USE_POOL_ARG and need_bwd):
         return None
@@ -339,7 +343,7 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(N, H, W, C, cout, kh, kw, stride, valid)
         need_bwd = w.requires_grad or x.requires_grad or bool(block_grads)
         wf, wb = packed_weights(d, w, w_param, need_bwd)
-        if pool_only and pool_out is not None and _lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d)):      # (conv2d() passes pool_only only when nothing is tracked)
+        if pool_only == 1 and pool_out is not None and _lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d)):      # (nothing is tracked)
             # inference: nothing but the pool reads this activation - the kernel pools in its epilogue and never writes the full-resolution map
             pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
             e0 = _prof_begin()
@@ -347,7 +351,18 @@ class _Conv2d(torch.autograd.Function):
             _prof_end(e0, d, 4)
             pooled._dh_already_pooled = True
             return pooled
-        y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
+        # pool_only == 2 (training): nothing but the fused pool reads this activation, and backward reaches it only through the pool's arg-max
+        # codes and the pooled map's sign (the gradient arrives already masked in the slot) - the kernel gets y = NULL and skips the
+        # full-resolution stores (conv1_2: 839 MB, conv2_2: 419 MB per batch of 16 at 640 x 640).  The tensor autograd sees is a
+        # zero-stride view of one element: any op that tried to READ it fails ptr()'s contiguity assertion instead of reading garbage.
+        skip_y = (pool_only == 2 and pool_out is not None and USE_POOL_ARG and need_bwd and b is not None
+                  and bool(_lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d)))
+                  and _conv_scratch(d, 0, x.device)[1] == 0)          # (a map small enough to split K runs the pool as its own kernel)
+        if skip_y:
+            y = torch.empty((1,), dtype=ACT, device=x.device).expand(N, d.Ho, d.Wo, cout)
+        else:
+            y = torch.empty((N, d.Ho, d.Wo, cout), dtype=torch.float32 if out_f32 else ACT, device=x.device)
+        yp = None if skip_y else ptr(y)
         e0 = _prof_begin()
         emit = (bits_out is not None and relu and not out_f32 and residual is None and b is not None
                 and _lib.lib().danhip_conv2d_fwd_emits_bits(ctypes.byref(d), 1 if pool_out is not None else 0))
@@ -359,7 +374,7 @@ class _Conv2d(torch.autograd.Function):
                 pbits = torch.empty((pooled.numel() // cout, cout // 8), dtype=torch.uint8, device=x.device)
                 parg = _pool_arg_buffer(pooled, need_bwd and tracked)
                 pool_out.extend([pooled, parg])
-            call("danhip_conv2d_fwd_relu_bits_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(ybits), ptr(pooled), ptr(pbits), ptr(parg),
+            call("danhip_conv2d_fwd_relu_bits_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), yp, ptr(ybits), ptr(pooled), ptr(pbits), ptr(parg),
                  stream())
             bits_out.extend([ybits, pbits])
         elif pool_out is not None:                       # conv_relu + the block's 2x2 max-pool in one call (fused epilogue where possible)
@@ -368,10 +383,11 @@ class _Conv2d(torch.autograd.Function):
             parg = _pool_arg_buffer(pooled, need_bwd and tracked)
             ws, nws = _conv_scratch(d, 0, x.device)
             if nws:                                      # a map small enough to split K: no kernel of it fuses the pool anyway
+                assert not skip_y
                 call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), BF16, 1, None, ptr(ws), nws, stream())
                 call("danhip_maxpool2x2_fwd_arg", ptr(y), ptr(pooled), ptr(parg), N, d.Ho, d.Wo, cout, stream())
             else:
-                call("danhip_conv2d_fwd_pool_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), ptr(y), ptr(pooled), ptr(parg), stream())
+                call("danhip_conv2d_fwd_pool_arg", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), yp, ptr(pooled), ptr(parg), stream())
             pool_out.extend([pooled, parg])
         else:
             ws, nws = _conv_scratch(d, 0, x.device)
@@ -383,7 +399,8 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.has_res = residual is not None
         ctx.w_param, ctx.b_param = w_param, b_param
-        ctx.save_for_backward(x, wb, y if relu else None)
+        ctx.save_for_backward(x, wb, y if (relu and not skip_y) else None)
+        ctx.y_unwritten = skip_y
         ctx.has_bias = b is not None
         ctx.block_w, ctx.block_b = bool(block_grads & 1), bool(block_grads & 2)   # fused parameter blocks: not autograd leaves themselves
         return y
@@ -404,6 +421,9 @@ class _Conv2d(torch.autograd.Function):
         # ---- gather the output gradient: slot deliveries (already ReLU-masked) and/or the autograd tensor
         g = ctx.yslot.take() if ctx.yslot is not None else None
         dres = None
+        if dy is not None and ctx.y_unwritten:
+            raise RuntimeError("conv2d(pool_only=True): the full-resolution activation was never written, but a gradient reached it outside the "
+                               "fused pool's direct hand-off (some op other than max_pool_2x2 consumed it)")
         if dy is not None:
             if ctx.has_res:
                 dres = dy                                # residual is added after the activation
@@ -528,8 +548,11 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     xs = _slot_of(x) if track else None
     xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
     bits_out = [] if (track and relu and USE_RELU_BITS) else None
+    # pool_only: 1 = nothing tracked, the pooled map is returned; 2 = training with the direct gradient hand-off: y is declared but never written
+    # (POOL_ONLY_TRAIN; off while a test records activations through TRACE)
+    po = (1 if not track else (2 if (POOL_ONLY_TRAIN and TRACE is None and USE_SLOTS and yslot is not None) else 0)) if pool_only else 0
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out,
-                      bool(pool_only and not track), bool(track))
+                      po, bool(track))
     if getattr(y, "_dh_already_pooled", False):
         return y
     if TRACE is not None and relu and wp is not None:

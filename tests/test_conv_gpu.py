@@ -2,6 +2,8 @@
 oracle's TF-SAME convolution.  bf16 storage + fp32 accumulate: inputs are rounded to bf16 first, the oracle then
 computes in fp32 on exactly those values, so the only differences are accumulation order and the final bf16
 rounding of the output: tolerance 2^-7 relative to the output scale (+ small abs)."""
+import ctypes
+
 import pytest
 import torch
 
@@ -760,7 +762,46 @@ def test_pool_only_inference_conv_equals_conv_then_pool(N, H, W, Cin, Cout, dev)
         assert torch.equal(got, want)
     else:                                        # (the small maps' ordinary route may split K over workgroups: another fp32 summation order)
         assert (got.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
-    # with a gradient tracked the promise is ignored: the full-resolution map exists for the backward pass
+    # with a gradient tracked the tensor keeps its shape (its DATA may be absent: next test)
     xg = x.clone().requires_grad_(True)
     y = ops.conv2d(xg, w, b, relu=True, pool=True, pool_only=True)
     assert y.shape == (N, H, W, Cout)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 96, 64, 64), (4, 160, 160, 128, 128), (1, 45, 67, 128, 256), (2, 40, 40, 512, 512)])
+def test_pool_only_training_skips_the_full_resolution_stores_and_changes_no_gradient(N, H, W, Cin, Cout, dev, monkeypatch):
+    """Training (round 5): conv1_2 / conv2_2 (net/sfd_net.py:128-135) feed nothing but their 2x2 pool, and backward reaches them only through
+    the pool's arg-max codes with the gradient already masked at the pooled level - so with the direct gradient hand-off the forward call
+    gets y = NULL (ops.POOL_ONLY_TRAIN): same pooled map bit for bit, same dX / dW / db as the form that writes y (weight gradients up
+    to the order of their fp32 partial sums); the declared-but-unwritten tensor cannot be read by any op of this package."""
+    from dan_amd import ops
+    g = torch.Generator().manual_seed(N * 11 + Cin)
+    x = torch.randn((N, H, W, Cin), generator=g).to(ops.ACT).to(dev)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) / (9 * Cin) ** 0.5).to(dev)
+    b = torch.randn((Cout,), generator=g).to(dev)
+    w2 = (torch.randn((3, 3, Cout, 64), generator=g) / (9 * Cout) ** 0.5).to(dev)
+    b2 = torch.randn((64,), generator=g).to(dev)
+    gz = torch.randn((N, (H + 1) // 2, (W + 1) // 2, 64), generator=g).to(ops.ACT).to(dev)
+
+    def run(flag):
+        monkeypatch.setattr(ops, "POOL_ONLY_TRAIN", flag)
+        xg, wg, bg = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, relu=True, pool=True, pool_only=True)
+        p = ops.max_pool_2x2(y)
+        z = ops.conv2d(p, w2, b2, relu=True)
+        z.backward(gz)
+        torch.cuda.synchronize()
+        return y, p.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone()
+
+    y0, p0, dx0, dw0, db0 = run(False)
+    y1, p1, dx1, dw1, db1 = run(True)
+    assert y0.is_contiguous() and tuple(y1.shape) == tuple(y0.shape)
+    skipped = not y1.is_contiguous()
+    d = ops._desc(N, H, W, Cin, Cout, 3, 3, 1)
+    fused_in_epilogue = bool(ops._lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d))) and ops._conv_scratch(d, 0, dev)[1] == 0
+    assert skipped == fused_in_epilogue, (skipped, fused_in_epilogue)
+    assert torch.equal(p0, p1) and torch.equal(dx0, dx1)
+    assert (dw0 - dw1).abs().max().item() <= 1e-4 * dw0.abs().max().item() and (db0 - db1).abs().max().item() <= 1e-4 * db0.abs().max().item()
+    if skipped:
+        with pytest.raises(AssertionError):              # nothing can read the unwritten map: ptr() refuses the zero-stride view
+            ops.conv2d(y1.detach(), w2[:, :, :Cout], b2, relu=True)
