@@ -97,8 +97,12 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 // One block per row: exact k-th largest value by 4 radix passes (8 bits each).  k[b] = min(int(ratio*npos), nneg)
 // (DAN: max(.,1)).  k == 0 -> thr = +inf (no negative selected; the reference indexes -1 there: undefined).
-__global__ void kth_largest_rows_kernel(const float* __restrict__ score, const int* __restrict__ counts, float* __restrict__ thr,
-                                        int* __restrict__ kout, int A, float ratio, int at_least_one) {
+// KREG > 0 (round 5): the row's keys are loaded ONCE into KREG registers per thread (A <= KREG * 1024) and the four passes run on them -
+// the loop used to re-load every score from L2 in each pass, one dependent ~500 ns round trip per 1024 elements and pass (34 x 4 at
+// 640 x 640: 76 us per step between the forward and the backward pass, where nothing else runs).  KREG == 0: the streaming form, any A.
+template <int KREG>
+__global__ __launch_bounds__(1024) void kth_largest_rows_kernel(const float* __restrict__ score, const int* __restrict__ counts, float* __restrict__ thr,
+                                                                int* __restrict__ kout, int A, float ratio, int at_least_one) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_k;
   const int b = blockIdx.x;
@@ -108,6 +112,14 @@ __global__ void kth_largest_rows_kernel(const float* __restrict__ score, const i
   if (at_least_one) k = max(k, 1);
   if (threadIdx.x == 0) kout[b] = k;
   if (k <= 0 || k > A) { if (threadIdx.x == 0) thr[b] = k <= 0 ? INFINITY : -INFINITY; return; }
+  [[maybe_unused]] unsigned keys[KREG > 0 ? KREG : 1];
+  if constexpr (KREG > 0) {
+#pragma unroll
+    for (int j = 0; j < KREG; ++j) {
+      const int a = j * 1024 + (int)threadIdx.x;
+      keys[j] = a < A ? f2key(row[a]) : 0u;
+    }
+  }
   unsigned prefix = 0, mask = 0;
   unsigned kk = (unsigned)k;
   for (int pass = 3; pass >= 0; --pass) {
@@ -117,14 +129,8 @@ __global__ void kth_largest_rows_kernel(const float* __restrict__ score, const i
     // address per pass (77 us per step whatever the batch).  The lanes that share the first live lane's digit (the sentinel, when it is
     // there) are combined into one atomic per wave-iteration; the remaining digits are spread over the bins and add themselves.  (Combining
     // EVERY distinct digit in a loop was slower than the plain form: 126 us — up to 64 rounds per wave-iteration on the low bytes.)
-    for (int a0 = 0; a0 < A; a0 += blockDim.x) {
-      const int a = a0 + (int)threadIdx.x;
-      unsigned key = 0;
-      bool live = false;
-      if (a < A) {
-        key = f2key(row[a]);
-        live = (key & mask) == prefix;
-      }
+    auto tally = [&](unsigned key, bool in_row) __attribute__((always_inline)) {
+      const bool live = in_row && (key & mask) == prefix;
       const unsigned digit = (key >> (pass * 8)) & 255u;
       const unsigned long long todo = __ballot(live);
       if (todo) {                                    // (wave-uniform)
@@ -133,6 +139,17 @@ __global__ void kth_largest_rows_kernel(const float* __restrict__ score, const i
         const unsigned long long same = __ballot(live && digit == d);
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
         if (live && digit != d) atomicAdd(&hist[digit], 1u);      // the other digits are spread out: no contention to speak of
+      }
+    };
+    if constexpr (KREG > 0) {
+#pragma unroll
+      for (int j = 0; j < KREG; ++j) {
+        if (j * 1024 < A) tally(keys[j], j * 1024 + (int)threadIdx.x < A);       // (uniform guard: whole 1024-element slabs beyond the row are skipped)
+      }
+    } else {
+      for (int a0 = 0; a0 < A; a0 += blockDim.x) {
+        const int a = a0 + (int)threadIdx.x;
+        tally(a < A ? f2key(row[a]) : 0u, a < A);
       }
     }
     __syncthreads();
@@ -159,7 +176,7 @@ __global__ void kth_largest_rows_kernel(const float* __restrict__ score, const i
 __global__ void detection_loss_fwd_kernel(const float* __restrict__ cls, const float* __restrict__ loc, const int* __restrict__ labels,
                                           const float* __restrict__ loc_t, const float* __restrict__ score, const float* __restrict__ thr,
                                           unsigned char* __restrict__ sel, float* __restrict__ acc, int A, long total) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   float ce = 0.f, ns = 0.f, ll = 0.f, np = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int b = (int)(i / A);
@@ -335,9 +352,15 @@ extern "C" int danhip_hard_neg_select(const float* cls, const int32_t* labels, f
   DH_REQUIRE(cls && labels && score && counts && thr && k_out && B > 0 && A > 0, DANHIP_EINVAL, "hard_neg_select: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * B, s) != hipSuccess) { danhip_set_error("hard_neg_select: memset failed"); return DANHIP_ELAUNCH; }
-  hipLaunchKernelGGL(hard_neg_scores_kernel, dim3((unsigned)grid_for(A, 256, 64), (unsigned)B), dim3(256), 0, s, cls, labels, score, counts, A);
+  // (few, fat blocks: the block totals end in atomics on two words per row - 64 blocks per row spent most of the kernel queueing on them)
+  hipLaunchKernelGGL(hard_neg_scores_kernel, dim3((unsigned)grid_for(A, 1024, 8), (unsigned)B), dim3(1024), 0, s, cls, labels, score, counts, A);
   DH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kth_largest_rows_kernel, dim3((unsigned)B), dim3(1024), 0, s, score, counts, thr, k_out, A, negative_ratio, at_least_one);
+  if (A <= 36 * 1024)
+    hipLaunchKernelGGL(kth_largest_rows_kernel<36>, dim3((unsigned)B), dim3(1024), 0, s, score, counts, thr, k_out, A, negative_ratio, at_least_one);
+  else if (A <= 88 * 1024)          // 1024 x 1024 inputs: 87 360 anchors
+    hipLaunchKernelGGL(kth_largest_rows_kernel<88>, dim3((unsigned)B), dim3(1024), 0, s, score, counts, thr, k_out, A, negative_ratio, at_least_one);
+  else
+    hipLaunchKernelGGL(kth_largest_rows_kernel<0>, dim3((unsigned)B), dim3(1024), 0, s, score, counts, thr, k_out, A, negative_ratio, at_least_one);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -348,7 +371,8 @@ extern "C" int danhip_detection_loss_fwd(const float* cls, const float* loc, con
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(acc4, 0, sizeof(float) * 4, s) != hipSuccess) { danhip_set_error("detection_loss_fwd: memset failed"); return DANHIP_ELAUNCH; }
   const long total = (long)B * A;
-  hipLaunchKernelGGL(detection_loss_fwd_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, s, cls, loc, labels, loc_targets, score, thr, sel,
+  // (the four sums end in atomics on ONE 16-byte word: 1024 blocks spent ~40 of the kernel's 57 us queueing there; 128 fat blocks do not)
+  hipLaunchKernelGGL(detection_loss_fwd_kernel, dim3(grid_for(total, 1024, 128)), dim3(1024), 0, s, cls, loc, labels, loc_targets, score, thr, sel,
                      acc4, A, total);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
