@@ -402,7 +402,7 @@ def main():
                     "what": "single-scale inference graph (forward + softmax + box decode%s), %dx%d" % (", anchor routing" if args.model.startswith("dan") else "", S, S)}
         # the same graph on the fp32 inference path (csrc/f32_infer.hip: the build that meets the 1e-4 box tolerance, tests/test_eval_f32_gpu.py)
         model.precision = "fp32"
-        b32 = min(B, 4)
+        b32 = B                      # (rounds 2-4 quoted it at batch 4: 275-295 img/s, a quarter of the workgroups per launch; same kernels)
         model.predict(imgs[:b32], anchors)
         et32 = timed(lambda: model.predict(imgs[:b32], anchors), 3)
         model.precision = "act"

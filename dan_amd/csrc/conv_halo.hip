@@ -447,6 +447,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   auto epilogue = [&]() __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(c_sp, n, y0, x0);
+#ifdef H_ABLATE_EPILOGUE
+    // timing-only build (tools/ab_variant.sh with AB_DEFINES=-DH_ABLATE_EPILOGUE): what the item boundary costs - the accumulators are
+    // consumed by an empty asm (kept live: cdna_hip_programming.md rule 17) and cleared, nothing is stored
+    if constexpr (NCU == 0) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int p = 0; p < NPT; ++p) {
+          asm volatile("" ::"v"(acc[c][p]));
+          acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      c_v += G;
+      c_ok = decode(c_v, c_sp, c_nb);
+      return;
+    }
+#endif
     if constexpr (NCU != 0) {                      // thin head: Cout < 64, possibly not a multiple of 4; forward only
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
@@ -509,8 +525,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr unsigned OOB = 0x80000000u;
         // (a.y == NULL - the pool-only inference call, danhip_conv2d_fwd_pool(y = NULL) - makes the descriptor ZERO bytes long: every store
         // of the full-resolution map is out of range and dropped by the hardware, without a branch)
+#ifdef H_ABLATE_STORES
+        // timing-only build: the whole epilogue runs, its full-resolution stores are dropped by a zero-length descriptor
+        const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, 0, 0x00020000);
+#else
         const __amdgpu_buffer_rsrc_t rsrc_y =
             __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y ? (int)((unsigned)(a.N * a.H * a.W) * (unsigned)a.Co * 2u) : 0, 0x00020000);
+#endif
         unsigned pix[NPT];
         bool okp[NPT];
 #pragma unroll
@@ -565,7 +586,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               for (int r = 0; r < 8; ++r) v[r] += bf2f(xp[r]);
             }
             u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+#ifdef H_ABLATE_STORE_PATTERN
+            // timing-only build (WRONG layout): the same bytes per item, but every store instruction covers ONE contiguous KiB
+            // (lane * 16 bytes inside the item's own 64 KiB of the output) instead of 16 half cache lines 512 bytes apart
+            __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((unsigned)((c_sp * g.NB + c_nb) & 0x3fff) * 65536u + (unsigned)(((wave * NPT + p) * NPAIR + q) * 1024 + lane * 16)), 0, 0);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
+#endif
             if constexpr (POOL) {
               if (!(okp[p] && cok[q])) tt = u32x4{0u, 0u, 0u, 0u};
               pk[q][p] = tt;
@@ -740,6 +767,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
           }
         }
       }
+      // Nothing with a register destination may look pending to the compiler when the loop comes round: the residual / mask / old-value
+      // loads of THIS path are issued and consumed under conditions hipcc cannot correlate, so it protected their destination registers
+      // with an s_waitcnt vmcnt(0) in step 0 of EVERY chunk of every path (in front of group A's fragment reads, in front of group B's
+      // barrier) - a full drain of the LDS-DMA queue, and of the lean epilogue's stores, every nine steps.  A builtin wait here (the waitcnt
+      // pass understands it; an asm one it would not) ends the uncertainty on the path that caused it.
+      __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0)
       }                                              // (the general epilogue)
     }
     c_v += G;

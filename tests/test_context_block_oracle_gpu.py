@@ -31,7 +31,7 @@ def _make_params(fwd, seed):
 def _hip_run(fn, vs, inputs, dy, dev):
     """-> (out, [input grads], {var: grad}, impose dict) of the HIP path with its ReLU decisions recorded."""
     from dan_amd import ops
-    from tests.gradcheck import collect_trace
+    from gradcheck import collect_trace
     named = vs.named()
     for _, p in named:
         p.grad = None

@@ -134,3 +134,35 @@ def dan_eval_case(deform, h, w, dev, logits16_tol=None):
     assert np.allclose(got_s[:n1], ref_s[:n1], atol=1e-5)
     bad = _box_bad(got_b[n1:], ref_b[n1:]).any(-1) | (np.abs(got_s[n1:] - ref_s[n1:]) > 1e-5)
     assert bad.mean() <= 1e-3, (int(bad.sum()), bad.size)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,relu,resid", [
+    (2, 96, 96, 64, 128, 3, 1, True, False),
+    (1, 125, 167, 3, 96, 3, 1, True, False),         # Cin = 3 (scalar loads, one ragged 16-channel chunk), ragged M, ragged Cout
+    (2, 100, 100, 64, 72, 3, 1, False, True),        # ragged Cout, residual after the activation
+    (2, 150, 150, 32, 256, 1, 1, True, False),       # pointwise
+    (4, 129, 127, 24, 128, 3, 2, True, False),       # stride 2, TF's asymmetric 'same' padding, C % 16 != 0
+])
+def test_fp32_conv_entry_point_vs_the_oracle(N, H, W, Cin, Cout, k, stride, relu, resid, dev):
+    """danhip_conv2d_fwd_f32 (the evaluation graphs in fp32: "boxes within 1e-4") alone against oracle.tf_ops.conv2d_same in fp32 - 1e-5 of the
+    output scale, the accumulation order being the only difference: ragged M / Cin / Cout, pointwise, stride 2, residual after the activation."""
+    import ctypes
+    from dan_amd import _lib, ops
+    from oracle import tf_ops as T
+    g = torch.Generator().manual_seed(N * 31 + Cin)
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((k, k, Cin, Cout), generator=g) / (k * k * Cin) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    want = T.conv2d_same(x, w, b, stride=stride, relu=relu)
+    r = torch.randn(want.shape, generator=g) if resid else None
+    if resid:
+        want = want + r
+    d = ops._desc(N, H, W, Cin, Cout, k, k, stride)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    rd = r.to(dev) if resid else None
+    y = torch.full(want.shape, float("nan"), device=dev)
+    _lib.call("danhip_conv2d_fwd_f32", ctypes.byref(d), _lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(y), int(relu), _lib.ptr(rd), _lib.stream())
+    torch.cuda.synchronize()
+    got = y.cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item()
