@@ -130,7 +130,8 @@ def flip_test(net, image, shrink):
 
 
 def bbox_vote_batch(dets, nms_threshold=NMS_THRESHOLD, max_per_image=MAX_PER_IMAGE):
-    """bbox_vote for a list of per-image detection sets in one launch (one workgroup per image)."""
+    """bbox_vote for a list of per-image detection sets in one launch (one workgroup per image).
+    Precondition (as bbox_vote): scores are fp32 values, possibly held in float64 - they are ordered after rounding to fp32."""
     B = len(dets)
     dev = dets[0].device
     nmax = max(1, max(d.shape[0] for d in dets))
@@ -149,7 +150,10 @@ def bbox_vote_batch(dets, nms_threshold=NMS_THRESHOLD, max_per_image=MAX_PER_IMA
 
 
 def bbox_vote(det, nms_threshold=NMS_THRESHOLD, max_per_image=MAX_PER_IMAGE):
-    """eval_dan.py:201-241 -> fp32 [K,5], K <= max_per_image."""
+    """eval_dan.py:201-241 -> fp32 [K,5], K <= max_per_image.
+    Precondition: the scores (column 4) are fp32 values, possibly carried in a float64 tensor - what this pipeline produces (softmax outputs
+    of detect_face).  They are ordered as fp32 (_order_desc): float64 scores that differ only below fp32 precision become ties and are
+    taken higher index first, not in their float64 order."""
     return bbox_vote_batch([det], nms_threshold, max_per_image)[0]
 
 

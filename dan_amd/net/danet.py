@@ -56,7 +56,9 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             return self.conv2d(hyper, filters, (1, 1), 1, name, relu=True, residual=x)
         return ops.add(self._cr(hyper, filters, (1, 1), name), x)
 
-    # False (or DANHIP_FUSED_CONTEXT=0 at import): the block as ten separate convolutions + concat + add (the round-3 form; A/B and tests)
+    # False (or DANHIP_FUSED_CONTEXT=0 at import): the block as ten separate convolutions + concat + add (the round-3 form; A/B and tests).
+    # Set it BEFORE a trainer is built: FlatParams lays the block's kernels out as strided views that only the fused call consumes
+    # (ops.packed_weights raises on the unfused path otherwise).
     FUSED_CONTEXT_BLOCK = os.environ.get("DANHIP_FUSED_CONTEXT", "1") == "1"
 
     def se_inception_block(self, inputs, name=None):
@@ -146,7 +148,8 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             outs.append(self.se_inception_block(mixed, "{}/predict_stage2_{}".format(name, i)))
         return outs
 
-    # False (or DANHIP_FUSED_STAGE2_MIX=0 at import): the two ragged 1x1 convolutions + concat (the form up to round 4; A/B and tests)
+    # False (or DANHIP_FUSED_STAGE2_MIX=0 at import): the two ragged 1x1 convolutions + concat (the form up to round 4; A/B and tests); as
+    # FUSED_CONTEXT_BLOCK, a choice to make before the trainer exists
     FUSED_STAGE2_MIX = os.environ.get("DANHIP_FUSED_STAGE2_MIX", "1") == "1"
 
     def _stage2_mix_fused(self, stage1, f, s1n, rsn):

@@ -50,7 +50,8 @@ def pack_conv_weight(d, w_hwio, need_bwd=True):
 # through raw pointers), same tensor version (in-place torch ops) and same storage.
 WEIGHT_EPOCH = 0
 _PACKED = {}
-_PACK_TABLE = None
+_PACK_TABLE_OF = {}          # key -> (entries, device table, workgroups, parameter ids, parameter pointers): repack_all(key, select);
+                             # cleared whenever the set of cached packings or one of their buffers changes
 
 
 class _Packed(object):
@@ -62,14 +63,12 @@ def _stamp(p):
 
 
 def _drop_packed(pid):
-    global _PACK_TABLE
     _PACKED.pop(pid, None)
-    _PACK_TABLE = None
+    _PACK_TABLE_OF.clear()
 
 
 def packed_weights(d, w, w_param, need_bwd):
     """-> (wf, wb) for conv descriptor d; cached per Parameter, packed on the spot for plain tensors."""
-    global _PACK_TABLE
     if w_param is None:
         return pack_conv_weight(d, w.detach(), need_bwd=need_bwd)
     import weakref
@@ -84,29 +83,39 @@ def packed_weights(d, w, w_param, need_bwd):
         rf, cf = packed_dims(e.d, 0)
         e.wf = torch.empty((rf, cf), dtype=ACT, device=w.device)
         _PACKED[pid] = e
-        _PACK_TABLE = None
+        _PACK_TABLE_OF.clear()
     if need_bwd and e.wb is None:
         rb, cb = packed_dims(e.d, 1)
         e.wb = torch.empty((rb, cb), dtype=ACT, device=w.device)
         e.stamp = None
-        _PACK_TABLE = None
+        _PACK_TABLE_OF.clear()
     st = _stamp(w_param)
     if e.stamp != st:
         wd = w_param.detach()
-        assert wd.dtype == torch.float32 and wd.is_contiguous()
+        if not (wd.dtype == torch.float32 and wd.is_contiguous()):
+            # e.g. a member of a fused block (VariableStore.fuse: a strided view of one flat-buffer segment once a trainer has laid the
+            # block out) reached an UNFUSED convolution: the fused / unfused choice (net.danet FUSED_CONTEXT_BLOCK / FUSED_STAGE2_MIX,
+            # DANHIP_FUSED_CONTEXT / DANHIP_FUSED_STAGE2_MIX) is per call, the layout is fixed when the trainer is built
+            raise RuntimeError("packed_weights: a kernel variable of shape %s arrives as a non-contiguous view (strides %s): it is a member of a "
+                               "fused parameter block, which only the fused op consumes - set the fused / unfused switches BEFORE the "
+                               "trainer (FlatParams) is built, not between calls" % (tuple(wd.shape), tuple(wd.stride())))
         call("danhip_pack_conv_weight", ctypes.byref(e.d), ptr(wd), wd.shape[2], ptr(e.wf), ptr(e.wb), stream())
         e.stamp = st
     return e.wf, (e.wb if need_bwd else None)
 
 
-def repack_all():
-    """One launch refreshing every cached packing (call after the optimizer changed the parameters)."""
-    global _PACK_TABLE
+def repack_all(key=None, select=None):
+    """One launch refreshing every cached packing (call after the optimizer changed the parameters).
+    key / select (round 5): a NAMED SUBSET of the cached packings - select(parameter) -> bool - with its own device table, for an optimizer
+    that runs bucket by bucket while backward is still producing the other buckets' gradients (trainer.DetectorTrainer._bucket_opt)."""
     entries = [(e, e.ref()) for e in _PACKED.values()]
-    entries = [(e, p) for e, p in entries if p is not None]
+    entries = [(e, p) for e, p in entries if p is not None and (select is None or select(p))]
     if not entries:
         return
-    if _PACK_TABLE is None or _PACK_TABLE[0] != len(entries):
+    tabs = _PACK_TABLE_OF
+    tab = tabs.get(key)
+    ids, ptrs = [id(p) for _, p in entries], [p.data_ptr() for _, p in entries]
+    if tab is None or tab[3] != ids or tab[4] != ptrs:
         arr = (_lib.PackEntry * len(entries))()
         first = 0
         nb = ctypes.c_int32()
@@ -115,12 +124,9 @@ def repack_all():
                  ctypes.byref(nb))
             first += nb.value
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        _PACK_TABLE = (len(entries), host.to(entries[0][1].device), first, [id(p) for _, p in entries], [p.data_ptr() for _, p in entries])
-    n, tab, blocks, ids, ptrs = _PACK_TABLE
-    if ids != [id(p) for _, p in entries] or ptrs != [p.data_ptr() for _, p in entries]:
-        _PACK_TABLE = None
-        return repack_all()
-    call("danhip_pack_conv_weights_batched", ptr(tab), n, blocks, stream())
+        tab = tabs[key] = (len(entries), host.to(entries[0][1].device), first, ids, ptrs)
+    n, dev_tab, blocks, _, _ = tab
+    call("danhip_pack_conv_weights_batched", ptr(dev_tab), n, blocks, stream())
     for e, p in entries:
         e.stamp = _stamp(p)
 

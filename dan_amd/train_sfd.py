@@ -129,6 +129,19 @@ class DetectorTrainer(object):
             model.forward(torch.zeros((1, init_hw[0], init_hw[1], 3), dtype=torch.uint8, device=dev))
         self.flat = FlatParams(model.vs, weight_decay)
         self.buckets = GradBuckets(self.flat)
+        # Round 5: the optimizer runs BUCKET BY BUCKET on the buckets' stream, right behind each bucket's all-reduce (or, on one GPU, as soon
+        # as both backward streams have produced the bucket's gradients), together with the re-packing of that bucket's convolution
+        # weights - instead of one update + one re-packing pass over all parameters after backward, with nothing beside them.  What stays
+        # behind the last backward kernel is the small tail bucket (GradBuckets: conv1_1 .. conv3_1).  Needs stream-ordered collectives
+        # (RCCL or none) and a static loss scale (the dynamic one inspects ALL gradients before any update).  DANHIP_OPT_OVERLAP=0: A/B.
+        self.opt_overlap = (os.environ.get("DANHIP_OPT_OVERLAP", "1") == "1" and self.ls_state is None and self.flat.g.is_cuda
+                            and (not self.buckets.enabled or self.buckets.device_collectives))
+        if self.opt_overlap:
+            self.buckets.enable_local()
+            self.buckets.on_bucket = self._bucket_opt
+            self._bucket_plans = [self.flat.range_plan(s, e) for s, e in self.buckets.bounds]
+            w0 = self.flat.w.data_ptr()
+            self._bucket_select = [(lambda p, lo=w0 + 4 * s, hi=w0 + 4 * e: lo <= p.data_ptr() < hi) for s, e in self.buckets.bounds]
         self.param_name = {id(p): n for n, p in model.vs.named()}
         self.param_name.update({id(t): key[0] for key, t in model.vs.fused.items()})
         self.step_no = 0
@@ -144,6 +157,15 @@ class DetectorTrainer(object):
         n = self.param_name.get(id(p))
         if n is not None:
             self.buckets.ready(n)
+
+    def _bucket_opt(self, b, s, e):
+        """GradBuckets.on_bucket: momentum-SGD of the flat range [s, e) and the 16-bit re-packing of its convolution weights, on the
+        buckets' stream (the kernels that needed the old packings of these layers were launched before the events this stream waited for)."""
+        self.flat.sgd_range(s, e, self._bucket_plans[b], self._step_lr, self.momentum, grad_scale=1.0 / self.loss_scale)
+        if not self._epoch_bumped:
+            ops.WEIGHT_EPOCH += 1                             # (the packings refreshed below are stamped with the new epoch)
+            self._epoch_bumped = True
+        ops.repack_all(key=("bucket", id(self), b), select=self._bucket_select[b])
 
     def loss_terms(self, images_u8, *targets):
         raise NotImplementedError
@@ -179,9 +201,13 @@ class DetectorTrainer(object):
     def _eager_towers(self, towers):
         self.flat.zero_grad()
         self.buckets.begin_step()
+        self._step_lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
+        self._epoch_bumped = False
+        if self.opt_overlap:
+            self.flat.l2.zero_()                              # (every bucket's update adds its share of the L2 term)
         for t, args in enumerate(towers):
             # gradients become final in the last tower's backward: only then may a bucket leave
-            ops.GRAD_READY_HOOK = self._hook if (self.buckets.enabled and t == len(towers) - 1) else None
+            ops.GRAD_READY_HOOK = self._hook if (self.buckets.active and t == len(towers) - 1) else None
             terms = self.loss_terms(*args)
             accs = [a[2] for a in terms]
             # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
@@ -202,9 +228,9 @@ class DetectorTrainer(object):
                 ops.wgrad_overlap_join()                      # (the next tower's forward reuses this one's activation buffers)
         self.buckets.finish()
         ops.wgrad_overlap_join()
-        lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         # the L2 term is rank-independent: its gradient wd*w is added inside the fused optimizer kernel
-        self.flat.sgd_step(lr, self.momentum, grad_scale=1.0 / self.loss_scale, dynamic_state=self.ls_state)
+        if not self.opt_overlap:                              # (else every bucket has been updated and re-packed behind its reduction)
+            self.flat.sgd_step(self._step_lr, self.momentum, grad_scale=1.0 / self.loss_scale, dynamic_state=self.ls_state)
         self.step_no += 1
         self.last = terms
         return terms

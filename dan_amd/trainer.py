@@ -255,6 +255,28 @@ class FlatParams(object):
         if self.struct_zero_idx is not None:
             self.g.index_fill_(0, self.struct_zero_idx, 0.0)
 
+    def range_plan(self, s, e):
+        """(first segment, segment count, device table of the segment starts relative to s, flat offsets of the structured zeros inside) of
+        the flat range [s, e) - which must begin and end on segment boundaries (gradient buckets do)."""
+        k0, k1 = self.starts.index(s), (self.starts.index(e) if e < self.total else len(self.starts))
+        rel = (self.seg[k0:k1 + 1] - s).contiguous()
+        idx = None
+        if self.struct_zero_idx is not None:
+            m = (self.struct_zero_idx >= s) & (self.struct_zero_idx < e)
+            idx = self.struct_zero_idx[m].contiguous() if bool(m.any()) else None
+        return k0, k1 - k0, rel, idx
+
+    def sgd_range(self, s, e, plan, lr, momentum=0.9, grad_scale=1.0):
+        """The update of sgd_step restricted to the flat range [s, e) (plan = range_plan(s, e)), on the CURRENT stream: the same kernel on
+        offset pointers and a relative segment table.  The caller zeroes self.l2 once per step and refreshes the packings of the range."""
+        k0, nseg, rel, idx = plan
+        if idx is not None:
+            self.g.index_fill_(0, idx, 0.0)
+        off = ctypes.c_void_p
+        base = lambda t, elems: off(t.data_ptr() + 4 * elems)
+        call("danhip_sgd_momentum_flat", base(self.w, s), base(self.g, s), base(self.v, s), ptr(rel), base(self.gmult, k0), base(self.wdc, k0), nseg,
+             e - s, float(lr), float(momentum), float(grad_scale), ptr(self.l2), stream())
+
     def sgd_step(self, lr, momentum=0.9, grad_scale=1.0, dynamic_state=None):
         """dynamic_state: fp32[4] device tensor {loss scale, clean steps, growth interval, flag} (danhip_sgd_momentum_flat_dynamic)."""
         self.mask_structured()
@@ -277,8 +299,12 @@ class GradBuckets(object):
     the start; bucket b is reduced once backward has produced every gradient at or after its start offset.  The
     trainer calls `ready(name)` from per-layer autograd hooks; reductions run on a dedicated side stream."""
 
-    def __init__(self, flat, bucket_bytes=32 << 20):
+    def __init__(self, flat, bucket_bytes=32 << 20, tail_bytes=2 << 20):
         self.flat = flat
+        # on_bucket(b, s, e): called on the communication stream behind bucket b's reduction (the trainer's per-bucket optimizer);
+        # local = True runs the bucket machinery (events, side stream, on_bucket) without any collective: one GPU, overlapped optimizer
+        self.on_bucket = None
+        self.local = False
         self.enabled = (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or (os.environ.get("DANHIP_FORCE_DIST") == "1" and flat.g.is_cuda)
         # DANHIP_FAKE_ALLREDUCE=1 (diagnosis, single process): run the bucket machinery with a device-only stand-in for the collective
         self.fake = (not self.enabled) and os.environ.get("DANHIP_FAKE_ALLREDUCE") == "1" and flat.g.is_cuda
@@ -295,6 +321,15 @@ class GradBuckets(object):
                 cur_end = s
         if cur_end > 0:
             self.bounds.append((0, cur_end))
+        # The LAST bucket holds the first layers' variables, whose gradients backward produces at the very end of the step: whatever is
+        # reduced (and updated) behind them is exposed.  It is therefore split so that its final part is small (<= tail_bytes: conv1_1 ..
+        # conv3_1 of the VGG backbone, 2.2 MB) - the larger part above it becomes complete ~3 ms of backward earlier and hides there.
+        s0, e0 = self.bounds[-1]
+        tail = max(1, tail_bytes // 4)
+        if e0 - s0 > 2 * tail:
+            cut = max((st for st in flat.starts if s0 < st <= s0 + tail), default=None)
+            if cut is not None and cut < e0:
+                self.bounds[-1:] = [(cut, e0), (s0, cut)]
         self.on_gpu = flat.g.is_cuda
         # Data plane: RCCL called directly through the library (RcclComm) for GPU buffers — DANHIP_DP_TRANSPORT=gloo keeps the process
         # group's host-staged collectives instead (the test hook that runs several ranks on ONE GPU: RCCL refuses duplicate devices).
@@ -302,7 +337,7 @@ class GradBuckets(object):
         self.transport = dp_transport() if (self.enabled and not self.fake and self.on_gpu) else ("fake" if self.fake else "gloo")
         self.rccl = RcclComm.shared(flat.g.device) if self.transport == "rccl" else None
         self.device_collectives = self.enabled and (self.fake or self.rccl is not None)
-        self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
+        self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None     # (enable_local creates it for one-GPU runs)
         self.pending = []
         self.next_bucket = 0
         self.start_of = dict(getattr(flat, "start_of_member", None) or zip(flat.names, flat.starts))   # members of fused blocks map to their block
@@ -328,6 +363,19 @@ class GradBuckets(object):
             longest = max(-(-(e - s) // w) * w for s, e in self.bounds)
             self.stage = [torch.zeros(longest, dtype=torch.bfloat16 if self.wire_bf16 else torch.float32, device=flat.g.device)
                           for _ in self.bounds]      # one staging buffer per bucket: several reductions are in flight at once
+
+    @property
+    def active(self):
+        """the per-layer gradient-ready hooks matter: collectives to launch, or a per-bucket optimizer to run"""
+        return self.enabled or self.local
+
+    def enable_local(self):
+        """One process, no collectives: keep the bucket machinery (gradient-ready events of both backward streams, the side stream) for the
+        trainer's per-bucket optimizer."""
+        if not self.enabled and self.on_gpu:
+            self.local = True
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream()
 
     def _reduce(self, b, s, e):
         """Sum flat.g[s:e] over the ranks on the current (communication) stream; -> work handle or None."""
@@ -361,7 +409,7 @@ class GradBuckets(object):
 
     def ready(self, name):
         """Gradient of `name` (and of everything created after it) is final."""
-        if not self.enabled:
+        if not self.active:
             return
         # The overlap rests on two properties of the step: a variable's gradient is produced by exactly ONE backward call, and the calls
         # arrive in reverse creation order (autograd runs nodes by decreasing sequence number; variables are created in forward order).
@@ -393,7 +441,7 @@ class GradBuckets(object):
                         self.comm_stream.wait_event(ev)
                     if self.fake:
                         self.flat.g[s:e].mul_(1.0)
-                    else:
+                    elif self.enabled:
                         wk = self._reduce(self.next_bucket, s, e)
                         if wk is not None:
                             self.pending.append(wk)
@@ -401,6 +449,8 @@ class GradBuckets(object):
                                 wk.wait()            # (orders the snapshot behind the collective on this stream; host-blocking for gloo)
                     if self.check:
                         self.snapshots.append((s, e, self.flat.g[s:e].clone()))
+                    if self.on_bucket is not None:   # (device collectives only: the reduction above is stream-ordered in front of it)
+                        self.on_bucket(self.next_bucket, s, e)
             else:                                    # gloo / CPU tensors (unit tests)
                 wk = dist.all_reduce(self.flat.g[s:e], op=dist.ReduceOp.SUM, async_op=True)
                 self.pending.append(wk)
@@ -410,7 +460,7 @@ class GradBuckets(object):
             self.next_bucket += 1
 
     def finish(self):
-        if not self.enabled:
+        if not self.active:
             return
         self.done_upto = 0
         self._launch_ready()

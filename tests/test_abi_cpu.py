@@ -481,3 +481,34 @@ def test_fused_context_block_fires_its_gradient_hooks_in_flat_buffer_order():
     g3[2, 2, 1, 40] = float("nan")
     flat.mask_structured()
     assert torch.isfinite(g3).all() and g3.sum().item() == 2 * 3 * 64 * 32
+
+
+def test_gradient_buckets_split_a_small_tail_off_the_last_bucket():
+    """trainer.GradBuckets (round 5): the last bucket holds the FIRST layers' variables, whose gradients backward produces at the very end of
+    the step - it is split so that only a small tail (<= tail_bytes) is reduced / updated behind the last backward kernel.  S3FD-like
+    layout: the buckets still tile the flat buffer back to front, on segment boundaries."""
+    from dan_amd.trainer import GradBuckets
+
+    class Flat:
+        pass
+    f = Flat()
+    sizes = [1728, 64, 36864, 64, 73728, 128, 147456, 128, 294912, 256, 589824, 256, 589824, 256, 1179648, 512, 2359296, 512, 2359296, 512,
+             2359296, 512, 2359296, 512, 2359296, 512, 4718592, 1024, 1048576, 1024]
+    f.starts, off = [], 0
+    for n in sizes:
+        f.starts.append(off); off += (n + 63) // 64 * 64
+    f.total = off
+    f.names = ["v%d" % i for i in range(len(sizes))]
+    f.g = torch.zeros(8)                                   # (CPU: no streams; only the layout is exercised)
+    b = GradBuckets(f, bucket_bytes=32 << 20, tail_bytes=2 << 20)
+    cov = sorted(b.bounds)
+    assert cov[0][0] == 0 and cov[-1][1] == f.total and all(cov[i][1] == cov[i + 1][0] for i in range(len(cov) - 1))
+    assert all(s in f.starts for s, _ in b.bounds)
+    assert b.bounds == sorted(b.bounds, reverse=True)      # launch order = back to front
+    s_tail, e_tail = b.bounds[-1]
+    assert s_tail == 0 and 0 < (e_tail - s_tail) * 4 <= 2 << 20
+    assert (b.bounds[-2][1] - b.bounds[-2][0]) * 4 > 2 << 20
+    # a buffer smaller than two tails keeps its single bucket
+    g = Flat()
+    g.starts, g.total, g.names, g.g = [0, 64000], 128000, ["a", "b"], torch.zeros(8)
+    assert GradBuckets(g, bucket_bytes=32 << 20, tail_bytes=2 << 20).bounds == [(0, 128000)]

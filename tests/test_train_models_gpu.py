@@ -336,3 +336,49 @@ def test_towers_step_sums_the_towers_gradients_like_the_reference_places_towers_
         # DAN's train-mode routing draws from a counter-based stream that the second tower continues: whole-gradient agreement in direction
         cos = torch.nn.functional.cosine_similarity(tw.flat.g, want, dim=0).item()
         assert cos >= 0.98 and torch.isfinite(tw.flat.g).all(), cos
+
+
+@pytest.mark.parametrize("which", ["sfd", "dan"])
+def test_bucketwise_optimizer_equals_the_single_pass_optimizer(which, dev, monkeypatch):
+    """Round 5: momentum-SGD and the 16-bit re-packing run bucket by bucket on the buckets' stream while backward continues
+    (DetectorTrainer._bucket_opt) instead of as one pass behind it.  Same arithmetic per element (train_sfd.py:419-447: L2 term, bias
+    gradient x 2, Momentum), so three steps land on the same parameters and momenta as DANHIP_OPT_OVERLAP=0 - up to the order of the
+    weight gradients' fp32 partial sums - with the structured zero places of DAN's 'plus' blocks still exactly zero, and the L2 loss the
+    buckets add up equals the single pass's."""
+    from dan_amd import synthetic
+    S = 64
+    imgs = synthetic.make_images(2, S, S, dev, seed=51)
+    gts = synthetic.make_gt_boxes(2, S, S, seed=52, max_faces=4)
+
+    def run(flag):
+        monkeypatch.setenv("DANHIP_OPT_OVERLAP", flag)
+        if which == "sfd":
+            from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+            anchors = AnchorConfig(S, S, dev)
+            loc_t, cls_t, _ = anchors.encode_batch(gts)
+            tr = SFDTrainer(SFDModel(device=dev, seed=9))
+            args = (imgs, loc_t, cls_t)
+        else:
+            from dan_amd.train_dan import DANModel, DANTrainer, dan_anchor_config, encode_batch_dan
+            anchors = dan_anchor_config(S, S, dev)
+            tr = DANTrainer(DANModel(device=dev, seed=9), anchors)
+            args = (imgs,) + tuple(encode_batch_dan(anchors, gts))
+        assert tr.opt_overlap == (flag == "1")
+        l2 = []
+        for _ in range(3):
+            tr.train_step(*args)
+            l2.append(tr.loss_values()["l2"])
+        torch.cuda.synchronize()
+        zeros = tr.flat.w[tr.flat.struct_zero_idx] if tr.flat.struct_zero_idx is not None else None
+        return tr.flat.w.clone(), tr.flat.v.clone(), l2, zeros, len(tr.buckets.bounds)
+
+    w1, v1, l1, z1, nb = run("1")
+    w0, v0, l0, z0, _ = run("0")
+    assert nb >= 2
+    scale = w0.abs().max().item()
+    assert (w1 - w0).abs().max().item() <= 1e-5 * scale
+    assert (v1 - v0).abs().max().item() <= 1e-4 * v0.abs().max().item()
+    for a, b in zip(l1, l0):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    if z1 is not None:
+        assert z1.eq(0).all() and z0.eq(0).all()
