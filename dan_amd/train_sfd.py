@@ -129,12 +129,16 @@ class DetectorTrainer(object):
             model.forward(torch.zeros((1, init_hw[0], init_hw[1], 3), dtype=torch.uint8, device=dev))
         self.flat = FlatParams(model.vs, weight_decay)
         self.buckets = GradBuckets(self.flat)
-        # Round 5: the optimizer runs BUCKET BY BUCKET on the buckets' stream, right behind each bucket's all-reduce (or, on one GPU, as soon
-        # as both backward streams have produced the bucket's gradients), together with the re-packing of that bucket's convolution
-        # weights - instead of one update + one re-packing pass over all parameters after backward, with nothing beside them.  What stays
-        # behind the last backward kernel is the small tail bucket (GradBuckets: conv1_1 .. conv3_1).  Needs stream-ordered collectives
-        # (RCCL or none) and a static loss scale (the dynamic one inspects ALL gradients before any update).  DANHIP_OPT_OVERLAP=0: A/B.
-        self.opt_overlap = (os.environ.get("DANHIP_OPT_OVERLAP", "1") == "1" and self.ls_state is None and self.flat.g.is_cuda
+        # Round 5, OPT-IN (DANHIP_OPT_OVERLAP=1): the optimizer runs BUCKET BY BUCKET on the buckets' stream, right behind each bucket's
+        # all-reduce (or, on one GPU, as soon as both backward streams have produced the bucket's gradients), together with the re-packing of
+        # that bucket's convolution weights - instead of one update + one re-packing pass over all parameters after backward.  What stays
+        # behind the last backward kernel is then the small tail bucket (GradBuckets: conv1_1 .. conv3_1).  Needs stream-ordered collectives
+        # (RCCL or none) and a static loss scale (the dynamic one inspects ALL gradients before any update).  MEASURED ON ONE GPU it LOSES:
+        # same box, alternating, S3FD batch 16: 12.68-12.74 ms with it against 12.60-12.68 without (profiles/r5/ab_vs_round4_same_box.txt) -
+        # the persistent convolution kernels leave no CU for the update to hide on, so it only adds launches and HBM traffic mid-backward.
+        # With more than one rank the end of the step is exposed to the last all-reduce anyway and the form may pay; nobody has measured it
+        # (one-GPU boxes), so the default stays the single pass.
+        self.opt_overlap = (os.environ.get("DANHIP_OPT_OVERLAP", "0") == "1" and self.ls_state is None and self.flat.g.is_cuda
                             and (not self.buckets.enabled or self.buckets.device_collectives))
         if self.opt_overlap:
             self.buckets.enable_local()
