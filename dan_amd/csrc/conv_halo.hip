@@ -500,10 +500,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       [[maybe_unused]] u32x4 pk[POOL ? NPAIR : 1][POOL ? NPT : 1];      // POOL: packed outputs (zero where the pixel is outside)
       if constexpr (BITS_OK) {
         if (a.mask_bits) {                           // the staged bit mask: 8 bytes = this wave's 64 channels of one pixel
+          // The staging area was filled by LDS-DMA in step 1 of this item (retired by the counted waits many steps ago: tests/
+          // test_handoff_replay_cpu.py, kind "bits").  Read through the compiler these loads drew an s_waitcnt vmcnt(0) - hipcc orders a
+          // ds_read behind every LDS-DMA it has seen - i.e. a full drain of the weight / patch prefetch queue once per item; asm reads with
+          // their own lgkmcnt wait do not (cdna_hip_programming.md 5.7, form (ii)).
+          dh_u32x2 bbv[NPT];
 #pragma unroll
           for (int p = 0; p < NPT; ++p) {
-            const int t = wm * TP + p * 16 + frow;
-            const uint2 bb = *reinterpret_cast<const uint2*>(smem + SBIAS + t * 16 + wn * 8);
+            const unsigned la = (unsigned)(size_t)(LDS_AS const char*)(smem + SBIAS + (wm * TP + p * 16 + frow) * 16 + wn * 8);
+            asm volatile("ds_read_b64 %0, %1" : "=v"(bbv[p]) : "v"(la) : "memory");
+          }
+          static_assert(NPT == 4 || NPT == 2, "the wait below names every destination");
+          if constexpr (NPT == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bbv[0]), "+v"(bbv[1]), "+v"(bbv[2]), "+v"(bbv[3])::"memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bbv[0]), "+v"(bbv[1])::"memory");
+#pragma unroll
+          for (int p = 0; p < NPT; ++p) {
+            const uint2 bb = uint2{bbv[p][0], bbv[p][1]};
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
               const int bi = fq + q * 4;                                // byte of channels cb + q*32 .. +7
