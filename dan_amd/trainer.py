@@ -500,6 +500,8 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (before the first HIP call of the process: the host driver only supports dmabuf IPC, and RCCL's peer mappings need this mode)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # DANHIP_FORCE_DIST=1: run the bucketed all-reduce even for ONE rank — the only way to put the RCCL code path on a single-GPU box
     # (tests/test_zz_ddp_gpu.py); a one-rank job needs no process group for it
     if torch.cuda.is_available():
@@ -507,7 +509,6 @@ def init_distributed():
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend=os.environ.get("DANHIP_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
     return rank, world, local
 

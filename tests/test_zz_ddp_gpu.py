@@ -174,3 +174,26 @@ print("COMM_OK")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "COMM_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[:3000], r.stderr[-3000:])
+
+
+def test_bench_line_of_a_two_rank_run_on_one_gpu(dev):
+    """bench.py as the driver launches it for N > 1 (`python bench.py --gpus 2` spawns torch.distributed.run): two ranks share the one GPU of
+    this box with the host-staged data plane (DANHIP_DP_TRANSPORT=gloo; RCCL refuses two ranks on one device) - what is exercised is the
+    multi-rank plumbing of the line itself: gloo control plane, barrier + max-over-ranks timing, the weak `value` and the strong-scaling leg
+    (global batch 8 on 2 ranks = 4 images per rank as two 2-image towers... here one 4-image tower), the roofline legs, orderly shutdown."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DANHIP_DP_TRANSPORT="gloo", DANHIP_BENCH_RCCL_LOG="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "2", "--size", "128",
+           "--strong-global-batch", "8", "--repeats", "2", "--eager", "--no-cpu-baseline", "--no-eval"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[:3000], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["repeats"]["regions"] == 2 and len(d["repeats"]["ms_per_step"]) == 2
+    s = d["strong"]
+    assert s["global_batch"] == 8 and s["n_gpus"] == 2 and s["batch_per_gpu"] == 4 and s["towers_per_gpu"] * s["tower_batch"] == 4 and s["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
+    assert d["config"]["dp_transport"] == "gloo" and d["config"]["rccl_ranks"] == 1
