@@ -95,16 +95,19 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// One block per row: exact k-th largest value by 4 radix passes (8 bits each).  k[b] = min(int(ratio*npos), nneg)
-// (DAN: max(.,1)).  k == 0 -> thr = +inf (no negative selected; the reference indexes -1 there: undefined).
-// KREG > 0 (round 5): the row's keys are loaded ONCE into KREG registers per thread (A <= KREG * 1024) and the four passes run on them -
-// the loop used to re-load every score from L2 in each pass, one dependent ~500 ns round trip per 1024 elements and pass (34 x 4 at
-// 640 x 640: 76 us per step between the forward and the backward pass, where nothing else runs).  KREG == 0: the streaming form, any A.
+// One block per row: exact k-th largest value.  k[b] = min(int(ratio*npos), nneg) (DAN: max(.,1)).  k == 0 -> thr = +inf (no negative
+// selected; the reference indexes -1 there: undefined).
+// Round 5: BIT-WISE selection on the monotone 32-bit keys, most significant bit first - "how many of the still-matching keys have this bit
+// set" is a ballot + population count per 64 keys and one 16-word LDS exchange per bit, no atomics at all.  The round-3 form built 256-bin
+// histograms with LDS atomics in four passes: almost all scores of a row share their top bytes (negatives' scores lie in (-1, 0), every
+// other anchor carries the sentinel -1), so a wave's 64 atomics hit one or two bins and serialised - 66 us per step at ANY batch size,
+// between the forward and the backward pass where nothing else runs (76 us before the keys moved into registers).
+// KREG > 0: the row's keys live in KREG registers per thread (A <= KREG * 1024); KREG == 0: the streaming form for any A (re-reads the
+// row for every bit: only rows beyond 88 * 1024 anchors take it).
 template <int KREG>
 __global__ __launch_bounds__(1024) void kth_largest_rows_kernel(const float* __restrict__ score, const int* __restrict__ counts, float* __restrict__ thr,
                                                                 int* __restrict__ kout, int A, float ratio, int at_least_one) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_k;
+  __shared__ unsigned part[2][16];
   const int b = blockIdx.x;
   const float* row = score + (long)b * A;
   int k = (int)(ratio * (float)counts[b * 2]);
@@ -114,60 +117,46 @@ __global__ __launch_bounds__(1024) void kth_largest_rows_kernel(const float* __r
   if (k <= 0 || k > A) { if (threadIdx.x == 0) thr[b] = k <= 0 ? INFINITY : -INFINITY; return; }
   [[maybe_unused]] unsigned keys[KREG > 0 ? KREG : 1];
   if constexpr (KREG > 0) {
+    // (unconditional loads from clamped addresses: a load under `if (a < A)` became a branch + s_waitcnt vmcnt(0) per slab - 36 dependent
+    // L2 round trips, most of the kernel's 53 us)
+    float raw[KREG];
 #pragma unroll
-    for (int j = 0; j < KREG; ++j) {
-      const int a = j * 1024 + (int)threadIdx.x;
-      keys[j] = a < A ? f2key(row[a]) : 0u;
-    }
+    for (int j = 0; j < KREG; ++j) raw[j] = row[min(j * 1024 + (int)threadIdx.x, A - 1)];
+#pragma unroll
+    for (int j = 0; j < KREG; ++j)
+      keys[j] = (j * 1024 + (int)threadIdx.x < A) ? f2key(raw[j]) : 0u;      // (a key of 0 never has the tested bit set: slots beyond the row never count)
   }
-  unsigned prefix = 0, mask = 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned prefix = 0, mask = 0;                       // the k-th largest key restricted to the bits decided so far
   unsigned kk = (unsigned)k;
-  for (int pass = 3; pass >= 0; --pass) {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    // Almost every score is the sentinel of a non-negative anchor (-1): one LDS atomic per element serialised 34 125 adds on a single
-    // address per pass (77 us per step whatever the batch).  The lanes that share the first live lane's digit (the sentinel, when it is
-    // there) are combined into one atomic per wave-iteration; the remaining digits are spread over the bins and add themselves.  (Combining
-    // EVERY distinct digit in a loop was slower than the plain form: 126 us — up to 64 rounds per wave-iteration on the low bytes.)
-    auto tally = [&](unsigned key, bool in_row) __attribute__((always_inline)) {
-      const bool live = in_row && (key & mask) == prefix;
-      const unsigned digit = (key >> (pass * 8)) & 255u;
-      const unsigned long long todo = __ballot(live);
-      if (todo) {                                    // (wave-uniform)
-        const int leader = __ffsll((long long)todo) - 1;
-        const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
-        const unsigned long long same = __ballot(live && digit == d);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
-        if (live && digit != d) atomicAdd(&hist[digit], 1u);      // the other digits are spread out: no contention to speak of
-      }
-    };
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned bm = 1u << bit, m2 = mask | bm, want = prefix | bm;
+    unsigned cnt = 0;                                  // wave-uniform: matching keys of this wave whose bit is set
     if constexpr (KREG > 0) {
+      // per-lane count in the vector ALU (and + compare + add-with-carry per key; slabs beyond the row hold zeros), then ONE wave sum of the
+      // (at most 7-bit) lane counts by a ballot per bit - a ballot + scalar population count per KEY made every compare wait for its
+      // round trip through the scalar unit (35 us)
+      unsigned cl = 0;
 #pragma unroll
-      for (int j = 0; j < KREG; ++j) {
-        if (j * 1024 < A) tally(keys[j], j * 1024 + (int)threadIdx.x < A);       // (uniform guard: whole 1024-element slabs beyond the row are skipped)
-      }
+      for (int j = 0; j < KREG; ++j) cl += ((keys[j] & m2) == want) ? 1u : 0u;
+#pragma unroll
+      for (int t = 0; (1 << t) <= KREG; ++t) cnt += (unsigned)__popcll(__ballot((cl >> t) & 1u)) << t;
     } else {
-      for (int a0 = 0; a0 < A; a0 += blockDim.x) {
+      for (int a0 = 0; a0 < A; a0 += 1024) {
         const int a = a0 + (int)threadIdx.x;
-        tally(a < A ? f2key(row[a]) : 0u, a < A);
+        const unsigned key = a < A ? f2key(row[a]) : 0u;
+        cnt += (unsigned)__popcll(__ballot((key & m2) == want));
       }
     }
+    unsigned* slot = part[bit & 1];                    // (two buffers: the one written now was last read two bits ago, behind a barrier)
+    if (lane == 0) slot[wave] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned cum = 0;
-      int bin = 255;
-      for (; bin > 0; --bin) {
-        if (cum + hist[bin] >= kk) break;
-        cum += hist[bin];
-      }
-      s_prefix = prefix | ((unsigned)bin << (pass * 8));
-      s_k = kk - cum;
-    }
-    __syncthreads();
-    prefix = s_prefix;
-    kk = s_k;
-    mask |= 255u << (pass * 8);
-    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += slot[w];
+    if (tot >= kk) prefix = want;                      // the k-th largest has this bit set
+    else kk -= tot;                                    // ... or lies among the keys without it
+    mask = m2;
   }
   if (threadIdx.x == 0) thr[b] = key2f(prefix);
 }
