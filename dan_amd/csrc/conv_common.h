@@ -146,6 +146,9 @@ size_t danhip_wgrad_pw_workspace_bytes(const danhip_conv_desc* d);
 int danhip_launch_wgrad_rows(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s,
                              void* ws = nullptr, size_t ws_bytes = 0, int ldx = 0, int ldy = 0);      // ldx / ldy: pixel pitches (0 = dense)
 size_t danhip_wgrad_rows_workspace_bytes(const danhip_conv_desc* d);
+// First-layer weight gradient (3x3 / stride 1, 8-channel image with <= 4 real channels, 64 outputs; conv_wgrad_c8.hip)
+bool danhip_wgrad_c8_eligible(const danhip_conv_desc* d, int cin_real, int ldx, int ldy);
+int danhip_launch_wgrad_c8(const danhip_conv_desc* d, const bf16_t* x, const bf16_t* dy, float* dw, float* db, int cin_real, hipStream_t s);
 
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
 __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {

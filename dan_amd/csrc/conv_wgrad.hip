@@ -244,6 +244,7 @@ extern "C" const char* danhip_conv_wgrad_kernel_label(const danhip_conv_desc* d)
   const char* pl = danhip_wgrad_pw_label(d);
   if (pl) return pl;
   const int co8 = (d->Cout + 7) / 8 * 8;
+  if (danhip_wgrad_c8_eligible(d, 3, d->Cin, co8)) return "conv_wgrad_c8_kernel";
   if (d->Cin == 8 && d->kh * d->kw <= 16) return co8 > 64 ? "conv_wgrad_kernel<128, 128, 2>" : "conv_wgrad_kernel<128, 64, 2>";
   const bool ci_small = d->Cin <= 64, co_small = co8 <= 64;
   if (ci_small && co_small) return "conv_wgrad_kernel<64, 64, 2>";
@@ -296,6 +297,8 @@ static int bwd_weight_impl(const danhip_conv_desc* d, const uint16_t* x, const u
   a.ktiles = (a.M + 63) / 64;
   a.div_wo = make_fastdiv(a.Wo); a.div_howo = make_fastdiv(a.Ho * a.Wo);
   hipStream_t s = (hipStream_t)stream;
+  if (danhip_wgrad_c8_eligible(d, cin_real, ldx, ldy))     // conv1_1: both operands staged once, taps as address offsets (conv_wgrad_c8.hip)
+    return danhip_launch_wgrad_c8(d, x, dy, dw_hwio, db, cin_real, s);
   if (d->Cin == 8 && d->kh * d->kw <= 16 && !view) {       // first layer: taps ride in the tile columns
     a.tapcols = 1;
     return a.Co8 > 64 ? launch_wgrad<128, 128, 2>(a, s) : launch_wgrad<128, 64, 2>(a, s);

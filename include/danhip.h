@@ -51,6 +51,8 @@ int danhip_version(void);
  *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 form by the offsets' statistics (on the device), 1 always the
  *                                           gather form with a +-2 px window, 2 always the fp32-atomics scatter form, 3 gather form, +-1 px
  *   "halo_general_epilogue" [DANHIP_HALO_GENERAL_EPILOGUE, 0]  1: csrc/conv_halo.hip always takes its general epilogue (A/B of the lean one)
+ *   "wgrad_c8"   [DANHIP_WGRAD_C8, 1]    0: the first layer's weight gradient (3x3, 8-channel image, 64 outputs) on the general kernel instead of
+ *                                           csrc/conv_wgrad_c8.hip
  *   "pw_dgrad_ld_bn" [DANHIP_PW_DGRAD_LD_BN, 128]  256: csrc/conv_pointwise.hip's data gradient with a ReLU mask / accumulation may take 256-wide tiles
  * Results agree up to fp32 summation order whatever the setting.  danhip_set_option returns DANHIP_EINVAL for an unknown name. */
 int danhip_set_option(const char* name, int value);

@@ -805,3 +805,42 @@ def test_pool_only_training_skips_the_full_resolution_stores_and_changes_no_grad
     if skipped:
         with pytest.raises(AssertionError):              # nothing can read the unwritten map: ptr() refuses the zero-stride view
             ops.conv2d(y1.detach(), w2[:, :, :Cout], b2, relu=True)
+
+
+@pytest.mark.parametrize("N,H,W,cin_real", [(2, 37, 131, 3), (1, 8, 64, 3), (3, 64, 100, 4), (1, 5, 1, 1), (2, 96, 96, 3), (1, 203, 331, 3)])
+def test_first_layer_weight_gradient_kernel_vs_the_oracle_and_the_general_kernel(N, H, W, cin_real, dev):
+    """conv_wgrad_c8.hip (round 5): conv1_1's weight and bias gradient (net/sfd_net.py:128; 3x3 / 'same', the image padded to 8 channels) with
+    both operands staged once and the nine taps as address offsets of one halo patch, against the fp32 oracle gradient (autograd through
+    oracle.tf_ops.conv2d_same on the 16-bit-rounded operands: what remains is the fp32 summation order, 1e-3 of the gradient's scale) and
+    against the general kernel it replaces (option "wgrad_c8" = 0).  Ragged sizes: tiles of 8 x 64 pixels with zero-filled remainders;
+    accumulation into a non-zero dW / db (the flat gradient buffer's += semantics)."""
+    from dan_amd import _lib, ops
+    g = torch.Generator().manual_seed(N * 13 + H)
+    x = torch.zeros((N, H, W, 8))
+    x[..., :cin_real] = torch.randn((N, H, W, cin_real), generator=g)
+    x = x.to(ops.ACT)
+    dy = torch.randn((N, H, W, 64), generator=g).to(ops.ACT)
+    w = torch.zeros((3, 3, cin_real, 64), requires_grad=True)
+    b = torch.zeros((64,), requires_grad=True)
+    y = T.conv2d_same(x[..., :cin_real].float(), w, b)
+    (y * dy.float()).sum().backward()
+    d = ops._desc(N, H, W, 8, 64, 3, 3, 1)
+    xd, dyd = x.to(dev), dy.to(dev)
+    L = _lib.lib()
+    outs = []
+    for new in (1, 0):
+        assert L.danhip_set_option(b"wgrad_c8", new) == 0
+        dw = torch.full((3, 3, cin_real, 64), 0.5, dtype=torch.float32, device=dev)
+        db = torch.full((64,), -0.25, dtype=torch.float32, device=dev)
+        try:
+            assert (L.danhip_conv_wgrad_kernel_label(ctypes.byref(d)) == b"conv_wgrad_c8_kernel") == bool(new)
+            _lib.call("danhip_conv2d_bwd_weight", ctypes.byref(d), _lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw), _lib.ptr(db), cin_real, _lib.stream())
+            torch.cuda.synchronize()
+        finally:
+            L.danhip_set_option(b"wgrad_c8", 1)
+        outs.append((dw.cpu() - 0.5, db.cpu() + 0.25))
+    sw, sb = w.grad.abs().max().item() + 1e-6, b.grad.abs().max().item() + 1e-6
+    for dw, db in outs:
+        assert (dw - w.grad).abs().max().item() <= 1e-3 * sw + 2e-6 * N * H * W ** 0.5      # (+ the 0.5 start value's fp32 rounding of large sums)
+        assert (db - b.grad).abs().max().item() <= 1e-3 * sb + 2e-6 * N * H * W ** 0.5
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-3 * sw + 2e-6 * N * H * W ** 0.5
