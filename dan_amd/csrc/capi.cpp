@@ -34,6 +34,7 @@ extern "C" int danhip_act_dtype(void) {
 //   "wgrad_b2"   DANHIP_WGRAD_B2    0 (default) / 1: the same for conv_wgrad_rows.hip / conv_wgrad_pw.hip
 //   "halo_general_epilogue" DANHIP_HALO_GENERAL_EPILOGUE  0 (default) / 1: conv_halo.hip always takes its general epilogue (A/B of the lean one)
 //   "wgrad_c8"   DANHIP_WGRAD_C8    1 (default) / 0: the first layer's weight gradient on conv_wgrad_c8.hip (0: the general kernel; A/B and tests)
+//   "deform_dx_untiled" DANHIP_DEFORM_DX_UNTILED  0 (default) / 1: the deformable backward's +-1 px gather as the wave-per-pixel kernel (A/B, tests)
 //   "pw_dgrad_ld_bn" DANHIP_PW_DGRAD_LD_BN  128 (default) / 256: widest tile of conv_pointwise.hip's data gradient WITH epilogue inputs (A/B:
 //                the 256-wide form reads dY once but measured no faster - S3FD 1198.6 vs 1197.6 img/s, DAN 433.9 vs 436.2)
 namespace {
@@ -45,7 +46,7 @@ struct Opt { const char* name; const char* env; int def; std::atomic<int> value;
 Opt g_opts[] = {{"splitk", "DANHIP_SPLITK", 1, {0}}, {"wgrad_slab", "DANHIP_WGRAD_SLAB", 1, {0}}, {"halo_b2", "DANHIP_HALO_B2", 0, {0}},
                 {"wgrad_b2", "DANHIP_WGRAD_B2", 0, {0}}, {"halo_general_epilogue", "DANHIP_HALO_GENERAL_EPILOGUE", 0, {0}},
                 {"deform_bwd_form", "DANHIP_DEFORM_BWD_FORM", 0, {0}}, {"pw_dgrad_ld_bn", "DANHIP_PW_DGRAD_LD_BN", 128, {0}},
-                {"wgrad_c8", "DANHIP_WGRAD_C8", 1, {0}}};
+                {"wgrad_c8", "DANHIP_WGRAD_C8", 1, {0}}, {"deform_dx_untiled", "DANHIP_DEFORM_DX_UNTILED", 0, {0}}};
 std::once_flag g_opts_once;
 Opt* find_opt(const char* name) {
   std::call_once(g_opts_once, [] {

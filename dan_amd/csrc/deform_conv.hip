@@ -285,7 +285,6 @@ __global__ void deform_sample_bwd_c64_kernel(const bf16_t* __restrict__ x, const
 // deterministic gather.  Corners further than R from their nominal position (offsets beyond ~R-1 px) keep the memory atomic
 // (`far` below); the two sets are complementary by construction.  dOffset needs no atomics at all: one wave per (output pixel, group)
 // has all nine taps' loads in flight and reduces the 18 sums with a transposing butterfly (29 shuffles instead of 108).
-constexpr int DEFORM_R = 2;      // the widest gather window (the kernels are instantiated for 1 and 2)
 
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
@@ -336,6 +335,60 @@ __device__ __forceinline__ float corner_weight_at(float inv_h, float inv_w, int 
   return axis_factor(inv_h, h, H) * axis_factor(inv_w, w, W);
 }
 
+// The 18 sums of an item, spread over its 8 lanes -> lane l8 holds the (dh, dw) pair of tap (4*b0 + 2*b1 + b2) and stores it as one 32-bit
+// word: a transposing butterfly (14 + 6 shuffles).  `dp` = the item's 18 bf16 of dOffset (an even element index: 32-bit aligned pairs).
+__device__ __forceinline__ void doff_reduce_store(const float (&sv)[18], bool live, bf16_t* __restrict__ dp, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  // 16 of the 18 sums: after the step with partner distance d a lane keeps the half its bit selects
+  float r8[8], r4[4], r2[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r8[j] = (b0 ? sv[j + 8] : sv[j]) + __shfl_xor(b0 ? sv[j] : sv[j + 8], 1, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r4[j] = (b1 ? r8[j + 4] : r8[j]) + __shfl_xor(b1 ? r8[j] : r8[j + 4], 2, 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) r2[j] = (b2 ? r4[j + 2] : r4[j]) + __shfl_xor(b2 ? r4[j] : r4[j + 2], 4, 64);
+  float e0 = sv[16], e1 = sv[17];
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); }
+  if (live) {
+    *reinterpret_cast<unsigned*>(dp + (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0)) = pack2bf(r2[0], r2[1]);
+    if ((lane & 7) == 0) *reinterpret_cast<unsigned*>(dp + 16) = pack2bf(e0, e1);
+  }
+}
+
+// Far corners: not reachable by the gather kernels' +-R enumeration.  A corner that corner_set() accepts sits floor(o) or
+// floor(o) + 1 from the nominal position (under the high-edge clamp the only candidate one further away, H - 1 for a position of
+// exactly H, fails the |position - corner| < 1 guard), so offsets in [-R, R) cannot produce one: the whole search is skipped then.
+// `farm` = the item's taps with an offset outside [-R, R); uo / ud = the item's offsets and (lane's piece of the) dS rows.
+template <int R>
+__device__ __forceinline__ void doff_far_corners(unsigned farm, bool live, const bf16_t* __restrict__ uo, const bf16_t* __restrict__ ud,
+                                                 float* __restrict__ far_dx, const DeformGeom& g, int n, int h_in, int w_in, int grp, int l8) {
+  if (!__any(live && farm != 0)) return;
+  if (!live) farm = 0;
+  while (farm) {                                                        // (uniform inside an 8-lane item; rare)
+    const int t = __builtin_ctz(farm);
+    farm &= farm - 1;
+    const unsigned oraw = *reinterpret_cast<const unsigned*>(uo + 2 * t);
+    const int nh = h_in + (t / 3) * g.dil, nw = w_in + (t % 3) * g.dil;
+    const CornerSet cs = corner_set((float)nh + bf2f((bf16_t)(oraw & 0xffffu)), (float)nw + bf2f((bf16_t)(oraw >> 16)), g.H, g.W);
+    bool any_far = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) any_far = any_far || (cs.ok[k] && (abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R));
+    if (!any_far) continue;
+    float cg[8];
+    unpack8(*reinterpret_cast<const uint4*>(ud + t * g.C), cg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool far = abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R;
+      if (cs.ok[k] && far) {
+        float* dst = far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + grp * 64 + l8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dst + e, cs.wg[k] * cg[e]);
+      }
+    }
+  }
+}
+
 // dOffset (+ the far corners' atomics into the fp32 side buffer): EIGHT LANES per (output pixel, group) — lane l8 owns 8 of the group's
 // 64 channels, i.e. one 16-byte piece of every row it touches, so the 45 loads of an item are 16-byte lane accesses (the earlier
 // wave-per-item form issued them as 2-byte ones: eight times the load instructions for the same bytes).  The sampling geometry is
@@ -350,7 +403,6 @@ __device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restri
   const unsigned nwork = (unsigned)g.N * g.Ho * g.Wo * g.dg;            // (< 2^31: checked by the launcher)
   const float Hf = (float)g.H, Wf = (float)g.W;
   const float lim = (float)R;
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
   for (unsigned wbase = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8u; wbase < nwork; wbase += gridDim.x * (blockDim.x >> 6) * 8u) {
     const unsigned item = wbase + (lane >> 3);
     const bool live = item < nwork;
@@ -405,49 +457,8 @@ __device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restri
         sv[2 * (tb * 3 + u) + 1] = s_w;
       }
     }
-    // 16 of the 18 sums: after the step with partner distance d a lane keeps the half its bit selects
-    float r8[8], r4[4], r2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r8[j] = (b0 ? sv[j + 8] : sv[j]) + __shfl_xor(b0 ? sv[j] : sv[j + 8], 1, 64);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r4[j] = (b1 ? r8[j + 4] : r8[j]) + __shfl_xor(b1 ? r8[j] : r8[j + 4], 2, 64);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) r2[j] = (b2 ? r4[j + 2] : r4[j]) + __shfl_xor(b2 ? r4[j] : r4[j + 2], 4, 64);
-    float e0 = sv[16], e1 = sv[17];
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { e0 += __shfl_xor(e0, o, 64); e1 += __shfl_xor(e1, o, 64); }
-    if (live) {
-      bf16_t* dp = doffs + (long)m * offc + grp * 18;                   // (an even element index: 32-bit aligned pairs)
-      *reinterpret_cast<unsigned*>(dp + (b0 ? 8 : 0) + (b1 ? 4 : 0) + (b2 ? 2 : 0)) = pack2bf(r2[0], r2[1]);
-      if (l8 == 0) *reinterpret_cast<unsigned*>(dp + 16) = pack2bf(e0, e1);
-    }
-    // ---- far corners: not reachable by the gather kernel's +-R enumeration.  A corner that corner_set() accepts sits floor(o) or
-    // floor(o) + 1 from the nominal position (under the high-edge clamp the only candidate one further away, H - 1 for a position of
-    // exactly H, fails the |position - corner| < 1 guard), so offsets in [-R, R) cannot produce one: skip the whole search then
-    if (!__any(live && farm != 0)) continue;
-    if (!live) farm = 0;
-    while (farm) {                                                      // (uniform inside an 8-lane item; rare)
-      const int t = __builtin_ctz(farm);
-      farm &= farm - 1;
-      const unsigned oraw = *reinterpret_cast<const unsigned*>(uo + 2 * t);
-      const int nh = h_in + (t / 3) * g.dil, nw = w_in + (t % 3) * g.dil;
-      const CornerSet cs = corner_set((float)nh + bf2f((bf16_t)(oraw & 0xffffu)), (float)nw + bf2f((bf16_t)(oraw >> 16)), g.H, g.W);
-      bool any_far = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) any_far = any_far || (cs.ok[k] && (abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R));
-      if (!any_far) continue;
-      float cg[8];
-      unpack8(*reinterpret_cast<const uint4*>(ud + t * g.C), cg);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool far = abs(cs.rh[k] - nh) > R || abs(cs.rw[k] - nw) > R;
-        if (cs.ok[k] && far) {
-          float* dst = far_dx + (((long)n * g.H + cs.rh[k]) * g.W + cs.rw[k]) * g.C + grp * 64 + l8 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(dst + e, cs.wg[k] * cg[e]);
-        }
-      }
-    }
+    doff_reduce_store(sv, live, doffs + (long)m * offc + grp * 18, lane);
+    doff_far_corners<R>(farm, live, uo, ud, far_dx, g, n, h_in, w_in, grp, l8);
   }
 }
 
@@ -456,9 +467,9 @@ __device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restri
 // launch of its own on a 65536-block grid (~150 us to retire empty; DAN-Deform has 12 of these calls per step).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
                                                                    const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
-                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
+                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate, int tiled0) {
   const int form = gate_form(gate);
-  if (form == 0) deform_bwd_doff9_c64_body<1>(x, offs, dS, far_dx, doffs, g);
+  if (form == 0 && !tiled0) deform_bwd_doff9_c64_body<1>(x, offs, dS, far_dx, doffs, g);
   else if (form == 1) deform_bwd_doff9_c64_body<2>(x, offs, dS, far_dx, doffs, g);
 }
 
@@ -537,10 +548,233 @@ __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __r
 // (160 x 160 x 256, batch 16).  The opposite trade - prefetching the next item's offsets, 90 VGPRs, 5 waves - was 7-13 % SLOWER.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                         const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                        int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x) {
+                                                                        int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x, int tiled0) {
   const int form = gate_form(gate);
-  if (form == 0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, relu_x);
+  if (form == 0 && !tiled0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, relu_x);   // (tiled0: the tile kernel has form 0)
   else if (form == 1) deform_bwd_dx_gather9_c64_body<2>(offs, dS, far_dx, dx, g, accumulate, relu_x);
+}
+
+constexpr int DT_H = 8, DT_W = 16, DT_RH = DT_H + 4, DT_RW = DT_W + 4;
+
+// dOffset in the +-1 window, TILE form (round 5).  The item-per-8-lanes kernel above reads the four bilinear corners of all nine taps
+// from L1 / L2: 36 sixteen-byte gathers of x per 9 of dS, and at 160 x 160 x 256 (batch 16) the cache pipes, not HBM, set its 0.77 ms.
+// Here a 256-thread block owns an 8 x 16 tile of OUTPUT pixels of one group and stages the group's 64 channels of the x pixels any tap
+// with an offset in [-1, 1) can touch (tile +-2: 12 x 20 pixels, 30 KB) in LDS once; the corner gathers become ds_read_b128.  A tap whose
+// corners leave the staged region (offset outside [-1, 1): at most 1 / 128 of them in this form) takes the global loads.  Arithmetic,
+// reduction and the far corners' atomics are the item kernel's.  3 x 3, stride 1, dilation 1, C / deformable_group == 64.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff_tile_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                                       const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                                       bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate, int tiles_h, int tiles_w) {
+  if (gate_form(gate) != 0) return;
+  __shared__ uint4 sx[DT_RH * DT_RW * 8];
+  unsigned b = blockIdx.x;
+  const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
+  const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
+  const int th0 = (int)(b % (unsigned)tiles_h) * DT_H;
+  const int n = (int)(b / (unsigned)tiles_h);
+  const int offc = g.dg * 18;
+  const bf16_t* xn = x + ((long)n * g.H * g.W) * g.C + grp * 64;
+  for (int idx = threadIdx.x; idx < DT_RH * DT_RW * 8; idx += 256) {
+    const int px = idx >> 3, pc = idx & 7;
+    const int hh = th0 - 2 + px / DT_RW, ww = tw0 - 2 + px % DT_RW;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) v = *reinterpret_cast<const uint4*>(xn + (long)(hh * g.W + ww) * g.C + pc * 8);
+    sx[idx] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l8 = lane & 7;
+  const int slot = threadIdx.x >> 3;
+  const int pw = slot % DT_W, ph0 = slot / DT_W;
+  const float Hf = (float)g.H, Wf = (float)g.W;
+#pragma unroll 1
+  for (int bt = 0; bt < 4; ++bt) {
+    const int ho_raw = th0 + 2 * bt + ph0, wo_raw = tw0 + pw;
+    const bool live = ho_raw < g.Ho && wo_raw < g.Wo;
+    const int ho = live ? ho_raw : g.Ho - 1, wo = live ? wo_raw : g.Wo - 1;
+    const long m = ((long)n * g.Ho + ho) * g.Wo + wo;
+    const int h_in = ho - g.pad_t, w_in = wo - g.pad_l;
+    const bf16_t* ub = xn + l8 * 8;
+    const bf16_t* ud = dS + m * 9 * g.C + grp * 64 + l8 * 8;
+    const bf16_t* uo = offs + m * offc + grp * 18;
+    unsigned farm = 0;                                                  // taps whose offset may reach a corner beyond +-1
+    bf16_t* dp = doffs + m * offc + grp * 18;
+    // A tap ROW at a time, the loop kept rolled: unrolled over all nine taps hipcc computes every tap's geometry up front (290 VGPRs).
+    // The row's six sums are reduced over the item's 8 lanes by a transposing butterfly (4 + 2 + 1 shuffles): lane l8 ends with sum
+    // 4*b0 + 2*b1 + b2 (6 and 7 are padding) and stores it as one 16-bit value.
+#pragma unroll 1
+    for (int tb = 0; tb < 3; ++tb) {
+      uint4 cgr[3];
+      unsigned orw[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) { cgr[u] = *reinterpret_cast<const uint4*>(ud + (tb * 3 + u) * g.C); orw[u] = *reinterpret_cast<const unsigned*>(uo + 2 * (tb * 3 + u)); }
+      float sv[8];
+      sv[6] = 0.f; sv[7] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const float off_h = bf2f((bf16_t)(orw[u] & 0xffffu)), off_w = bf2f((bf16_t)(orw[u] >> 16));
+        if (off_h < -1.f || off_h >= 1.f || off_w < -1.f || off_w >= 1.f) farm |= 1u << (tb * 3 + u);
+        const float inv_h = (float)(h_in + tb) + off_h, inv_w = (float)(w_in + u) + off_w;
+        const bool in = !(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf);
+        float ih = in ? inv_h : 0.f, iw = in ? inv_w : 0.f;
+        int hl = (int)ih, wl = (int)iw, hh, wh;
+        if (hl >= g.H - 1) { hh = hl = g.H - 1; ih = (float)hl; } else hh = hl + 1;
+        if (wl >= g.W - 1) { wh = wl = g.W - 1; iw = (float)wl; } else wh = wl + 1;
+        const float a_w = in ? (float)(wl + 1) - iw : 0.f, b_w = in ? iw - (float)wl : 0.f;      // get_coordinate_weight (:177-221)
+        const float a_h = in ? (float)(hl + 1) - ih : 0.f, b_h = in ? ih - (float)hl : 0.f;
+        const int rl = hl - (th0 - 2), rh = hh - (th0 - 2), cl = wl - (tw0 - 2), ch = wh - (tw0 - 2);
+        const bool staged = rl >= 0 && rh < DT_RH && cl >= 0 && ch < DT_RW;
+        uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+        if (in && staged) {
+          v0 = sx[(rl * DT_RW + cl) * 8 + l8]; v1 = sx[(rl * DT_RW + ch) * 8 + l8];
+          v2 = sx[(rh * DT_RW + cl) * 8 + l8]; v3 = sx[(rh * DT_RW + ch) * 8 + l8];
+        }
+        if (__any(in && !staged)) {                                     // (an offset outside [-1, 1): rare in this form)
+          if (in && !staged) {
+            v0 = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wl) * g.C); v1 = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wh) * g.C);
+            v2 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wl) * g.C); v3 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wh) * g.C);
+          }
+        }
+        float vll[8], vlh[8], vhl[8], vhh[8], cg[8];
+        unpack8(v0, vll); unpack8(v1, vlh); unpack8(v2, vhl); unpack8(v3, vhh); unpack8(cgr[u], cg);
+        float s_h = 0.f, s_w = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s_h += (-1.f * a_w * vll[e] + -1.f * b_w * vlh[e] + a_w * vhl[e] + b_w * vhh[e]) * cg[e];
+          s_w += (-1.f * a_h * vll[e] + a_h * vlh[e] + -1.f * b_h * vhl[e] + b_h * vhh[e]) * cg[e];
+        }
+        sv[2 * u] = s_h;
+        sv[2 * u + 1] = s_w;
+      }
+      const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+      float r4[4], r2[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r4[j] = (b0 ? sv[j + 4] : sv[j]) + __shfl_xor(b0 ? sv[j] : sv[j + 4], 1, 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) r2[j] = (b1 ? r4[j + 2] : r4[j]) + __shfl_xor(b1 ? r4[j] : r4[j + 2], 2, 64);
+      const float r1 = (b2 ? r2[1] : r2[0]) + __shfl_xor(b2 ? r2[0] : r2[1], 4, 64);
+      const int which = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+      if (live && which < 6) dp[tb * 6 + which] = f2bf(r1);
+    }
+    doff_far_corners<1>(farm, live, uo, ud, far_dx, g, n, h_in, w_in, grp, l8);
+  }
+}
+
+// dX in the +-1 window, TILE form (round 5).  The wave-per-pixel gather above spends its life on memory round trips: per input pixel and
+// group it loads 81 candidates' offsets from 81 scattered 4-byte places, then the dS rows they select as 2-byte lane accesses (1.96 ms at
+// 160 x 160 x 256, batch 16, zero offsets: 9 rows per pixel).  Here a 256-thread block owns an 8 x 16 tile of INPUT pixels of one group:
+// the offsets of every (output pixel, tap) that can reach the tile (output pixels within +-2: 12 x 20 x 9 words) are staged in LDS once,
+// EIGHT lanes own a pixel (lane l8 = 8 of the group's 64 channels = one 16-byte piece of each dS row), the 81 candidates are weighed
+// eight at a time (one per lane, offsets from LDS), and every non-zero one is handed to the pixel's eight lanes by two ds_bpermutes and
+// accumulated from ONE 16-byte load per lane.  Same candidate set, same weights (corner_weight_at) and the same order (candidate
+// index ascending) as the wave-per-pixel form: deterministic, no atomics; far corners as before (the fp32 side buffer, read only when
+// the statistic says an offset left [-1, 1) at all).  3 x 3, stride 1, dilation 1, C / deformable_group == 64.
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_tile_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                                     const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
+                                                                     int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x, int tiles_h,
+                                                                     int tiles_w) {
+  if (gate_form(gate) != 0) return;
+  __shared__ unsigned soff[DT_RH * DT_RW * 9];
+  unsigned b = blockIdx.x;
+  const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
+  const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
+  const int th0 = (int)(b % (unsigned)tiles_h) * DT_H;
+  const int n = (int)(b / (unsigned)tiles_h);
+  const int offc = g.dg * 18;
+  const bool has_far = gate.stat[1] != 0u;
+  {
+    const unsigned far_away = (unsigned)f2bf(60000.f) * 0x10001u;            // a position no pixel is near: weight 0
+    for (int idx = threadIdx.x; idx < DT_RH * DT_RW * 9; idx += 256) {
+      const int t = idx % 9, r = idx / 9;
+      const int ho = th0 - 2 + r / DT_RW, wo = tw0 - 2 + r % DT_RW;
+      unsigned v = far_away;
+      if (ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo)
+        v = *reinterpret_cast<const unsigned*>(offs + (((long)n * g.Ho + ho) * g.Wo + wo) * offc + (grp * 9 + t) * 2);
+      soff[idx] = v;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l8 = lane & 7, gbase = lane & 56;
+  const int slot = threadIdx.x >> 3;                                         // 0..31: pixel (2 * bt + slot / 16, slot % 16) of the tile in batch bt
+  const int pw = slot % DT_W, ph0 = slot / DT_W;
+  const int w = tw0 + pw;
+  const bf16_t* dsg = dS + grp * 64 + l8 * 8;
+  // (batch outermost, one pixel's eight sums live at a time: 8 waves per SIMD — the loop is two dependent round trips per candidate round)
+#pragma unroll 1
+  for (int bt = 0; bt < 4; ++bt) {
+    const int ph = 2 * bt + ph0, h = th0 + ph;
+    const bool pvalid = h < g.H && w < g.W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 11; ++r) {
+      const int cand = r * 8 + l8;
+      const bool live = cand < 81 && pvalid;
+      const int t = cand % 9, pos = cand < 81 ? cand / 9 : 4;
+      const int dh = pos / 3 - 1, dw = pos % 3 - 1;
+      const int ti = t / 3, tj = t % 3;
+      // output pixel of the candidate: (nominal position) + pad - tap, pad = 1: row h + dh + 1 - ti, staged at row index (that) - (th0 - 2)
+      const int nh = h + dh, nw = w + dw;
+      const unsigned oraw = soff[((ph + dh + 3 - ti) * DT_RW + (pw + dw + 3 - tj)) * 9 + t];
+      const float inv_h = (float)nh + bf2f((bf16_t)(oraw & 0xffffu)), inv_w = (float)nw + bf2f((bf16_t)(oraw >> 16));
+      float wv = corner_weight_at(inv_h, inv_w, h, w, g.H, g.W);
+      if (!live) wv = 0.f;
+      const int row = (((n * g.Ho + (nh + 1 - ti)) * g.Wo) + (nw + 1 - tj)) * 9 + t;       // (used only where wv != 0: a valid output pixel)
+      unsigned m8 = (unsigned)(__ballot(wv != 0.f) >> gbase) & 0xffu;
+      while (__any(m8 != 0u)) {                                              // four dS rows in flight per trip and pixel
+        float w4[4];
+        int r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool has = m8 != 0u;
+          const int src = gbase + (has ? __builtin_ctz(m8) : 0);
+          m8 &= m8 - 1u;
+          const float wq = __shfl(wv, src, 64);
+          const int rq = __shfl(row, src, 64);
+          w4[q] = has ? wq : 0.f;
+          r4[q] = has ? rq : 0;
+        }
+        uint4 d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d4[q] = *reinterpret_cast<const uint4*>(dsg + (long)r4[q] * g.C);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float f[8];
+          unpack8(d4[q], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w4[q] * f[e];
+        }
+      }
+    }
+    if (!pvalid) continue;
+    const long o = (((long)n * g.H + h) * g.W + w) * g.C + grp * 64 + l8 * 8;
+    if (has_far) {
+      const float4 fa = *reinterpret_cast<const float4*>(far_dx + o), fb = *reinterpret_cast<const float4*>(far_dx + o + 4);
+      acc[0] += fa.x; acc[1] += fa.y; acc[2] += fa.z; acc[3] += fa.w; acc[4] += fb.x; acc[5] += fb.y; acc[6] += fb.z; acc[7] += fb.w;
+    }
+    if (relu_x) {                                                            // x is a ReLU output: its producer's ReLU backward, folded in here
+      float m[8];
+      unpack8(*reinterpret_cast<const uint4*>(relu_x + o), m);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (!(m[e] > 0.f)) acc[e] = 0.f;
+    }
+    if (accumulate) {
+      float old[8];
+      unpack8(*reinterpret_cast<const uint4*>(dx + o), old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += old[e];
+    }
+    *reinterpret_cast<uint4*>(dx + o) = pack8(acc);
+  }
+}
+
+// The fp32 side buffer is needed only when a corner can fall outside the gather window or the scatter form runs: both imply an offset
+// outside [-1, 1) (stat[1] != 0) unless a form is forced.  420 MB of zero stores per call at 160 x 160 x 256, batch 16, otherwise.
+__global__ void zero_if_far_kernel(uint4* __restrict__ p16, long n16, const unsigned* __restrict__ stat, int force) {
+  if (!(stat[1] != 0u || force == 1 || force == 2)) return;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) p16[i] = z;
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8, int accumulate, BwdGate gate,
@@ -576,9 +810,12 @@ __global__ __launch_bounds__(256) void deform_far_stat_kernel(const bf16_t* __re
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { c2 += __shfl_xor(c2, o, 64); c1 += __shfl_xor(c1, o, 64); }
-  if ((threadIdx.x & 63) == 0) {
-    if (c2) atomicAdd(stat, c2);
-    if (c1) atomicAdd(stat + 1, c1);
+  __shared__ unsigned part[2][4];                                        // one atomic per block and word (8192 waves queued on one address: 100 us)
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = c2; part[1][threadIdx.x >> 6] = c1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const unsigned v = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (v) atomicAdd(stat + threadIdx.x, v);
   }
 }
 
@@ -644,10 +881,13 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const long nx = (long)N * H * W * C;
-  // fp32 scatter target + 64 words of statistics behind it, zeroed together
-  { const int zrc = danhip_zero_async(workspace, sizeof(float) * (nx + 64), s); if (zrc) return zrc; }
   unsigned* stat = reinterpret_cast<unsigned*>(workspace + nx);
-  if (C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9) {
+  const bool gathered = C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9;
+  // fp32 scatter target + 64 words of statistics behind it: zeroed together — or, for the gather forms, the statistics now and the
+  // target by zero_if_far_kernel once they say it will be used at all
+  const bool lazy_zero = gathered && (nx * 4) % 16 == 0;
+  { const int zrc = lazy_zero ? danhip_zero_async(stat, sizeof(unsigned) * 64, s) : danhip_zero_async(workspace, sizeof(float) * (nx + 64), s); if (zrc) return zrc; }
+  if (gathered) {
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
     const long pairs = (long)N * g.Ho * g.Wo * deformable_group * 9;
     // A corner lies floor(o) or floor(o) + 1 from the tap's nominal position, so it is outside the +-R window iff o is outside [-R, R).
@@ -655,10 +895,24 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
     // 3.4 / 7.7 ms in the +-2 gather form; s = 2.0 -> 53 % -> 43 ms; the scatter form: 12.0 ms whatever the offsets); the +-1 window
     // (81 candidates per input pixel and group instead of 225) while fewer than 1 / 128 of the taps lie outside [-1, 1).
     BwdGate gate{stat, (unsigned)(pairs / 20 * 3), (unsigned)(pairs / 128), danhip_option("deform_bwd_form")};
-    hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 2048)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs, stat);
-    const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, 65536));
-    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate);
-    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate, rx);
+    hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 1024)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs, stat);
+    if (lazy_zero)
+      hipLaunchKernelGGL(zero_if_far_kernel, dim3(grid_for(nx / 4, 256, 2048)), dim3(256), 0, s, reinterpret_cast<uint4*>(workspace), nx / 4, stat, gate.force);
+    // the +-1 window as the tile kernel (dilation 1, 32-bit dS row indices); the wave-per-pixel kernel keeps the +-2 window on a grid that
+    // costs ~10 us to retire when it is not its turn (grid-stride loop: 8 resident blocks per CU x 2)
+    const int tiles_h = (H + DT_H - 1) / DT_H, tiles_w = (W + DT_W - 1) / DT_W;
+    const long tile_blocks = (long)N * tiles_h * tiles_w * deformable_group;
+    const int tiled0 = dilation == 1 && g.pad_t == 1 && g.pad_l == 1 && tile_blocks < (1l << 31) && !danhip_option("deform_dx_untiled") ? 1 : 0;
+    const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, tiled0 ? 4096 : 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, tiled0 ? 4096 : 65536));
+    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate, tiled0);
+    if (tiled0)
+      hipLaunchKernelGGL(deform_bwd_doff_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x),
+                         reinterpret_cast<const bf16_t*>(offsets), reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(d_offsets), g, gate,
+                         tiles_h, tiles_w);
+    if (tiled0)
+      hipLaunchKernelGGL(deform_bwd_dx_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets),
+                         reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(dx), g, accumulate, gate, rx, tiles_h, tiles_w);
+    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate, rx, tiled0);
     // the scatter form's two kernels on small grids (grid-stride loops): empty ~10 us each when a gather form runs
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 2048)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,

@@ -50,6 +50,8 @@ int danhip_version(void);
  *   "wgrad_b2"   [DANHIP_WGRAD_B2, 0]    1: the same for csrc/conv_wgrad_rows.hip and csrc/conv_wgrad_pw.hip
  *   "deform_bwd_form" [DANHIP_DEFORM_BWD_FORM, 0]  deformable backward: 0 form by the offsets' statistics (on the device), 1 always the
  *                                           gather form with a +-2 px window, 2 always the fp32-atomics scatter form, 3 gather form, +-1 px
+ *   "deform_dx_untiled" [DANHIP_DEFORM_DX_UNTILED, 0]  1: the +-1 px gather of the deformable backward as the wave-per-input-pixel kernel instead
+ *                                           of the LDS-staged tile kernel (same candidates, weights and summation order)
  *   "halo_general_epilogue" [DANHIP_HALO_GENERAL_EPILOGUE, 0]  1: csrc/conv_halo.hip always takes its general epilogue (A/B of the lean one)
  *   "wgrad_c8"   [DANHIP_WGRAD_C8, 1]    0: the first layer's weight gradient (3x3, 8-channel image, 64 outputs) on the general kernel instead of
  *                                           csrc/conv_wgrad_c8.hip
