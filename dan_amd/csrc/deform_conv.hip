@@ -467,9 +467,9 @@ __device__ __forceinline__ void deform_bwd_doff9_c64_body(const bf16_t* __restri
 // launch of its own on a 65536-block grid (~150 us to retire empty; DAN-Deform has 12 of these calls per step).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff9_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
                                                                    const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
-                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate, int tiled0) {
+                                                                   bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate) {
   const int form = gate_form(gate);
-  if (form == 0 && !tiled0) deform_bwd_doff9_c64_body<1>(x, offs, dS, far_dx, doffs, g);
+  if (form == 0) deform_bwd_doff9_c64_body<1>(x, offs, dS, far_dx, doffs, g);
   else if (form == 1) deform_bwd_doff9_c64_body<2>(x, offs, dS, far_dx, doffs, g);
 }
 
@@ -548,25 +548,25 @@ __device__ __forceinline__ void deform_bwd_dx_gather9_c64_body(const bf16_t* __r
 // (160 x 160 x 256, batch 16).  The opposite trade - prefetching the next item's offsets, 90 VGPRs, 5 waves - was 7-13 % SLOWER.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_gather9_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
                                                                         const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                        int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x, int tiled0) {
+                                                                        int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x) {
   const int form = gate_form(gate);
-  if (form == 0 && !tiled0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, relu_x);   // (tiled0: the tile kernel has form 0)
+  if (form == 0) deform_bwd_dx_gather9_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, relu_x);
   else if (form == 1) deform_bwd_dx_gather9_c64_body<2>(offs, dS, far_dx, dx, g, accumulate, relu_x);
 }
 
-constexpr int DT_H = 8, DT_W = 16, DT_RH = DT_H + 4, DT_RW = DT_W + 4;
+constexpr int DT_H = 8, DT_W = 16;
 
-// dOffset in the +-1 window, TILE form (round 5).  The item-per-8-lanes kernel above reads the four bilinear corners of all nine taps
+// dOffset in a +-R window (R = 1, 2), TILE form (round 5).  The item-per-8-lanes kernel above reads the four bilinear corners of all nine taps
 // from L1 / L2: 36 sixteen-byte gathers of x per 9 of dS, and at 160 x 160 x 256 (batch 16) the cache pipes, not HBM, set its 0.77 ms.
 // Here a 256-thread block owns an 8 x 16 tile of OUTPUT pixels of one group and stages the group's 64 channels of the x pixels any tap
-// with an offset in [-1, 1) can touch (tile +-2: 12 x 20 pixels, 30 KB) in LDS once; the corner gathers become ds_read_b128.  A tap whose
-// corners leave the staged region (offset outside [-1, 1): at most 1 / 128 of them in this form) takes the global loads.  Arithmetic,
+// with an offset in [-R, R) can touch (tile +-(R + 1): 12 x 20 pixels, 30 KB for R = 1) in LDS once; the corner gathers become ds_read_b128.
+// A tap whose corners leave the staged region (offset outside [-R, R): rare in the form the statistic picks) takes the global loads.  Arithmetic,
 // reduction and the far corners' atomics are the item kernel's.  3 x 3, stride 1, dilation 1, C / deformable_group == 64.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff_tile_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
-                                                                       const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
-                                                                       bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate, int tiles_h, int tiles_w) {
-  if (gate_form(gate) != 0) return;
-  __shared__ uint4 sx[DT_RH * DT_RW * 8];
+template <int R>
+__device__ __forceinline__ void deform_bwd_doff_tile_c64_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                              const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                              bf16_t* __restrict__ doffs, const DeformGeom& g, int tiles_h, int tiles_w, uint4* sx) {
+  constexpr int DT_RH = DT_H + 2 * (R + 1), DT_RW = DT_W + 2 * (R + 1);
   unsigned b = blockIdx.x;
   const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
   const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const bf16_t* xn = x + ((long)n * g.H * g.W) * g.C + grp * 64;
   for (int idx = threadIdx.x; idx < DT_RH * DT_RW * 8; idx += 256) {
     const int px = idx >> 3, pc = idx & 7;
-    const int hh = th0 - 2 + px / DT_RW, ww = tw0 - 2 + px % DT_RW;
+    const int hh = th0 - (R + 1) + px / DT_RW, ww = tw0 - (R + 1) + px % DT_RW;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) v = *reinterpret_cast<const uint4*>(xn + (long)(hh * g.W + ww) * g.C + pc * 8);
     sx[idx] = v;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bf16_t* ub = xn + l8 * 8;
     const bf16_t* ud = dS + m * 9 * g.C + grp * 64 + l8 * 8;
     const bf16_t* uo = offs + m * offc + grp * 18;
-    unsigned farm = 0;                                                  // taps whose offset may reach a corner beyond +-1
+    unsigned farm = 0;                                                  // taps whose offset may reach a corner beyond +-R
     bf16_t* dp = doffs + m * offc + grp * 18;
     // A tap ROW at a time, the loop kept rolled: unrolled over all nine taps hipcc computes every tap's geometry up front (290 VGPRs).
     // The row's six sums are reduced over the item's 8 lanes by a transposing butterfly (4 + 2 + 1 shuffles): lane l8 ends with sum
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const float off_h = bf2f((bf16_t)(orw[u] & 0xffffu)), off_w = bf2f((bf16_t)(orw[u] >> 16));
-        if (off_h < -1.f || off_h >= 1.f || off_w < -1.f || off_w >= 1.f) farm |= 1u << (tb * 3 + u);
+        if (off_h < -(float)R || off_h >= (float)R || off_w < -(float)R || off_w >= (float)R) farm |= 1u << (tb * 3 + u);
         const float inv_h = (float)(h_in + tb) + off_h, inv_w = (float)(w_in + u) + off_w;
         const bool in = !(inv_h < 0 || inv_w < 0 || inv_h >= Hf || inv_w >= Wf);
         float ih = in ? inv_h : 0.f, iw = in ? inv_w : 0.f;
@@ -621,14 +621,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (wl >= g.W - 1) { wh = wl = g.W - 1; iw = (float)wl; } else wh = wl + 1;
         const float a_w = in ? (float)(wl + 1) - iw : 0.f, b_w = in ? iw - (float)wl : 0.f;      // get_coordinate_weight (:177-221)
         const float a_h = in ? (float)(hl + 1) - ih : 0.f, b_h = in ? ih - (float)hl : 0.f;
-        const int rl = hl - (th0 - 2), rh = hh - (th0 - 2), cl = wl - (tw0 - 2), ch = wh - (tw0 - 2);
+        const int rl = hl - (th0 - (R + 1)), rh = hh - (th0 - (R + 1)), cl = wl - (tw0 - (R + 1)), ch = wh - (tw0 - (R + 1));
         const bool staged = rl >= 0 && rh < DT_RH && cl >= 0 && ch < DT_RW;
         uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
         if (in && staged) {
           v0 = sx[(rl * DT_RW + cl) * 8 + l8]; v1 = sx[(rl * DT_RW + ch) * 8 + l8];
           v2 = sx[(rh * DT_RW + cl) * 8 + l8]; v3 = sx[(rh * DT_RW + ch) * 8 + l8];
         }
-        if (__any(in && !staged)) {                                     // (an offset outside [-1, 1): rare in this form)
+        if (__any(in && !staged)) {                                     // (an offset outside [-R, R): rare in this form)
           if (in && !staged) {
             v0 = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wl) * g.C); v1 = *reinterpret_cast<const uint4*>(ub + (long)(hl * g.W + wh) * g.C);
             v2 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wl) * g.C); v3 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wh) * g.C);
@@ -655,38 +655,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int which = (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
       if (live && which < 6) dp[tb * 6 + which] = f2bf(r1);
     }
-    doff_far_corners<1>(farm, live, uo, ud, far_dx, g, n, h_in, w_in, grp, l8);
+    doff_far_corners<R>(farm, live, uo, ud, far_dx, g, n, h_in, w_in, grp, l8);
   }
 }
 
-// dX in the +-1 window, TILE form (round 5).  The wave-per-pixel gather above spends its life on memory round trips: per input pixel and
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void deform_bwd_doff_tile_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ offs,
+                                                                       const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
+                                                                       bf16_t* __restrict__ doffs, DeformGeom g, BwdGate gate, int tiles_h, int tiles_w) {
+  __shared__ uint4 sx[(DT_H + 6) * (DT_W + 6) * 8];                     // the +-2 window's region: 14 x 22 pixels x 128 B = 39 KB
+  const int form = gate_form(gate);
+  if (form == 0) deform_bwd_doff_tile_c64_body<1>(x, offs, dS, far_dx, doffs, g, tiles_h, tiles_w, sx);
+  else if (form == 1) deform_bwd_doff_tile_c64_body<2>(x, offs, dS, far_dx, doffs, g, tiles_h, tiles_w, sx);
+}
+
+// dX in a +-R window (R = 1: 81 candidates per input pixel, R = 2: 225), TILE form (round 5).  The wave-per-pixel gather above spends its life on memory round trips: per input pixel and
 // group it loads 81 candidates' offsets from 81 scattered 4-byte places, then the dS rows they select as 2-byte lane accesses (1.96 ms at
 // 160 x 160 x 256, batch 16, zero offsets: 9 rows per pixel).  Here a 256-thread block owns an 8 x 16 tile of INPUT pixels of one group:
-// the offsets of every (output pixel, tap) that can reach the tile (output pixels within +-2: 12 x 20 x 9 words) are staged in LDS once,
+// the offsets of every (output pixel, tap) that can reach the tile (output pixels within +-(R + 1): 12 x 20 x 9 words for R = 1) are staged in LDS once,
 // EIGHT lanes own a pixel (lane l8 = 8 of the group's 64 channels = one 16-byte piece of each dS row), the 81 candidates are weighed
 // eight at a time (one per lane, offsets from LDS), and every non-zero one is handed to the pixel's eight lanes by two ds_bpermutes and
 // accumulated from ONE 16-byte load per lane.  Same candidate set, same weights (corner_weight_at) and the same order (candidate
 // index ascending) as the wave-per-pixel form: deterministic, no atomics; far corners as before (the fp32 side buffer, read only when
-// the statistic says an offset left [-1, 1) at all).  3 x 3, stride 1, dilation 1, C / deformable_group == 64.
+// the statistic says an offset left [-R, R) at all).  3 x 3, stride 1, dilation 1, C / deformable_group == 64.
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_tile_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
-                                                                     const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
-                                                                     int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x, int tiles_h,
-                                                                     int tiles_w) {
-  if (gate_form(gate) != 0) return;
-  __shared__ unsigned soff[DT_RH * DT_RW * 9];
+template <int R>
+__device__ __forceinline__ void deform_bwd_dx_tile_c64_body(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                            const float* __restrict__ far_dx, bf16_t* __restrict__ dx, const DeformGeom& g,
+                                                            int accumulate, const BwdGate& gate, const bf16_t* __restrict__ relu_x, int tiles_h,
+                                                            int tiles_w, unsigned* soff) {
+  constexpr int DT_RH = DT_H + 2 * (R + 1), DT_RW = DT_W + 2 * (R + 1), D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 7) / 8;
   unsigned b = blockIdx.x;
   const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
   const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
   const int th0 = (int)(b % (unsigned)tiles_h) * DT_H;
   const int n = (int)(b / (unsigned)tiles_h);
   const int offc = g.dg * 18;
-  const bool has_far = gate.stat[1] != 0u;
+  const bool has_far = gate.stat[R == 1 ? 1 : 0] != 0u;                     // an offset outside [-R, R) exists at all
   {
     const unsigned far_away = (unsigned)f2bf(60000.f) * 0x10001u;            // a position no pixel is near: weight 0
     for (int idx = threadIdx.x; idx < DT_RH * DT_RW * 9; idx += 256) {
       const int t = idx % 9, r = idx / 9;
-      const int ho = th0 - 2 + r / DT_RW, wo = tw0 - 2 + r % DT_RW;
+      const int ho = th0 - (R + 1) + r / DT_RW, wo = tw0 - (R + 1) + r % DT_RW;
       unsigned v = far_away;
       if (ho >= 0 && ho < g.Ho && wo >= 0 && wo < g.Wo)
         v = *reinterpret_cast<const unsigned*>(offs + (((long)n * g.Ho + ho) * g.Wo + wo) * offc + (grp * 9 + t) * 2);
@@ -708,15 +717,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll 1
-    for (int r = 0; r < 11; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       const int cand = r * 8 + l8;
-      const bool live = cand < 81 && pvalid;
-      const int t = cand % 9, pos = cand < 81 ? cand / 9 : 4;
-      const int dh = pos / 3 - 1, dw = pos % 3 - 1;
+      const bool live = cand < NC && pvalid;
+      const int t = cand % 9, pos = cand < NC ? cand / 9 : (D * D) / 2;
+      const int dh = pos / D - R, dw = pos % D - R;
       const int ti = t / 3, tj = t % 3;
-      // output pixel of the candidate: (nominal position) + pad - tap, pad = 1: row h + dh + 1 - ti, staged at row index (that) - (th0 - 2)
+      // output pixel of the candidate: (nominal position) + pad - tap, pad = 1: row h + dh + 1 - ti, staged at row index (that) - (th0 - R - 1)
       const int nh = h + dh, nw = w + dw;
-      const unsigned oraw = soff[((ph + dh + 3 - ti) * DT_RW + (pw + dw + 3 - tj)) * 9 + t];
+      const unsigned oraw = soff[((ph + dh + R + 2 - ti) * DT_RW + (pw + dw + R + 2 - tj)) * 9 + t];
       const float inv_h = (float)nh + bf2f((bf16_t)(oraw & 0xffffu)), inv_w = (float)nw + bf2f((bf16_t)(oraw >> 16));
       float wv = corner_weight_at(inv_h, inv_w, h, w, g.H, g.W);
       if (!live) wv = 0.f;
@@ -767,6 +776,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     *reinterpret_cast<uint4*>(dx + o) = pack8(acc);
   }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void deform_bwd_dx_tile_c64_kernel(const bf16_t* __restrict__ offs, const bf16_t* __restrict__ dS,
+                                                                     const float* __restrict__ far_dx, bf16_t* __restrict__ dx, DeformGeom g,
+                                                                     int accumulate, BwdGate gate, const bf16_t* __restrict__ relu_x, int tiles_h,
+                                                                     int tiles_w) {
+  __shared__ unsigned soff[(DT_H + 6) * (DT_W + 6) * 9];                     // the +-2 window's region: 14 x 22 output pixels x 9 taps = 11 KB
+  const int form = gate_form(gate);
+  if (form == 0) deform_bwd_dx_tile_c64_body<1>(offs, dS, far_dx, dx, g, accumulate, gate, relu_x, tiles_h, tiles_w, soff);
+  else if (form == 1) deform_bwd_dx_tile_c64_body<2>(offs, dS, far_dx, dx, g, accumulate, gate, relu_x, tiles_h, tiles_w, soff);
 }
 
 // The fp32 side buffer is needed only when a corner can fall outside the gather window or the scatter form runs: both imply an offset
@@ -885,7 +904,11 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
   const bool gathered = C / deformable_group == 64 && stride == 1 && kh == 3 && kw == 3 && (long)N * g.Ho * g.Wo * 9 < (1l << 31) && deformable_group <= 9;
   // fp32 scatter target + 64 words of statistics behind it: zeroed together — or, for the gather forms, the statistics now and the
   // target by zero_if_far_kernel once they say it will be used at all
-  const bool lazy_zero = gathered && (nx * 4) % 16 == 0;
+  const int tiles_h = (H + DT_H - 1) / DT_H, tiles_w = (W + DT_W - 1) / DT_W;
+  const long tile_blocks = (long)N * tiles_h * tiles_w * deformable_group;
+  // both gather windows as the tile kernels (dilation 1); other dilations keep the item / wave-per-pixel kernels (which read the side buffer always)
+  const bool tiled = gathered && dilation == 1 && g.pad_t == 1 && g.pad_l == 1 && tile_blocks < (1l << 31) && !danhip_option("deform_dx_untiled");
+  const bool lazy_zero = tiled && (nx * 4) % 16 == 0;
   { const int zrc = lazy_zero ? danhip_zero_async(stat, sizeof(unsigned) * 64, s) : danhip_zero_async(workspace, sizeof(float) * (nx + 64), s); if (zrc) return zrc; }
   if (gathered) {
     const long nd = (long)N * g.Ho * g.Wo * deformable_group, ng = (long)N * H * W * deformable_group;
@@ -898,21 +921,17 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
     hipLaunchKernelGGL(deform_far_stat_kernel, dim3(grid_for(pairs, 256, 1024)), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets), pairs, stat);
     if (lazy_zero)
       hipLaunchKernelGGL(zero_if_far_kernel, dim3(grid_for(nx / 4, 256, 2048)), dim3(256), 0, s, reinterpret_cast<uint4*>(workspace), nx / 4, stat, gate.force);
-    // the +-1 window as the tile kernel (dilation 1, 32-bit dS row indices); the wave-per-pixel kernel keeps the +-2 window on a grid that
-    // costs ~10 us to retire when it is not its turn (grid-stride loop: 8 resident blocks per CU x 2)
-    const int tiles_h = (H + DT_H - 1) / DT_H, tiles_w = (W + DT_W - 1) / DT_W;
-    const long tile_blocks = (long)N * tiles_h * tiles_w * deformable_group;
-    const int tiled0 = dilation == 1 && g.pad_t == 1 && g.pad_l == 1 && tile_blocks < (1l << 31) && !danhip_option("deform_dx_untiled") ? 1 : 0;
-    const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, tiled0 ? 4096 : 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, tiled0 ? 4096 : 65536));
-    hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate, tiled0);
-    if (tiled0)
+    if (tiled) {
       hipLaunchKernelGGL(deform_bwd_doff_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x),
                          reinterpret_cast<const bf16_t*>(offsets), reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(d_offsets), g, gate,
                          tiles_h, tiles_w);
-    if (tiled0)
       hipLaunchKernelGGL(deform_bwd_dx_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets),
                          reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(dx), g, accumulate, gate, rx, tiles_h, tiles_w);
-    hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate, rx, tiled0);
+    } else {
+      const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, 65536));
+      hipLaunchKernelGGL(deform_bwd_doff9_c64_kernel, gd, dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g, gate);
+      hipLaunchKernelGGL(deform_bwd_dx_gather9_c64_kernel, gg, dim3(256), 0, s, offsets, dS, workspace, dx, g, accumulate, gate, rx);
+    }
     // the scatter form's two kernels on small grids (grid-stride loops): empty ~10 us each when a gather form runs
     const long nwork = (long)N * g.Ho * g.Wo * kh * kw * deformable_group;
     hipLaunchKernelGGL(deform_sample_bwd_c64_kernel, dim3(grid_for((nwork + 3) / 4 * 256, 256, 2048)), dim3(256), 0, s, x, offsets, dS, workspace, d_offsets, g,
