@@ -134,12 +134,15 @@ __global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const Fused
       if (w_low >= cur_w - 1) { w_high = w_low = cur_w - 1; mw = (float)w_low; } else w_high = w_low + 1;
       const float lh = mh - h_low, lw = mw - w_low, hh = 1 - lh, hw = 1 - lw;
       g.wq[u][0] = hh * hw; g.wq[u][1] = hh * lw; g.wq[u][2] = lh * hw; g.wq[u][3] = lh * lw;          // :118-125
+      // (24-bit multiplies: rows, pixels of one image and C are all below 2^24 and an image below 2^32 elements — the launcher checks;
+      // the 64-bit forms cost three quarter-rate v_mul_lo_u32 / v_mad_u64_u32 per corner in a loop that is VALU-bound)
       const bf16_t* base = xq2[u] + grp * 64;
-      const int rl = (h_in + h_low) * a.W + w_in, rh = (h_in + h_high) * a.W + w_in;
-      g.cn[u][0] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_low) * a.C);
-      g.cn[u][1] = *reinterpret_cast<const uint4*>(base + (long)(rl + w_high) * a.C);
-      g.cn[u][2] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_low) * a.C);
-      g.cn[u][3] = *reinterpret_cast<const uint4*>(base + (long)(rh + w_high) * a.C);
+      const unsigned rl = __umul24((unsigned)(h_in + h_low), (unsigned)a.W) + (unsigned)w_in;
+      const unsigned rh = __umul24((unsigned)(h_in + h_high), (unsigned)a.W) + (unsigned)w_in;
+      g.cn[u][0] = *reinterpret_cast<const uint4*>(base + __umul24(rl + (unsigned)w_low, (unsigned)a.C));
+      g.cn[u][1] = *reinterpret_cast<const uint4*>(base + __umul24(rl + (unsigned)w_high, (unsigned)a.C));
+      g.cn[u][2] = *reinterpret_cast<const uint4*>(base + __umul24(rh + (unsigned)w_low, (unsigned)a.C));
+      g.cn[u][3] = *reinterpret_cast<const uint4*>(base + __umul24(rh + (unsigned)w_high, (unsigned)a.C));
     }
   };
   uint4 pend[2];
@@ -221,6 +224,8 @@ __global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const Fused
       for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(wf[s2][c], xf[s2][p], acc[c][p]);
+    // (tried, round 5: the blend issued BETWEEN this step's MFMAs by sched_group_barrier — one MFMA, four VALU — instead of behind them:
+    // 1.02 -> 1.16 ms without, 1.22 -> 1.45 ms with the column buffer; the second resident workgroup already fills the other pipe)
     __builtin_amdgcn_sched_barrier(0);
     if (more) blend_store(nxt, ks + 1, st ^ 1);
     if (!more2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -279,7 +284,7 @@ bool danhip_deform_fused_eligible(int N, int H, int W, int C, int Cout, int kh, 
   if (!(kh == 3 && kw == 3 && dg > 0 && C % dg == 0 && C / dg == 64)) return false;
   if (Cout % 64 != 0 || Cout > 256 || Cout == 192) return false;         // one N tile = the whole Cout (64 / 128 / 256)
   const long Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  return (long)N * Ho * Wo * 9 * C < (1l << 40) && (long)N * H * W * C < (1l << 31);
+  return (long)N * Ho * Wo * 9 * C < (1l << 40) && (long)N * H * W * C < (1l << 31) && (long)H * W < (1l << 24) && C < (1 << 24);
 }
 
 // Returns DANHIP_OK when launched.  `col` may be NULL (no column buffer is written).
