@@ -9,6 +9,7 @@ has been produced so it overlaps the remaining backward kernels); the update is 
 import atexit
 import ctypes
 import os
+import sys
 import weakref
 
 import torch
@@ -52,6 +53,48 @@ class RcclComm(object):
             world = dist.get_world_size() if dist.is_initialized() else 1
             cls._shared = cls(rank, world, device.index if device.index is not None else torch.cuda.current_device())
         return cls._shared
+
+    @classmethod
+    def shared_or_none(cls, device):
+        """The shared communicator, or None on EVERY rank when it could not be built on any of them (librccl missing from the process,
+        communicator initialisation refused): the caller then keeps the gradients on the process group's host-staged collectives — slow,
+        but a multi-GPU job still runs and says so (`transport`).  The ranks agree through the control plane after each local step that
+        can fail, so none of them waits in a collective the others never enter.  DANHIP_DP_NO_FALLBACK=1: raise instead."""
+        if cls._shared is not None and cls._shared.handle is not None:
+            return cls._shared
+        multi = dist.is_initialized() and dist.get_world_size() > 1
+        strict = os.environ.get("DANHIP_DP_NO_FALLBACK", "0") == "1"
+
+        def everyone(ok):
+            if not multi:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        err = None
+        try:                                         # (1) the library is loadable here (a local step: no rank waits on another)
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            call("danhip_comm_load", cand.encode() if os.path.exists(cand) else None)
+        except Exception as e:                       # noqa: BLE001 - reported below
+            err = e
+        if not everyone(err is None):
+            if strict and err is not None:
+                raise err
+            sys.stderr.write("dan_amd: RCCL is not loadable on every rank (%s): gradients travel on the process group (gloo)\n" % (err,))
+            return None
+        try:                                         # (2) the communicator itself (collective inside RCCL)
+            comm = cls.shared(device)
+        except Exception as e:                       # noqa: BLE001
+            err, comm = e, None
+        if not everyone(comm is not None):
+            if comm is not None:
+                comm.close()
+            if strict and err is not None:
+                raise err
+            sys.stderr.write("dan_amd: no RCCL communicator on every rank (%s): gradients travel on the process group (gloo)\n" % (err,))
+            return None
+        return comm
 
     @staticmethod
     def _dtype(t):
@@ -335,7 +378,11 @@ class GradBuckets(object):
         # group's host-staged collectives instead (the test hook that runs several ranks on ONE GPU: RCCL refuses duplicate devices).
         # Device-side collectives coexist with the weight-gradient stream; gloo's host-staged ones stalled with it.
         self.transport = dp_transport() if (self.enabled and not self.fake and self.on_gpu) else ("fake" if self.fake else "gloo")
-        self.rccl = RcclComm.shared(flat.g.device) if self.transport == "rccl" else None
+        self.rccl = RcclComm.shared_or_none(flat.g.device) if self.transport == "rccl" else None
+        if self.transport == "rccl" and self.rccl is None:
+            self.transport = "gloo"                  # (agreed by all ranks inside shared_or_none; a one-rank forced job has no group: stays local)
+            if not (dist.is_initialized() and dist.get_world_size() > 1):
+                raise RuntimeError("RCCL communicator unavailable and no process group to fall back to (DANHIP_FORCE_DIST on one rank)")
         self.device_collectives = self.enabled and (self.fake or self.rccl is not None)
         self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None     # (enable_local creates it for one-GPU runs)
         self.pending = []

@@ -512,3 +512,48 @@ def test_gradient_buckets_split_a_small_tail_off_the_last_bucket():
     g = Flat()
     g.starts, g.total, g.names, g.g = [0, 64000], 128000, ["a", "b"], torch.zeros(8)
     assert GradBuckets(g, bucket_bytes=32 << 20, tail_bytes=2 << 20).bounds == [(0, 128000)]
+
+
+FALLBACK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from dan_amd import trainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+# rank 1 cannot load RCCL (simulated); rank 0 could: BOTH must come back with None, neither may wait in a collective the other skipped
+real = trainer.call
+def fake(name, *a):
+    if name == "danhip_comm_load" and rank == 1:
+        raise RuntimeError("librccl.so: cannot open shared object file (simulated)")
+    if name == "danhip_comm_create":
+        raise AssertionError("no rank may try to build the communicator after one of them failed to load the library")
+    return real(name, *a)
+trainer.call = fake
+got = trainer.RcclComm.shared_or_none(torch.device("cpu"))
+assert got is None, got
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_every_rank_falls_back_to_the_process_group_when_one_cannot_have_rccl(tmp_path):
+    """A multi-GPU job whose RCCL communicator cannot be built on some rank keeps running on the control plane's collectives (and says so
+    on stderr) instead of hanging or dying: the decision is taken by all ranks together (dan_amd.trainer.RcclComm.shared_or_none)."""
+    script = tmp_path / "f.py"
+    script.write_text(FALLBACK_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("gradients travel on the process group" in o for o in outs), outs
+
+
+def test_one_rank_without_rccl_is_an_error_not_a_silent_fallback(monkeypatch):
+    import torch
+    from dan_amd import trainer
+    monkeypatch.setattr(trainer.RcclComm, "_shared", None)
+    assert trainer.RcclComm.shared_or_none(torch.device("cpu")) is None            # no GPU here: the communicator cannot exist
+    monkeypatch.setenv("DANHIP_DP_NO_FALLBACK", "1")
+    with pytest.raises(Exception):
+        trainer.RcclComm.shared_or_none(torch.device("cpu"))
