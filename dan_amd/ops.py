@@ -15,6 +15,71 @@ from . import _lib
 from ._lib import ACT_DTYPE as ACT, BF16, F32, ConvDesc, call, ptr, stream
 
 
+class OpsContext(object):
+    """Everything mutable that STEERS the ops of this module, in one object (SURVEY 8b "no mutable globals on the data path"; VERDICT r4
+    item 9): which kernel form an op launches, where it reports, and the per-step hooks a trainer arms.  Rounds 1-4 kept these as module
+    attributes (`ops.USE_SLOTS = False` ...); those names still read and write through to the ACTIVE context (module __getattr__ /
+    __setattr__ at the end of the file), so tests and A/B scripts are unchanged, but a caller can now hold its own:
+
+        ctx = ops.OpsContext(USE_SPLITK=False)
+        with ops.use_context(ctx): ...            # every op issued inside (and the backward of those ops, if run inside) sees ctx
+
+    A DetectorTrainer keeps the context it was built under (`trainer.ops_ctx`) and runs its steps inside it.  The active context is
+    process-wide, not thread-local: autograd runs backward functions on its own threads, and the deployment model is one process per GPU.
+    What is NOT in here are caches (packed weights and their version stamp WEIGHT_EPOCH, scratch sizes): derived data, not steering.
+
+    Kernel-form switches (results agree up to fp32 summation order whatever they say):
+      USE_SPLITK       False: never pass the split-K scratch buffer (every shape on its single-pass kernel)
+      USE_SLOTS        False: activation gradients travel through autograd's own edges instead of the direct hand-off (GradSlot)
+      USE_RELU_BITS    [DANHIP_RELU_BITS, 1]  0: ReLU masks read as 16-bit activations instead of bit masks
+      USE_POOL_ARG     [DANHIP_POOL_ARG, 1]   0: max-pool backward re-reads the activation instead of the 2-bit arg-max codes
+      POOL_ONLY_TRAIN  [DANHIP_POOL_ONLY_TRAIN, 1]  0: the training forward of a conv whose only consumer is a fused pool still writes its map
+      KEEP_DEFORM_COL  False: the deformable backward re-samples the im2col buffer as the reference does instead of keeping the forward's
+      WGRAD_STREAM     [DANHIP_WGRAD_STREAM, 1]  0: weight gradients on the data gradients' stream
+    Diagnostic sinks (None = off): TRACE (tests: activations / decisions by variable id), PROFILE / PROFILE_BYTES (bench.py: HIP events
+    and algorithmic bytes per convolution launch).
+    Per-step state a trainer arms: GRAD_READY_HOOK (a parameter's gradient is final), LOSS_SCALE_DEV (device scalar of the dynamic loss
+    scale), wgrad (the second backward stream: {"on", "side", "main", "keep"})."""
+    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "TRACE", "PROFILE",
+                 "PROFILE_BYTES", "GRAD_READY_HOOK", "LOSS_SCALE_DEV", "wgrad")
+
+    def __init__(self, **overrides):
+        env = os.environ.get
+        self.USE_SPLITK = True
+        self.USE_SLOTS = True
+        self.USE_RELU_BITS = env("DANHIP_RELU_BITS", "1") == "1"
+        self.USE_POOL_ARG = env("DANHIP_POOL_ARG", "1") == "1"
+        self.POOL_ONLY_TRAIN = env("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
+        self.KEEP_DEFORM_COL = True
+        self.WGRAD_STREAM = env("DANHIP_WGRAD_STREAM", "1") == "1"
+        self.TRACE = self.PROFILE = self.PROFILE_BYTES = None
+        self.GRAD_READY_HOOK = self.LOSS_SCALE_DEV = None
+        self.wgrad = {"on": False, "side": None, "main": None, "keep": []}
+        for k, v in overrides.items():
+            setattr(self, k, v)                       # (AttributeError for a name that is not a field)
+
+
+_CTX = OpsContext()                                   # the active context (rebound by use_context only)
+_CTX_FIELDS = frozenset(OpsContext.__slots__) - {"wgrad"}
+
+
+def context():
+    """The active OpsContext."""
+    return _CTX
+
+
+@contextlib.contextmanager
+def use_context(ctx):
+    """Make `ctx` the active context for the duration of the block (process-wide: see OpsContext)."""
+    global _CTX
+    prev, _CTX = _CTX, ctx
+    try:
+        yield ctx
+    finally:
+        _CTX = prev
+
+
+
 def _desc(N, H, W, Cin, Cout, kh, kw, stride, valid=False):
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride = N, H, W, Cin, Cout, kh, kw, stride
@@ -143,12 +208,12 @@ def _sink_trainable(t):
 
 # Optional per-kernel timing (bench.py): when PROFILE is a dict, every conv forward / stride-1 data-gradient launch is
 # bracketed by events on the launch stream and recorded under its kernel-instance label with its algorithmic FLOPs.
-PROFILE = None
-PROFILE_BYTES = None        # {label: [algorithmic bytes per launch]} beside PROFILE (bench.py: GB/s of the HBM-bound convolutions)
+# (PROFILE: a field of OpsContext, see the top of the module)
+# (PROFILE_BYTES: a field of OpsContext, see the top of the module)
 
 
 def _prof_begin(st=None):
-    if PROFILE is None:
+    if _CTX.PROFILE is None:
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record(st if st is not None else torch.cuda.current_stream())
@@ -166,11 +231,11 @@ def _prof_end(e0, d, which, st=None):
         label = _lib.lib().danhip_conv_kernel_label(ctypes.byref(d), which).decode()
     cin = d.Cin                              # MACs are the same for fwd and dgrad: Ho*Wo*Cin*Cout*kh*kw per image
     flops = 2.0 * d.N * d.Ho * d.Wo * cin * d.Cout * d.kh * d.kw
-    PROFILE.setdefault(label, []).append((e0, e1, flops))
-    if PROFILE_BYTES is not None:            # algorithmic HBM bytes: activations in + out (16-bit; the heads write fp32), weights once
+    _CTX.PROFILE.setdefault(label, []).append((e0, e1, flops))
+    if _CTX.PROFILE_BYTES is not None:            # algorithmic HBM bytes: activations in + out (16-bit; the heads write fp32), weights once
         co8 = (d.Cout + 7) // 8 * 8
         nbytes = 2.0 * d.N * (d.H * d.W * cin + d.Ho * d.Wo * co8) + 2.0 * d.kh * d.kw * cin * d.Cout
-        PROFILE_BYTES.setdefault(label, []).append(nbytes)
+        _CTX.PROFILE_BYTES.setdefault(label, []).append(nbytes)
 
 
 # ---- weight gradients on a second stream.  dgrad(L) and wgrad(L) both consume dY_L and are independent of each other; on one stream
@@ -178,39 +243,39 @@ def _prof_end(e0, d, which, st=None):
 # (tools/probe_concurrent_bwd.py: conv4_2 0.95 -> 0.84 ms, conv5_1 0.37 -> 0.31, fc6 0.25 -> 0.18 for the pair).  The trainer switches
 # this on around its backward pass and joins before the gradients are consumed; tensors the side stream still reads are kept alive
 # until that join (no allocator reuse while in flight, also valid inside a hipGraph capture).
-_WGRAD = {"on": False, "side": None, "main": None, "keep": []}
+# (_WGRAD: a field of OpsContext, see the top of the module)
 # read ONCE at import (DANHIP_WGRAD_STREAM=0: A/B on one stream); a process that wants to switch mid-run (bench.py's serialized
 # roofline leg, tests) assigns ops.WGRAD_STREAM - the environment is never re-read or written
-WGRAD_STREAM = os.environ.get("DANHIP_WGRAD_STREAM", "1") == "1"
+# (WGRAD_STREAM: a field of OpsContext, see the top of the module)
 
 
 def wgrad_overlap_begin():
     if not torch.cuda.is_available():
         return
-    if not WGRAD_STREAM:
+    if not _CTX.WGRAD_STREAM:
         return
-    if _WGRAD["side"] is None:
-        _WGRAD["side"] = torch.cuda.Stream()
-    _WGRAD["main"] = torch.cuda.current_stream()
-    _WGRAD["on"] = True
+    if _CTX.wgrad["side"] is None:
+        _CTX.wgrad["side"] = torch.cuda.Stream()
+    _CTX.wgrad["main"] = torch.cuda.current_stream()
+    _CTX.wgrad["on"] = True
 
 
 def wgrad_overlap_join():
     """The launching stream waits for every weight gradient issued on the side stream; releases the kept tensors."""
-    if _WGRAD["on"]:
-        torch.cuda.current_stream().wait_stream(_WGRAD["side"])
-    _WGRAD["on"] = False
-    _WGRAD["keep"].clear()
+    if _CTX.wgrad["on"]:
+        torch.cuda.current_stream().wait_stream(_CTX.wgrad["side"])
+    _CTX.wgrad["on"] = False
+    _CTX.wgrad["keep"].clear()
 
 
 def wgrad_streams():
     """Streams gradient producers may be running on (the data-parallel buckets wait for all of them)."""
-    return [_WGRAD["main"], _WGRAD["side"]] if _WGRAD["on"] else []
+    return [_CTX.wgrad["main"], _CTX.wgrad["side"]] if _CTX.wgrad["on"] else []
 
 
 # Optional callback(param) invoked right after a layer's weight/bias gradients have been produced in backward
 # (the data-parallel trainer uses it to launch the bucketed gradient all-reduce while backward continues).
-GRAD_READY_HOOK = None
+# (GRAD_READY_HOOK: a field of OpsContext, see the top of the module)
 
 
 
@@ -248,15 +313,15 @@ class GradSlot(object):
 
 # USE_SLOTS = False (tests): every activation gradient travels through autograd's own edges instead of the direct hand-off, which gives
 # the parity tests a second, independent route through the same kernels (tests/test_grad_parity_gpu.py)
-USE_SLOTS = True
+# (USE_SLOTS: a field of OpsContext, see the top of the module)
 
 
 def _slot_of(t):
-    return getattr(t, "_dh_slot", None) if USE_SLOTS else None
+    return getattr(t, "_dh_slot", None) if _CTX.USE_SLOTS else None
 
 
 def _new_slot(track):
-    return GradSlot.__new__(GradSlot) if (track and USE_SLOTS) else None
+    return GradSlot.__new__(GradSlot) if (track and _CTX.USE_SLOTS) else None
 
 
 def _attach_slot(t, is_relu):
@@ -267,7 +332,7 @@ def _attach_slot(t, is_relu):
 
 # ReLU masks as bits for the data-gradient kernels that stage them in LDS (danhip_relu_bits).  One activation may feed several convolutions:
 # every consumer's forward shares ONE holder hung on the activation tensor, the first backward that needs the bits fills it.
-USE_RELU_BITS = os.environ.get("DANHIP_RELU_BITS", "1") == "1"        # (0: A/B against the 16-bit mask reads)
+# (USE_RELU_BITS: a field of OpsContext, see the top of the module)
 
 
 def _bits_holder(x):
@@ -290,16 +355,16 @@ def relu_bits(x, holder):
 
 # TRACE (tests): when a dict, every ReLU layer records its output under id(weight variable) and every 2x2 max-pool its input under
 # "pools" (call order) — the discrete decisions of this forward pass, which the gradient-parity tests impose on the oracle graph
-TRACE = None
+# (TRACE: a field of OpsContext, see the top of the module)
 
-USE_SPLITK = True           # False (tests): never pass the scratch buffer, i.e. every shape runs on its single-pass kernel
+# (USE_SPLITK: a field of OpsContext, see the top of the module)
 
 
 def _conv_scratch(d, which, dev):
     """Scratch buffer for a split-K launch of this forward (which = 0) / data-gradient (which = 1) call, or (None, 0): maps with too few
     output tiles to fill the chip (danhip_conv2d_workspace_bytes).  Only small problems are worth asking the library about."""
     M, co = (d.N * d.Ho * d.Wo, d.Cout) if which == 0 else (d.N * d.H * d.W, d.Cin)
-    if not USE_SPLITK or -(-M // 128) * -(-co // 128) > 160:
+    if not _CTX.USE_SPLITK or -(-M // 128) * -(-co // 128) > 160:
         return None, 0
     key = (which, d.N, d.H, d.W, d.Cin, d.Cout, d.kh, d.kw, d.stride, d.Ho)
     n = _SCRATCH_BYTES.get(key)
@@ -322,15 +387,15 @@ def _wgrad_scratch(d, dev):
 # USE_POOL_ARG (round 4): the 2 x 2 max-pool keeps 2-bit arg-max codes from its forward pass (written by the pooling conv epilogues / the pool
 # kernel) and its backward scatters the pooled gradient through them instead of re-reading the full-resolution activation to find each
 # window's maximum (danhip_maxpool2x2_bwd_arg: 1.28 instead of 2.25 map-sized HBM passes).  DANHIP_POOL_ARG=0: the round-3 form (A/B).
-USE_POOL_ARG = os.environ.get("DANHIP_POOL_ARG", "1") == "1"
+# (USE_POOL_ARG: a field of OpsContext, see the top of the module)
 
 
 # DANHIP_POOL_ONLY_TRAIN=0: conv1_2 / conv2_2 write their full-resolution outputs in training too (A/B; round 4's behaviour)
-POOL_ONLY_TRAIN = os.environ.get("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
+# (POOL_ONLY_TRAIN: a field of OpsContext, see the top of the module)
 
 
 def _pool_arg_buffer(pooled, need_bwd):
-    if not (USE_POOL_ARG and need_bwd):
+    if not (_CTX.USE_POOL_ARG and need_bwd):
         return None
     c = pooled.shape[-1]
     return torch.empty((pooled.numel() // c, c // 4), dtype=torch.uint8, device=pooled.device)
@@ -361,7 +426,7 @@ class _Conv2d(torch.autograd.Function):
         # codes and the pooled map's sign (the gradient arrives already masked in the slot) - the kernel gets y = NULL and skips the
         # full-resolution stores (conv1_2: 839 MB, conv2_2: 419 MB per batch of 16 at 640 x 640).  The tensor autograd sees is a
         # zero-stride view of one element: any op that tried to READ it fails ptr()'s contiguity assertion instead of reading garbage.
-        skip_y = (pool_only == 2 and pool_out is not None and USE_POOL_ARG and need_bwd and b is not None
+        skip_y = (pool_only == 2 and pool_out is not None and _CTX.USE_POOL_ARG and need_bwd and b is not None
                   and bool(_lib.lib().danhip_conv2d_fwd_pool_only(ctypes.byref(d)))
                   and _conv_scratch(d, 0, x.device)[1] == 0)          # (a map small enough to split K runs the pool as its own kernel)
         if skip_y:
@@ -484,8 +549,8 @@ class _Conv2d(torch.autograd.Function):
             dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
             # split partial sums as plain stores into a scratch slab + a combine pass, where the library's kernel for this shape offers it
             ws, nws = _wgrad_scratch(d, g.device)
-            if _WGRAD["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
-                side = _WGRAD["side"]
+            if _CTX.wgrad["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
+                side = _CTX.wgrad["side"]
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 side.wait_event(ev)
@@ -493,9 +558,9 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
                      ptr(ws), nws, ctypes.c_void_p(side.cuda_stream))
                 _prof_end(e0, d, 2, side)
-                if GRAD_READY_HOOK is not None and wp is not None:
-                    GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
-                _WGRAD["keep"].append((g, x, ws))
+                if _CTX.GRAD_READY_HOOK is not None and wp is not None:
+                    _CTX.GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
+                _CTX.wgrad["keep"].append((g, x, ws))
                 hooked = True
             else:
                 e0 = _prof_begin()
@@ -506,8 +571,8 @@ class _Conv2d(torch.autograd.Function):
                 dw = None
         if db_sink is not None:
             db = None
-        if GRAD_READY_HOOK is not None and wp is not None and not hooked:
-            GRAD_READY_HOOK(wp)
+        if _CTX.GRAD_READY_HOOK is not None and wp is not None and not hooked:
+            _CTX.GRAD_READY_HOOK(wp)
         return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -552,17 +617,17 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     if torch.is_grad_enabled():
         blk = (1 if _sink_trainable(w) else 0) | (2 if (b is not None and _sink_trainable(b)) else 0)
     xs = _slot_of(x) if track else None
-    xbits = _bits_holder(x) if (xs is not None and xs.is_relu and USE_RELU_BITS) else None
-    bits_out = [] if (track and relu and USE_RELU_BITS) else None
+    xbits = _bits_holder(x) if (xs is not None and xs.is_relu and _CTX.USE_RELU_BITS) else None
+    bits_out = [] if (track and relu and _CTX.USE_RELU_BITS) else None
     # pool_only: 1 = nothing tracked, the pooled map is returned; 2 = training with the direct gradient hand-off: y is declared but never written
     # (POOL_ONLY_TRAIN; off while a test records activations through TRACE)
-    po = (1 if not track else (2 if (POOL_ONLY_TRAIN and TRACE is None and USE_SLOTS and yslot is not None) else 0)) if pool_only else 0
+    po = (1 if not track else (2 if (_CTX.POOL_ONLY_TRAIN and _CTX.TRACE is None and _CTX.USE_SLOTS and yslot is not None) else 0)) if pool_only else 0
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out,
                       po, bool(track))
     if getattr(y, "_dh_already_pooled", False):
         return y
-    if TRACE is not None and relu and wp is not None:
-        TRACE[id(wp)] = y.detach()
+    if _CTX.TRACE is not None and relu and wp is not None:
+        _CTX.TRACE[id(wp)] = y.detach()
     if bits_out:                                         # the forward kernel wrote the masks: the holders of y (and its pooled map) start filled
         y._dh_bits = [bits_out[0]]
     if yslot is not None:
@@ -641,8 +706,8 @@ def max_pool_2x2(x):
         y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
         call("danhip_maxpool2x2_fwd_f32", ptr(x.contiguous()), ptr(y), N, H, W, C, stream())
         return y
-    if TRACE is not None:
-        TRACE.setdefault("pools", []).append(x.detach())
+    if _CTX.TRACE is not None:
+        _CTX.TRACE.setdefault("pools", []).append(x.detach())
     track = torch.is_grad_enabled() and x.requires_grad
     xs = _slot_of(x) if track else None
     yslot = _new_slot(track)
@@ -761,7 +826,7 @@ def head_split(h, loc, cls, nneg, npos, off):
 
 
 # 1-element device tensor holding the current dynamic loss scale (set by the trainer around its backward pass), or None
-LOSS_SCALE_DEV = None
+# (LOSS_SCALE_DEV: a field of OpsContext, see the top of the module)
 
 
 class _DetectionLoss(torch.autograd.Function):
@@ -786,8 +851,8 @@ class _DetectionLoss(torch.autograd.Function):
         acc = torch.empty((4,), dtype=torch.float32, device=dev)
         call("danhip_hard_neg_select", ptr(cls), ptr(labels), ptr(score), ptr(counts), ptr(thr), ptr(k), B, A, float(ratio), int(at_least_one), stream())
         call("danhip_detection_loss_fwd", ptr(cls), ptr(loc), ptr(labels), ptr(loc_t), ptr(score), ptr(thr), ptr(sel), ptr(acc), B, A, stream())
-        if TRACE is not None:                           # tests: the hard-negative selection of this term (call order), imposed on the oracle's loss
-            TRACE.setdefault("loss_sel", []).append(sel)
+        if _CTX.TRACE is not None:                           # tests: the hard-negative selection of this term (call order), imposed on the oracle's loss
+            _CTX.TRACE.setdefault("loss_sel", []).append(sel)
         ctx.save_for_backward(cls, loc, loc_t, sel, acc)
         ctx.cfg = (ratio, scale)
         ctx.aux = (score, thr, k, counts)
@@ -802,9 +867,9 @@ class _DetectionLoss(torch.autograd.Function):
         dloc = torch.empty_like(loc)
         call("danhip_detection_loss_bwd", ptr(cls), ptr(loc), ptr(loc_t), ptr(sel), ptr(acc), ptr(dcls), ptr(dloc), float((ratio + 1.0) * scale),
              float(scale), B, A, stream())
-        if LOSS_SCALE_DEV is not None:                  # dynamic loss scale (fp16 build): a device scalar, so the step stays capturable
-            dcls.mul_(LOSS_SCALE_DEV)
-            dloc.mul_(LOSS_SCALE_DEV)
+        if _CTX.LOSS_SCALE_DEV is not None:                  # dynamic loss scale (fp16 build): a device scalar, so the step stays capturable
+            dcls.mul_(_CTX.LOSS_SCALE_DEV)
+            dloc.mul_(_CTX.LOSS_SCALE_DEV)
         return dcls, dloc, None, None, None, None, None
 
 
@@ -974,7 +1039,7 @@ def concat(tensors):
     """Channel concatenation of NHWC activations."""
     tensors = list(tensors)
     track = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
-    if tensors[0].dtype != ACT or not track or not USE_SLOTS:
+    if tensors[0].dtype != ACT or not track or not _CTX.USE_SLOTS:
         return torch.cat(tensors, dim=-1)
     slots = [(getattr(t, "_dh_slot", None) or getattr(t, "_dh_pslot", None)) if t.requires_grad else None for t in tensors]
     all_relu = all(s is not None and s.is_relu for s in slots)
@@ -1036,7 +1101,7 @@ class _Add(torch.autograd.Function):
 
 def add(a, b):
     track = torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)
-    if a.dtype != ACT or not track or not USE_SLOTS or a.shape != b.shape or a.shape[-1] % 8:
+    if a.dtype != ACT or not track or not _CTX.USE_SLOTS or a.shape != b.shape or a.shape[-1] % 8:
         return a + b
     yslot = _new_slot(True)
     y = _Add.apply(a, b, _slot_of(a) if a.requires_grad else None, _slot_of(b) if b.requires_grad else None, yslot)
@@ -1060,8 +1125,8 @@ def _wgrad_launch(d, xv, dyv, dw, db, cin_real, keep):
     trainer has it on (same ordering rules as _Conv2d.backward)."""
     pitch = _lib.ConvPitch(xv.stride(2), dyv.stride(2), 0)
     ws, nws = _wgrad_scratch(d, dyv.device)
-    if _WGRAD["on"]:
-        side = _WGRAD["side"]
+    if _CTX.wgrad["on"]:
+        side = _CTX.wgrad["side"]
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         side.wait_event(ev)
@@ -1069,7 +1134,7 @@ def _wgrad_launch(d, xv, dyv, dw, db, cin_real, keep):
         call("danhip_conv2d_bwd_weight_strided", ctypes.byref(d), _vptr(xv), _vptr(dyv), ptr(dw), ptr(db), cin_real, ctypes.byref(pitch), ptr(ws), nws,
              ctypes.c_void_p(side.cuda_stream))
         _prof_end(e0, d, 2, side)
-        _WGRAD["keep"].append((xv, dyv, ws) + tuple(keep))
+        _CTX.wgrad["keep"].append((xv, dyv, ws) + tuple(keep))
     else:
         e0 = _prof_begin()
         call("danhip_conv2d_bwd_weight_strided", ctypes.byref(d), _vptr(xv), _vptr(dyv), ptr(dw), ptr(db), cin_real, ctypes.byref(pitch), ptr(ws), nws, stream())
@@ -1139,7 +1204,7 @@ class _ContextBlock(torch.autograd.Function):
         ctx.cin_real = [w.shape[2] for w, _ in pairs]
         ctx.couts = [w.shape[3] for w, _ in pairs]
         ctx.khw = [(w.shape[0], w.shape[1]) for w, _ in pairs]
-        if TRACE is not None:                           # the block's ten ReLU decisions (tests): context_block() files them under their kernel variables
+        if _CTX.TRACE is not None:                           # the block's ten ReLU decisions (tests): context_block() files them under their kernel variables
             _CB_LAST.clear()
             _CB_LAST.update({"b1": hyper[..., 0:64], "b2": hyper[..., 64:128], "b3": T[..., 0:64], "b3a": hyper[..., 128:160], "b3b": hyper[..., 160:192],
                              "b4": T[..., 64:128], "b43": U, "b4a": hyper[..., 192:224], "b4b": hyper[..., 224:256], "res": r})
@@ -1224,9 +1289,9 @@ class _ContextBlock(torch.autograd.Function):
         if need_dx:
             dgrad(0, dhyper[..., 0:64], xmask, xbuf, 1)
         wgrad(0, x, dhyper[..., 0:64])
-        if GRAD_READY_HOOK is not None:
+        if _CTX.GRAD_READY_HOOK is not None:
             for p_ in ctx.hook_order:                            # all of the block's gradients are issued: declare them in reverse creation order
-                GRAD_READY_HOOK(p_)
+                _CTX.GRAD_READY_HOOK(p_)
         return (dx_ret, None, None, None, None) + tuple(grads)
 
 
@@ -1246,9 +1311,9 @@ def context_block(x, params, hook_order, trace_params=None):
         flat += [w, b]
     yslot = _new_slot(track)
     out = _ContextBlock.apply(x, _slot_of(x) if (track and x.requires_grad) else None, yslot, handles, hook_order, *flat)
-    if TRACE is not None and trace_params:
+    if _CTX.TRACE is not None and trace_params:
         for k, prm in trace_params.items():
-            TRACE[id(prm)] = _CB_LAST[k].detach().contiguous()
+            _CTX.TRACE[id(prm)] = _CB_LAST[k].detach().contiguous()
         _CB_LAST.clear()
     if yslot is not None:
         yslot.__init__(out, False)
@@ -1345,14 +1410,14 @@ class _ConcatMix(torch.autograd.Function):
             _wgrad_launch(_desc(N, H, W, C1, Co, 1, 1, 1), a, g, dw[:, :, :C1, :], db, C1, (g,))
             _wgrad_launch(_desc(N, H, W, C2, Co, 1, 1, 1), f, g, dw[:, :, C1:, :], None, C2, (g,))
             if c1 is not None:
-                side = _WGRAD["side"] if _WGRAD["on"] else None
+                side = _CTX.wgrad["side"] if _CTX.wgrad["on"] else None
                 with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
                     dw[:, :, :c1, o1:].zero_()
                     dw[:, :, c1:, :o1].zero_()
         elif need_db:
             raise NotImplementedError("a trainable bias without its kernel (no reference graph has one)")
-        if GRAD_READY_HOOK is not None and wvp is not None:
-            GRAD_READY_HOOK(wvp)
+        if _CTX.GRAD_READY_HOOK is not None and wvp is not None:
+            _CTX.GRAD_READY_HOOK(wvp)
         return None, df, None, None, None, None, dwv, dbv
 
 
@@ -1367,9 +1432,9 @@ def concat_conv1x1_relu(a, f, wv, bv, split=None, trace_params=None):
     yslot = _new_slot(track)
     out = _ConcatMix.apply(a.detach(), f, _slot_of(f) if (track and f.requires_grad) else None, yslot, (wvp, bvp, lowp),
                            split if split is not None else (None, None), wv, bv)
-    if TRACE is not None and trace_params is not None and split is not None:
-        TRACE[id(trace_params[0])] = out.detach()[..., :split[1]].contiguous()
-        TRACE[id(trace_params[1])] = out.detach()[..., split[1]:].contiguous()
+    if _CTX.TRACE is not None and trace_params is not None and split is not None:
+        _CTX.TRACE[id(trace_params[0])] = out.detach()[..., :split[1]].contiguous()
+        _CTX.TRACE[id(trace_params[1])] = out.detach()[..., split[1]:].contiguous()
     if yslot is not None:
         yslot.__init__(out, True)
         out._dh_slot = yslot
@@ -1450,7 +1515,7 @@ class _DeformSample(torch.autograd.Function):
         return dx, doff, None, None, None, None, None
 
 
-KEEP_DEFORM_COL = True
+# (KEEP_DEFORM_COL: a field of OpsContext, see the top of the module)
 
 
 class _DeformConv(torch.autograd.Function):
@@ -1474,7 +1539,7 @@ class _DeformConv(torch.autograd.Function):
         # (w_param: the GEMM operand is a block of the trainer's flat buffers or a cached gradient-free copy: packed once per weight version)
         wf, wb = packed_weights(d, w, w_param, need_bwd) if w_param is not None else pack_conv_weight(d, w.detach().contiguous(), need_bwd=need_bwd)
         y = torch.empty((N, Ho, Wo, cout), dtype=ACT, device=x.device)
-        keep = KEEP_DEFORM_COL and need_bwd
+        keep = _CTX.KEEP_DEFORM_COL and need_bwd
         if not keep and _lib.lib().danhip_deform_conv_fused(N, H, W, C, cout, kh, kw, stride, dg):
             ws, nws = None, 0                            # the fused kernel samples straight into the GEMM's LDS tile: no column buffer
         else:
@@ -1525,10 +1590,10 @@ class _DeformConv(torch.autograd.Function):
         ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
         call("danhip_deform_conv_bwd_deliver", ptr(x), ptr(wb), ptr(offsets), ptr(g), ptr(col), ptr(dx), ptr(doff), ptr(dw), ptr(db), N, H, W, C, cout,
              kh, kw, stride, dilation, dg, acc, relu_x, ptr(ws), nws, stream())
-        if GRAD_READY_HOOK is not None and bp is not None:
-            GRAD_READY_HOOK(bp)
-        if GRAD_READY_HOOK is not None and dw_sink is not None:
-            GRAD_READY_HOOK(ctx.w_param)
+        if _CTX.GRAD_READY_HOOK is not None and bp is not None:
+            _CTX.GRAD_READY_HOOK(bp)
+        if _CTX.GRAD_READY_HOOK is not None and dw_sink is not None:
+            _CTX.GRAD_READY_HOOK(ctx.w_param)
         return ((None if xs is not None else dx), (None if dw_sink is not None else dw), (None if db_sink is not None else db), doff, None, None, None, None,
                 None, None, None, None, None, None)
 
@@ -1591,3 +1656,21 @@ def argsort_desc(scores, ties_high_index_first=False):
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=scores.device)
     call("danhip_argsort_desc_f32", ptr(s), n, 1 if ties_high_index_first else 0, ptr(idx), ptr(ws), nbytes, stream())
     return idx.long()
+
+
+# ---- `ops.USE_SLOTS`, `ops.TRACE = {}` ... (rounds 1-4 spelling; tests, bench.py, tools): reads and writes go to the active context
+class _OpsModule(type(os)):
+    def __getattr__(self, name):
+        if name in _CTX_FIELDS:
+            return getattr(_CTX, name)
+        raise AttributeError("module %r has no attribute %r" % (self.__name__, name))
+
+    def __setattr__(self, name, value):
+        if name in _CTX_FIELDS:
+            setattr(_CTX, name, value)
+        else:
+            super().__setattr__(name, value)
+
+
+import sys as _sys  # noqa: E402
+_sys.modules[__name__].__class__ = _OpsModule

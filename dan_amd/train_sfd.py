@@ -102,8 +102,11 @@ class DetectorTrainer(object):
 
     def __init__(self, model, world=1, weight_decay=5e-4, negative_ratio=3.0, momentum=0.9, base_lr=1e-3, init_hw=(64, 64),
                  lr_boundaries=(1000, 80000, 100000), lr_factors=(0.1, 1.0, 0.1, 0.01), loss_scale=None, dynamic_loss_scale=None,
-                 loss_scale_growth_interval=1000):
+                 loss_scale_growth_interval=1000, ops_ctx=None):
         self.model = model
+        # the ops' steering state this trainer runs under (kernel-form switches, diagnostic sinks, the per-step hooks armed below): the
+        # context active at construction unless one is handed in - every step runs inside it (ops.OpsContext)
+        self.ops_ctx = ops_ctx if ops_ctx is not None else ops.context()
         # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale (the factor enters
         # through the loss terms' `scale`: their backward ignores the upstream seed) and the
         # fused optimizer divides the (fp32) weight gradients again; bf16 has fp32's exponent range and needs none
@@ -203,6 +206,11 @@ class DetectorTrainer(object):
         return self._eager_towers([(images_u8,) + tuple(targets)])
 
     def _eager_towers(self, towers):
+        with ops.use_context(self.ops_ctx):
+            return self._eager_towers_in_context(towers)
+
+    def _eager_towers_in_context(self, towers):
+        octx = self.ops_ctx
         self.flat.zero_grad()
         self.buckets.begin_step()
         self._step_lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
@@ -211,7 +219,7 @@ class DetectorTrainer(object):
             self.flat.l2.zero_()                              # (every bucket's update adds its share of the L2 term)
         for t, args in enumerate(towers):
             # gradients become final in the last tower's backward: only then may a bucket leave
-            ops.GRAD_READY_HOOK = self._hook if (self.buckets.active and t == len(towers) - 1) else None
+            octx.GRAD_READY_HOOK = self._hook if (self.buckets.active and t == len(towers) - 1) else None
             terms = self.loss_terms(*args)
             accs = [a[2] for a in terms]
             # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
@@ -219,15 +227,15 @@ class DetectorTrainer(object):
             # host-staged all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
             if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
                 ops.wgrad_overlap_begin()
-            ops.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
+            octx.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
             try:
                 torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
             except BaseException:
                 ops.wgrad_overlap_join()                      # never leave the second stream armed behind a failed step
                 raise
             finally:
-                ops.GRAD_READY_HOOK = None
-                ops.LOSS_SCALE_DEV = None
+                octx.GRAD_READY_HOOK = None
+                octx.LOSS_SCALE_DEV = None
             if t < len(towers) - 1:
                 ops.wgrad_overlap_join()                      # (the next tower's forward reuses this one's activation buffers)
         self.buckets.finish()

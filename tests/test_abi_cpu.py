@@ -557,3 +557,30 @@ def test_one_rank_without_rccl_is_an_error_not_a_silent_fallback(monkeypatch):
     monkeypatch.setenv("DANHIP_DP_NO_FALLBACK", "1")
     with pytest.raises(Exception):
         trainer.RcclComm.shared_or_none(torch.device("cpu"))
+
+
+def test_ops_steering_state_lives_in_a_context_object(monkeypatch):
+    """dan_amd.ops keeps its kernel-form switches, diagnostic sinks and per-step hooks in ONE OpsContext; the rounds-1-4 spelling
+    (`ops.USE_SLOTS = False`) reads and writes the ACTIVE context, `ops.use_context` scopes another one."""
+    from dan_amd import ops
+    base = ops.context()
+    assert ops.USE_SLOTS is base.USE_SLOTS is True and ops.TRACE is None
+    assert "USE_SLOTS" not in vars(ops) and "TRACE" not in vars(ops) and "GRAD_READY_HOOK" not in vars(ops)     # no module-level copies
+    mine = ops.OpsContext(USE_SPLITK=False)
+    with ops.use_context(mine):
+        assert ops.context() is mine and ops.USE_SPLITK is False and base.USE_SPLITK is True
+        ops.TRACE = {"x": 1}                                   # legacy spelling writes the active context only
+        assert mine.TRACE == {"x": 1} and base.TRACE is None
+        assert ops._conv_scratch.__module__ == "dan_amd.ops"
+    assert ops.context() is base and ops.TRACE is None and ops.USE_SPLITK is True
+    monkeypatch.setattr(ops, "USE_SLOTS", False)               # pytest's monkeypatch goes through the same shim (and restores through it)
+    assert base.USE_SLOTS is False and ops._new_slot(True) is None
+    monkeypatch.undo()
+    assert base.USE_SLOTS is True
+    with pytest.raises(AttributeError):
+        ops.OpsContext(NO_SUCH_SWITCH=1)
+    with pytest.raises(AttributeError):
+        ops.NO_SUCH_ATTRIBUTE
+    ops.SOME_NEW_MODULE_ATTRIBUTE = 3                           # anything that is not a context field stays an ordinary module attribute
+    assert vars(ops)["SOME_NEW_MODULE_ATTRIBUTE"] == 3
+    del ops.SOME_NEW_MODULE_ATTRIBUTE

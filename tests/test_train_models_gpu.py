@@ -113,7 +113,7 @@ def test_weight_gradient_stream_does_not_change_the_trajectory(dev, monkeypatch)
         tr = SFDTrainer(SFDModel(device=dev, seed=6), world=1)
         tr.train_step(imgs, loc_t, cls_t)
         torch.cuda.synchronize()
-        assert not ops._WGRAD["on"] and not ops._WGRAD["keep"]          # joined, nothing kept alive
+        assert not ops.context().wgrad["on"] and not ops.context().wgrad["keep"]          # joined, nothing kept alive
         g1 = tr.flat.g.clone()
         for _ in range(2):
             tr.train_step(imgs, loc_t, cls_t)
