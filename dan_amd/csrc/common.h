@@ -68,6 +68,15 @@ __device__ __forceinline__ void unpack2bf(unsigned w, float& lo, float& hi) {
   lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u);
 }
 #endif
+// acc + lo(a) * lo(b) + hi(a) * hi(b) on packed 16-bit pairs: v_dot2c_f32_bf16 / v_dot2c_f32_f16 (products exact in fp32, fp32 accumulate) -
+// a dot product over packed activations without unpacking them first
+__device__ __forceinline__ float dh_dot2(unsigned a, unsigned b, float acc) {
+#ifdef DANHIP_FP16
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), acc, false);
+#endif
+}
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even (bf16: v_cvt_pk_bf16_f32, NaN-safe; fp16: v_cvt_f16_f32)
   const act16_t b = (act16_t)f;
   return __builtin_bit_cast(bf16_t, b);

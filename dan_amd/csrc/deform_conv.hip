@@ -634,16 +634,19 @@ __device__ __forceinline__ void deform_bwd_doff_tile_c64_body(const bf16_t* __re
             v2 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wl) * g.C); v3 = *reinterpret_cast<const uint4*>(ub + (long)(hh * g.W + wh) * g.C);
           }
         }
-        float vll[8], vlh[8], vhl[8], vhh[8], cg[8];
-        unpack8(v0, vll); unpack8(v1, vlh); unpack8(v2, vhl); unpack8(v3, vhh); unpack8(cgr[u], cg);
-        float s_h = 0.f, s_w = 0.f;
+        // get_coordinate_weight's two sums, with the corner weights (the same for every channel) taken out of the channel sum: four dot
+        // products of the packed dS piece with the packed corner pieces (v_dot2c: 16 instructions, nothing unpacked - the loop was
+        // VALU-bound on 40 unpacks + 80 multiply-adds per tap), then s_h = a_w (D_hl - D_ll) + b_w (D_hh - D_lh), s_w likewise
+        const unsigned cgw[4] = {cgr[u].x, cgr[u].y, cgr[u].z, cgr[u].w};
+        const unsigned w0[4] = {v0.x, v0.y, v0.z, v0.w}, w1[4] = {v1.x, v1.y, v1.z, v1.w}, w2[4] = {v2.x, v2.y, v2.z, v2.w}, w3[4] = {v3.x, v3.y, v3.z, v3.w};
+        float d_ll = 0.f, d_lh = 0.f, d_hl = 0.f, d_hh = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          s_h += (-1.f * a_w * vll[e] + -1.f * b_w * vlh[e] + a_w * vhl[e] + b_w * vhh[e]) * cg[e];
-          s_w += (-1.f * a_h * vll[e] + a_h * vlh[e] + -1.f * b_h * vhl[e] + b_h * vhh[e]) * cg[e];
+        for (int e = 0; e < 4; ++e) {
+          d_ll = dh_dot2(cgw[e], w0[e], d_ll); d_lh = dh_dot2(cgw[e], w1[e], d_lh);
+          d_hl = dh_dot2(cgw[e], w2[e], d_hl); d_hh = dh_dot2(cgw[e], w3[e], d_hh);
         }
-        sv[2 * u] = s_h;
-        sv[2 * u + 1] = s_w;
+        sv[2 * u] = a_w * (d_hl - d_ll) + b_w * (d_hh - d_lh);
+        sv[2 * u + 1] = a_h * (d_lh - d_ll) + b_h * (d_hh - d_hl);
       }
       const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
       float r4[4], r2[2];
