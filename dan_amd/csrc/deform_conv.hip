@@ -567,7 +567,11 @@ __device__ __forceinline__ void deform_bwd_doff_tile_c64_body(const bf16_t* __re
                                                               const bf16_t* __restrict__ dS, float* __restrict__ far_dx,
                                                               bf16_t* __restrict__ doffs, const DeformGeom& g, int tiles_h, int tiles_w, uint4* sx) {
   constexpr int DT_RH = DT_H + 2 * (R + 1), DT_RW = DT_W + 2 * (R + 1);
-  unsigned b = blockIdx.x;
+  // XCD-aware order: workgroup i runs on XCD i % 8; each XCD walks a contiguous eighth of the (image, tile, group) items, so the four groups of
+  // a tile (the same offset lines, neighbouring slices of the same x / dS rows) and the overlapping regions of neighbouring tiles meet in ONE L2
+  const unsigned nitems = (unsigned)g.N * (unsigned)tiles_h * (unsigned)tiles_w * (unsigned)g.dg, per_xcd = (nitems + 7u) / 8u;
+  unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (b >= nitems) return;                                               // (uniform; the grid is 8 * per_xcd)
   const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
   const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
   const int th0 = (int)(b % (unsigned)tiles_h) * DT_H;
@@ -687,7 +691,11 @@ __device__ __forceinline__ void deform_bwd_dx_tile_c64_body(const bf16_t* __rest
                                                             int accumulate, const BwdGate& gate, const bf16_t* __restrict__ relu_x, int tiles_h,
                                                             int tiles_w, unsigned* soff) {
   constexpr int DT_RH = DT_H + 2 * (R + 1), DT_RW = DT_W + 2 * (R + 1), D = 2 * R + 1, NC = D * D * 9, ROUNDS = (NC + 7) / 8;
-  unsigned b = blockIdx.x;
+  // XCD-aware order: workgroup i runs on XCD i % 8; each XCD walks a contiguous eighth of the (image, tile, group) items, so the four groups of
+  // a tile (the same offset lines, neighbouring slices of the same x / dS rows) and the overlapping regions of neighbouring tiles meet in ONE L2
+  const unsigned nitems = (unsigned)g.N * (unsigned)tiles_h * (unsigned)tiles_w * (unsigned)g.dg, per_xcd = (nitems + 7u) / 8u;
+  unsigned b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (b >= nitems) return;                                               // (uniform; the grid is 8 * per_xcd)
   const int grp = (int)(b % (unsigned)g.dg); b /= (unsigned)g.dg;
   const int tw0 = (int)(b % (unsigned)tiles_w) * DT_W; b /= (unsigned)tiles_w;
   const int th0 = (int)(b % (unsigned)tiles_h) * DT_H;
@@ -910,7 +918,7 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
   const int tiles_h = (H + DT_H - 1) / DT_H, tiles_w = (W + DT_W - 1) / DT_W;
   const long tile_blocks = (long)N * tiles_h * tiles_w * deformable_group;
   // both gather windows as the tile kernels (dilation 1); other dilations keep the item / wave-per-pixel kernels (which read the side buffer always)
-  const bool tiled = gathered && dilation == 1 && g.pad_t == 1 && g.pad_l == 1 && tile_blocks < (1l << 31) && !danhip_option("deform_dx_untiled");
+  const bool tiled = gathered && dilation == 1 && g.pad_t == 1 && g.pad_l == 1 && tile_blocks < (1l << 31) - 8 && !danhip_option("deform_dx_untiled");
   const bool lazy_zero = tiled && (nx * 4) % 16 == 0;
   { const int zrc = lazy_zero ? danhip_zero_async(stat, sizeof(unsigned) * 64, s) : danhip_zero_async(workspace, sizeof(float) * (nx + 64), s); if (zrc) return zrc; }
   if (gathered) {
@@ -925,10 +933,11 @@ static int deform_sample_bwd_impl(const uint16_t* x, const uint16_t* offsets, co
     if (lazy_zero)
       hipLaunchKernelGGL(zero_if_far_kernel, dim3(grid_for(nx / 4, 256, 2048)), dim3(256), 0, s, reinterpret_cast<uint4*>(workspace), nx / 4, stat, gate.force);
     if (tiled) {
-      hipLaunchKernelGGL(deform_bwd_doff_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x),
+      const unsigned tgrid = (unsigned)((tile_blocks + 7) / 8 * 8);       // 8 XCDs x their share of the items (the kernels map blockIdx -> item)
+      hipLaunchKernelGGL(deform_bwd_doff_tile_c64_kernel, dim3(tgrid), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(x),
                          reinterpret_cast<const bf16_t*>(offsets), reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(d_offsets), g, gate,
                          tiles_h, tiles_w);
-      hipLaunchKernelGGL(deform_bwd_dx_tile_c64_kernel, dim3((unsigned)tile_blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets),
+      hipLaunchKernelGGL(deform_bwd_dx_tile_c64_kernel, dim3(tgrid), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(offsets),
                          reinterpret_cast<const bf16_t*>(dS), workspace, reinterpret_cast<bf16_t*>(dx), g, accumulate, gate, rx, tiles_h, tiles_w);
     } else {
       const dim3 gd(grid_for((nd + 31) / 32 * 256, 256, 65536)), gg(grid_for((ng + 3) / 4 * 256, 256, 65536));

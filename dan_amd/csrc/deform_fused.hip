@@ -56,6 +56,13 @@ __global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const Fused
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS map: [A stage 0][A stage 1][W stage 0][W stage 1]
   const int tid = threadIdx.x, lane = tid & 63;
+  // XCD-aware tile order (round 5): workgroup i runs on XCD i % 8, so with tile = blockIdx the 64 workgroups resident on an XCD were spread
+  // over 512 consecutive tiles (205 image rows, 17 MB of x: its 4 MiB L2 kept nothing and the corner gathers fetched 4.9 GB per launch
+  // from the fabric for a 210 MB input - rocprofv3 FETCH_SIZE).  Each XCD now walks its own contiguous eighth of the tiles: its resident
+  // workgroups cover ~26 rows (2 MB) and the nine taps' gathers of a row hit L2.
+  const unsigned per_xcd = ((unsigned)((a.M + BM - 1) / BM) + 7u) / 8u;
+  const long tile = (long)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (tile * BM >= a.M) return;                              // (uniform; the grid is 8 * per_xcd)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int frow = lane & 15, fq = lane >> 4;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const Fused
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     px2[u] = (tid >> 3) + u * HP;
-    m2[u] = (long)blockIdx.x * BM + px2[u];
+    m2[u] = tile * BM + px2[u];
     live2[u] = m2[u] < a.M;
     const long mm = live2[u] ? m2[u] : a.M - 1;
     const int wo = (int)(mm % a.Wo);
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(BM * 4, 2) void deform_fused_fwd_kernel(const Fused
     }
 #pragma unroll
     for (int p = 0; p < NPT; ++p) {
-      const long mo = (long)blockIdx.x * BM + wm * 64 + p * 16 + frow;
+      const long mo = tile * BM + wm * 64 + p * 16 + frow;
       if (mo >= a.M) continue;
       float v[4];
 #pragma unroll
@@ -273,7 +280,8 @@ int launch_fused(const FusedArgs& a, hipStream_t s) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&deform_fused_fwd_kernel<BN, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   const long tiles = (a.M + BM - 1) / BM;
-  hipLaunchKernelGGL((deform_fused_fwd_kernel<BN, BM>), dim3((unsigned)tiles), dim3(BM * 4), LDS, s, a);
+  const long grid = (tiles + 7) / 8 * 8;                     // 8 XCDs x their share of the tiles (the kernel maps blockIdx -> tile)
+  hipLaunchKernelGGL((deform_fused_fwd_kernel<BN, BM>), dim3((unsigned)grid), dim3(BM * 4), LDS, s, a);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
