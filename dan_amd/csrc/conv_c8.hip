@@ -9,7 +9,7 @@
 //     load per lane and step — no LDS, no repacking: lane (px = lane & 15, kq = lane >> 4) loads tap 4*step + kq of pixel px.
 //   * weights are the A operand (4 tiles x 3 steps = 12 fragments = 48 VGPRs, resident), with the rows of each pair of tiles
 //     permuted so that a lane ends up owning 8 CONSECUTIVE output channels of one pixel: two 16-byte stores per lane and
-//     unit, each store instruction writing 16 pixels x 64 contiguous bytes.
+//     unit; neighbouring pixels' lanes trade halves so that each store instruction writes 8 whole 128-byte lines (round 5).
 //   * a wave walks units of 16 consecutive pixels of one image row, two units per iteration, the next pair's 6 loads
 //     issued before the current pair is multiplied and stored.
 #include "conv_common.h"
@@ -93,21 +93,42 @@ __global__ __launch_bounds__(256) void conv3x3_c8_kernel(const ConvArgs a, const
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = DH_MFMA_16x16x32(wr[m][2], f2, acc[m]);
     unsigned pbyte[2] = {0u, 0u};
-    if (t.x0 + px < a.W) {
-      bf16_t* yo = reinterpret_cast<bf16_t*>(a.y) + ((size_t)(unsigned)(t.base + px)) * 64 + q * 8;
+    u32x4 o2[2];
 #pragma unroll
-      for (int P = 0; P < 2; ++P) {                 // this lane: output channels [P*32 + q*8, +8) of pixel x0 + px
-        f32x4 lo = acc[2 * P], hi = acc[2 * P + 1];
-        lo[0] += bias[P][0]; lo[1] += bias[P][1]; lo[2] += bias[P][2]; lo[3] += bias[P][3];
-        hi[0] += bias[P][4]; hi[1] += bias[P][5]; hi[2] += bias[P][6]; hi[3] += bias[P][7];
-        if (a.relu) {
-          lo[0] = dh_relu(lo[0]); lo[1] = dh_relu(lo[1]); lo[2] = dh_relu(lo[2]); lo[3] = dh_relu(lo[3]);
-          hi[0] = dh_relu(hi[0]); hi[1] = dh_relu(hi[1]); hi[2] = dh_relu(hi[2]); hi[3] = dh_relu(hi[3]);
-        }
-        const u32x4 o = {pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
-        if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(yo + P * 32));
-        else *reinterpret_cast<u32x4*>(yo + P * 32) = o;
-        pbyte[P] = c8_pos_bits8(o);
+    for (int P = 0; P < 2; ++P) {                   // this lane: output channels [P*32 + q*8, +8) of pixel x0 + px
+      f32x4 lo = acc[2 * P], hi = acc[2 * P + 1];
+      lo[0] += bias[P][0]; lo[1] += bias[P][1]; lo[2] += bias[P][2]; lo[3] += bias[P][3];
+      hi[0] += bias[P][4]; hi[1] += bias[P][5]; hi[2] += bias[P][6]; hi[3] += bias[P][7];
+      if (a.relu) {
+        lo[0] = dh_relu(lo[0]); lo[1] = dh_relu(lo[1]); lo[2] = dh_relu(lo[2]); lo[3] = dh_relu(lo[3]);
+        hi[0] = dh_relu(hi[0]); hi[1] = dh_relu(hi[1]); hi[2] = dh_relu(hi[2]); hi[3] = dh_relu(hi[3]);
+      }
+      o2[P] = u32x4{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
+      pbyte[P] = c8_pos_bits8(o2[P]);
+    }
+    // WHOLE 128-byte lines per store instruction (round 5): a lane's two pieces are the [0, 64) and [64, 128) halves of its pixel's line, so
+    // storing piece P from every lane wrote 16 half lines per instruction and the layer's 839 MB went out as 1062 MB of write traffic
+    // (rocprofv3 WRITE_SIZE).  Neighbouring pixels (lane ^ 1) trade pieces instead: the even pixel's lane ends up with both pixels' low
+    // halves, the odd one with both high halves; instruction 1 then writes the even pixels' lines whole (low half from the even lane, high
+    // half from the odd one), instruction 2 the odd pixels'.
+    {
+      const bool odd = px & 1;
+      u32x4 give, got;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) give[e] = odd ? o2[0][e] : o2[1][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) got[e] = dh_lane_xor1(give[e]);
+      // even lane: own low half (pixel px) + the odd neighbour's low half (pixel px + 1); odd lane: the even neighbour's high half (px - 1) + own high half
+      const u32x4 first = odd ? got : o2[0], second = odd ? o2[1] : got;
+      const int pe = px & ~1;                       // the even pixel of the pair
+      bf16_t* line = reinterpret_cast<bf16_t*>(a.y) + ((size_t)(unsigned)(t.base + pe)) * 64 + (odd ? 32 : 0) + q * 8;
+      if (t.x0 + pe < a.W) {
+        if (NT) __builtin_nontemporal_store(first, reinterpret_cast<u32x4*>(line));
+        else *reinterpret_cast<u32x4*>(line) = first;
+      }
+      if (t.x0 + pe + 1 < a.W) {
+        if (NT) __builtin_nontemporal_store(second, reinterpret_cast<u32x4*>(line + 64));
+        else *reinterpret_cast<u32x4*>(line + 64) = second;
       }
     }
     // ReLU bit mask of the output for the next layer's data gradient (danhip_relu_bits layout: 8 bytes per pixel): this lane's two bytes

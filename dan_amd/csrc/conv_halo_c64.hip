@@ -156,8 +156,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       for (int p = 0; p < NPT; ++p) acc[c][p] = DH_MFMA_16x16x32(w[c], x[p], acc[c][p]);
   };
 
-  int sp = blockIdx.x;
-  if (sp >= g.sp_items) return;
+  // Tile order (round 5): workgroup b runs on XCD b % 8.  With tile = b + round * G the 32 workgroups of an XCD held every eighth tile of a
+  // 256-tile band, so no two neighbouring tiles shared an L2 and every halo row / column (10 x 34 patch for an 8 x 32 tile: 1.33 x) came
+  // from the fabric again (rocprofv3 FETCH_SIZE: 1.25-1.35 x the map).  Each XCD now walks its own contiguous eighth of the tiles, 32 at
+  // a time: horizontal neighbours load together, the row of tiles above was loaded one round earlier (1.4 MB ago in a 4 MiB L2).
+  const bool xcd_walk = (G & 7) == 0;
+  const int GS = xcd_walk ? (G >> 3) : G;
+  const int per_xcd = (g.sp_items + 7) >> 3;
+  const int xbase = xcd_walk ? (int)(blockIdx.x & 7u) * per_xcd : 0;
+  const int xend = xcd_walk ? (xbase + per_xcd < g.sp_items ? xbase + per_xcd : g.sp_items) : g.sp_items;
+  int sp = xcd_walk ? xbase + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (sp >= xend) return;
   issue_patch(sp, 0);
   if constexpr (!DGRAD) {
     if (tid < 64) reinterpret_cast<float*>(smem + RWBASE)[tid] = a.bias ? a.bias[tid] : 0.f;
@@ -167,8 +176,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   __builtin_amdgcn_s_barrier();
   int buf = 0;
   for (;;) {
-    const int nsp = sp + G;
-    const bool has_next = nsp < g.sp_items;
+    const int nsp = sp + GS;
+    const bool has_next = nsp < xend;
     if constexpr (DGRAD) {
       issue_rw(sp);                                // this tile's mask / old value (its own reads of the region ended with its last epilogue)
       if (a.mask_bits) issue_bits(sp, buf);
