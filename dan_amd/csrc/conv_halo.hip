@@ -578,6 +578,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int p = 0; p < NPT; ++p) {
           const unsigned yo = okp[p] ? (pix[p] * (unsigned)a.Co + (unsigned)cb) * 2u : OOB;
           [[maybe_unused]] unsigned pb[2] = {0u, 0u};
+          [[maybe_unused]] u32x4 ttq[2];
 #pragma unroll
           for (int q = 0; q < NPAIR; ++q) {
             float v[8] = {acc[2 * q][p][0], acc[2 * q][p][1], acc[2 * q][p][2], acc[2 * q][p][3],
@@ -603,7 +604,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // (lane * 16 bytes inside the item's own 64 KiB of the output) instead of 16 half cache lines 512 bytes apart
             __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((unsigned)((c_sp * g.NB + c_nb) & 0x3fff) * 65536u + (unsigned)(((wave * NPT + p) * NPAIR + q) * 1024 + lane * 16)), 0, 0);
 #else
-            __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
+            if constexpr (NPAIR == 2) ttq[q] = tt;
+            else __builtin_amdgcn_raw_buffer_store_b128(tt, rsrc_y, (int)((cok[q] ? yo : OOB) + q * 64), 0, 0);
 #endif
             if constexpr (POOL) {
               if (!(okp[p] && cok[q])) tt = u32x4{0u, 0u, 0u, 0u};
@@ -613,6 +615,27 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               if (a.bits_out) pb[q & 1] = pos_bits8(tt);
             }
           }
+#ifndef H_ABLATE_STORE_PATTERN
+          if constexpr (NPAIR == 2) {
+            // WHOLE 128-byte lines per store instruction (round 5; measured in conv_c8.hip and conv_pointwise.hip): the wave's 64 channels are
+            // one line of a pixel and a lane holds its two halves (q = 0, 1), so storing piece q from every lane wrote 16 half lines per
+            // instruction.  Neighbouring pixels of a row (lane ^ 1) trade pieces: the even pixel's lane ends up with both low halves, the odd
+            // one with both high halves; instruction 1 writes the even pixels' lines whole, instruction 2 the odd pixels'.  Same number of
+            // store instructions; a pixel outside the map or channels beyond Cout stay out-of-range offsets.
+            const bool odd = frow & 1;
+            u32x4 give, got;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) give[e] = odd ? ttq[0][e] : ttq[1][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) got[e] = dh_lane_xor1(give[e]);
+            const unsigned yo_n = dh_lane_xor1(yo);              // the neighbour's pixel (OOB when it is outside the map)
+            const u32x4 first = odd ? got : ttq[0], second = odd ? ttq[1] : got;
+            const unsigned off1 = odd ? (cok[1] ? yo_n : OOB) + 64u : (cok[0] ? yo : OOB);
+            const unsigned off2 = odd ? (cok[1] ? yo : OOB) + 64u : (cok[0] ? yo_n : OOB);
+            __builtin_amdgcn_raw_buffer_store_b128(first, rsrc_y, (int)off1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(second, rsrc_y, (int)off2, 0, 0);
+          }
+#endif
           if constexpr (EMIT_OK) {
             if (a.bits_out) {                        // (uniform) 8 bytes per pixel and wave, stored by the fq == 0 lane
               const uint2 w8 = gather_bits64(pb[0], pb[1], fq);

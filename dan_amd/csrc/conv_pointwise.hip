@@ -319,6 +319,7 @@ __device__ __forceinline__ void pw_body(const ConvArgs a, const PwGeom g) {
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const long m = (long)c_mt * BM + wm * TP + p * 16 + frow;
+        [[maybe_unused]] pw_u32x4 tq[2];
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) {
           float v[8];
@@ -351,13 +352,33 @@ __device__ __forceinline__ void pw_body(const ConvArgs a, const PwGeom g) {
               }
             }
           }
-          if (m < a.M) {
-            const pw_u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-            *reinterpret_cast<pw_u32x4*>(reinterpret_cast<bf16_t*>(a.y) + (size_t)m * a.ldy + cb + q * 32) = t;
+          const pw_u32x4 t = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+          if constexpr (NPAIR == 2) {
+            tq[q] = t;
+          } else {
+            if (m < a.M) *reinterpret_cast<pw_u32x4*>(reinterpret_cast<bf16_t*>(a.y) + (size_t)m * a.ldy + cb + q * 32) = t;
           }
           ++ns;
           acc[2 * q][p] = f32x4{0.f, 0.f, 0.f, 0.f};
           acc[2 * q + 1][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (NPAIR == 2) {
+          // WHOLE 128-byte lines per store instruction (round 5; conv_c8.hip has the measurement): the wave's 64 channels are one line of a
+          // pixel and a lane holds its [0, 64) and [64, 128) halves (q = 0, 1), so storing piece q from every lane wrote 16 half lines per
+          // instruction (1.2-1.3 x the bytes in write traffic).  Neighbouring pixels (lane ^ 1: rows m, m ^ 1 - tiles start on even rows)
+          // trade pieces: the even pixel's lane ends up with both low halves, the odd one with both high halves; instruction 1 writes the
+          // even pixels' lines whole, instruction 2 the odd pixels'.  Same number of store instructions (the counted waits rely on it).
+          const bool odd = frow & 1;
+          pw_u32x4 give, got;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) give[e] = odd ? tq[0][e] : tq[1][e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) got[e] = dh_lane_xor1(give[e]);
+          const pw_u32x4 first = odd ? got : tq[0], second = odd ? tq[1] : got;
+          const long me = m & ~1l;
+          bf16_t* line = reinterpret_cast<bf16_t*>(a.y) + (size_t)me * a.ldy + cb + (odd ? 32 : 0);
+          if (me < a.M) *reinterpret_cast<pw_u32x4*>(line) = first;
+          if (me + 1 < a.M) *reinterpret_cast<pw_u32x4*>(line + a.ldy) = second;
         }
       }
       st_age = 0;
