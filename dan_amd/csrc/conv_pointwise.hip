@@ -17,7 +17,8 @@
 //  * the step sequence is flattened across items: the next item's first K-steps are already landing while the epilogue stores run;
 //    the DMA is inline asm with a counted vmcnt (never drained in the loop: hipcc would wait vmcnt(0) before each ds_read), the
 //    epilogue's mask / old-value reads are asm loads issued BEFORE the item's last DMA so that waiting for them retires nothing else;
-//  * XCD-grouped item order: the Co / BN column blocks of one pixel tile run on one XCD (second .. last read X from that L2).
+//  * XCD-grouped item order: each XCD walks a contiguous eighth of the (pixel tile, column block) items, so the Co / BN column blocks of a
+//    pixel tile run on one XCD (second .. last read X from that L2) and, with taps, neighbouring pixel tiles' halo rows meet there too.
 #include <type_traits>
 
 #include "conv_common.h"
@@ -25,7 +26,7 @@
 namespace {
 
 struct PwGeom {
-  int m_tiles, NB, items, ksteps, grouped;
+  int m_tiles, NB, items, ksteps, grouped, per_xcd;
   FastDiv div_nb;
 };
 
@@ -99,8 +100,13 @@ __device__ __forceinline__ void pw_body(const ConvArgs a, const PwGeom g) {
   auto decode = [&](int v, int& mt, int& nb) __attribute__((always_inline)) -> bool {     // v = round * G + block
     int it;
     if (g.grouped) {
+      // an XCD (blocks b, b + 8, ...) walks its own contiguous EIGHTH of the items, G / 8 at a time (round 5; rounds 2-4: a contiguous run
+      // per round, and only when G / 8 was a multiple of NB - Co / BN = 9, the deformable column gradient, fell back to item = block and
+      // its nine column blocks of a pixel tile ran on nine XCDs: X fetched ~9 x, rocprofv3 FETCH_SIZE)
       const int r = v / G, b = v - r * G;
-      it = r * G + (b & 7) * (G >> 3) + (b >> 3);      // an XCD (blocks b, b + 8, ...) takes a contiguous run of items
+      const int j = r * (G >> 3) + (b >> 3);
+      it = (b & 7) * g.per_xcd + j;
+      if (j >= g.per_xcd) it = g.items;                // this XCD's share is done
     } else {
       it = v;
     }
@@ -437,7 +443,8 @@ int launch_pw_t(const ConvArgs& a, hipStream_t s) {
   g.div_nb = make_fastdiv(g.NB);
   int G = pw_cu_count();
   if (g.items < G) G = g.items;
-  g.grouped = (G % 8 == 0 && ((G >> 3) % g.NB) == 0 && g.items >= G) ? 1 : 0;
+  g.grouped = (G % 8 == 0 && g.items >= G) ? 1 : 0;
+  g.per_xcd = (g.items + 7) / 8;
   hipLaunchKernelGGL((conv_pointwise_kernel<BN, NST, DGRAD, LD, TAPS>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
@@ -457,7 +464,8 @@ int launch_pw_concat2(const ConvArgs& a, hipStream_t s) {
   g.div_nb = make_fastdiv(g.NB);
   int G = pw_cu_count();
   if (g.items < G) G = g.items;
-  g.grouped = (G % 8 == 0 && ((G >> 3) % g.NB) == 0 && g.items >= G) ? 1 : 0;
+  g.grouped = (G % 8 == 0 && g.items >= G) ? 1 : 0;
+  g.per_xcd = (g.items + 7) / 8;
   hipLaunchKernelGGL((conv_pointwise_concat2_kernel<BN, NST>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
