@@ -128,6 +128,8 @@ SIGNATURES = {
     "danhip_comm_create": [P, I32, I32, I32, ctypes.POINTER(ctypes.c_void_p)],
     "danhip_comm_destroy": [P],
     "danhip_comm_info": [P, ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32)],
+    "danhip_comm_async_error": [P, ctypes.POINTER(I32)],
+    "danhip_comm_abort": [P],
     "danhip_comm_allreduce_sum": [P, P, I64, ctypes.c_int, P],
     "danhip_comm_reduce_scatter_sum": [P, P, P, I64, ctypes.c_int, P],
     "danhip_comm_allgather": [P, P, P, I64, ctypes.c_int, P],

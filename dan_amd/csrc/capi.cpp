@@ -18,7 +18,7 @@ void danhip_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* danhip_last_error(void) { return g_err; }
-extern "C" int danhip_version(void) { return 3; }   // 2: danhip_deform_sample_bwd takes workspace_bytes; 3: danhip_comm_* (RCCL called directly)
+extern "C" int danhip_version(void) { return 4; }   // 2: danhip_deform_sample_bwd takes workspace_bytes; 3: danhip_comm_* (RCCL called directly); 4: danhip_comm_async_error / danhip_comm_abort
 extern "C" int danhip_act_dtype(void) {
 #ifdef DANHIP_FP16
   return DANHIP_F16;

@@ -36,6 +36,9 @@ struct Rccl {
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*ReduceScatter)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
+  // optional (rccl.h ncclCommGetAsyncError / ncclCommAbort): the failure-detection pair — a library without them reports "healthy"
+  int (*CommGetAsyncError)(rccl_comm_t, int*) = nullptr;
+  int (*CommAbort)(rccl_comm_t) = nullptr;
 };
 Rccl g_rccl;                       // written once under g_mu, published by g_bound (release) — read-only afterwards
 std::mutex g_mu;
@@ -73,6 +76,8 @@ int bind(const char* path) {
                   sym(h, "ncclCommCuDevice", r.CommCuDevice) && sym(h, "ncclGetErrorString", r.GetErrorString) &&
                   sym(h, "ncclAllReduce", r.AllReduce) && sym(h, "ncclReduceScatter", r.ReduceScatter) && sym(h, "ncclAllGather", r.AllGather);
   DH_REQUIRE(ok, DANHIP_ECOMM, "danhip_comm: %s lacks an RCCL entry point: %s", path ? path : "librccl.so", dlerror());
+  (void)sym(h, "ncclCommGetAsyncError", r.CommGetAsyncError);
+  (void)sym(h, "ncclCommAbort", r.CommAbort);
   g_rccl = r;
   g_bound.store(true, std::memory_order_release);
   return DANHIP_OK;
@@ -136,6 +141,28 @@ extern "C" int danhip_comm_destroy(void* comm) {
   if (!comm) return DANHIP_OK;
   DH_REQUIRE(g_bound.load(std::memory_order_acquire), DANHIP_ECOMM, "danhip_comm_destroy: RCCL was never bound");
   DH_RCCL(g_rccl.CommDestroy(comm), "ncclCommDestroy");
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_comm_abort(void* comm) {
+  if (!comm) return DANHIP_OK;
+  DH_REQUIRE(g_bound.load(std::memory_order_acquire), DANHIP_ECOMM, "danhip_comm_abort: RCCL was never bound");
+  if (g_rccl.CommAbort) {
+    DH_RCCL(g_rccl.CommAbort(comm), "ncclCommAbort");
+  } else {
+    DH_RCCL(g_rccl.CommDestroy(comm), "ncclCommDestroy");
+  }
+  return DANHIP_OK;
+}
+
+extern "C" int danhip_comm_async_error(void* comm, int32_t* err) {
+  DH_REQUIRE(comm && err && g_bound.load(std::memory_order_acquire), DANHIP_EINVAL, "danhip_comm_async_error: no communicator");
+  *err = 0;
+  if (!g_rccl.CommGetAsyncError) return DANHIP_OK;
+  int e = 0;
+  DH_RCCL(g_rccl.CommGetAsyncError(comm, &e), "ncclCommGetAsyncError");
+  *err = e;
+  if (e != 0) danhip_set_error("danhip_comm: asynchronous RCCL error %d (%s)", e, g_rccl.GetErrorString(e));
   return DANHIP_OK;
 }
 

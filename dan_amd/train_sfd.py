@@ -107,6 +107,9 @@ class DetectorTrainer(object):
         # the ops' steering state this trainer runs under (kernel-form switches, diagnostic sinks, the per-step hooks armed below): the
         # context active at construction unless one is handed in - every step runs inside it (ops.OpsContext)
         self.ops_ctx = ops_ctx if ops_ctx is not None else ops.context()
+        # a context handed in explicitly is entered by every step; otherwise a step runs in whatever context is active at CALL time, so
+        # `with ops.use_context(...): tr.train_step(...)` steers it as the OpsContext docstring promises
+        self._own_ctx = ops_ctx is not None
         # fp16 build: activation gradients below 6e-8 flush to zero, so the backward pass runs on loss * loss_scale (the factor enters
         # through the loss terms' `scale`: their backward ignores the upstream seed) and the
         # fused optimizer divides the (fp32) weight gradients again; bf16 has fp32's exponent range and needs none
@@ -206,32 +209,38 @@ class DetectorTrainer(object):
         return self._eager_towers([(images_u8,) + tuple(targets)])
 
     def _eager_towers(self, towers):
-        with ops.use_context(self.ops_ctx):
-            return self._eager_towers_in_context(towers)
+        if self._own_ctx:
+            with ops.use_context(self.ops_ctx):
+                return self._eager_towers_in_context(towers, self.ops_ctx)
+        return self._eager_towers_in_context(towers, ops.context())
 
-    def _eager_towers_in_context(self, towers):
-        octx = self.ops_ctx
+    def _eager_towers_in_context(self, towers, octx):
         self.flat.zero_grad()
         self.buckets.begin_step()
         self._step_lr = lr_schedule(self.step_no, self.base_lr, self.lr_boundaries, self.lr_factors)
         self._epoch_bumped = False
         if self.opt_overlap:
             self.flat.l2.zero_()                              # (every bucket's update adds its share of the L2 term)
+        tower_terms = []
         for t, args in enumerate(towers):
-            # gradients become final in the last tower's backward: only then may a bucket leave
-            octx.GRAD_READY_HOOK = self._hook if (self.buckets.active and t == len(towers) - 1) else None
-            terms = self.loss_terms(*args)
-            accs = [a[2] for a in terms]
-            # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
-            # collectives are device-side (RCCL; checked on hardware with a one-rank communicator, tests/test_zz_ddp_gpu.py).  gloo's
-            # host-staged all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
-            if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
-                ops.wgrad_overlap_begin()
-            octx.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
-            try:
+            armed = False
+            try:                                              # (the hooks are disarmed whichever of forward / backward raises: ADVICE r5)
+                # gradients become final in the last tower's backward: only then may a bucket leave
+                octx.GRAD_READY_HOOK = self._hook if (self.buckets.active and t == len(towers) - 1) else None
+                octx.LOSS_SCALE_DEV = self.ls_state[0:1] if self.ls_state is not None else None
+                terms = self.loss_terms(*args)
+                tower_terms.append(terms)
+                accs = [a[2] for a in terms]
+                # weight gradients on a second stream, next to the data gradients — also beside the bucketed all-reduce's stream when the
+                # collectives are device-side (RCCL; checked on hardware with a one-rank communicator, tests/test_zz_ddp_gpu.py).  gloo's
+                # host-staged all-reduce stalled in that combination (tools/debug_dp_overlap.py), so gloo groups keep one compute stream
+                if not self.buckets.enabled or self.buckets.device_collectives or os.environ.get("DANHIP_WGRAD_STREAM_DP") == "1":
+                    ops.wgrad_overlap_begin()
+                    armed = True
                 torch.autograd.backward(accs, [torch.ones_like(a) for a in accs])
             except BaseException:
-                ops.wgrad_overlap_join()                      # never leave the second stream armed behind a failed step
+                if armed:
+                    ops.wgrad_overlap_join()                  # never leave the second stream armed behind a failed step
                 raise
             finally:
                 octx.GRAD_READY_HOOK = None
@@ -245,6 +254,7 @@ class DetectorTrainer(object):
             self.flat.sgd_step(self._step_lr, self.momentum, grad_scale=1.0 / self.loss_scale, dynamic_state=self.ls_state)
         self.step_no += 1
         self.last = terms
+        self.last_towers = tower_terms                        # every tower's terms: loss_values() reports their mean
         return terms
 
     # ---- hipGraph capture of the whole step (forward, backward, bucketed all-reduce, optimizer, weight repack): one launch per step
@@ -286,6 +296,8 @@ class DetectorTrainer(object):
             self._capture()
         _tree_copy(self._static, (images_u8,) + tuple(targets))
         self._graph.replay()
+        if self.buckets.watch is not None:                   # failure detection of the exchange inside the replayed step (trainer.CommWatch)
+            self.buckets.watch.tick(torch.cuda.current_stream())
         self.step_no += 1
         self.last = self._graph_terms
         return self._graph_terms
@@ -313,10 +325,17 @@ class DetectorTrainer(object):
     def loss_values(self):
         """{name: (cross_entropy, loc_loss)} per term + 'l2' + 'total' as python floats (synchronises)."""
         out, total = {}, 0.0
-        for name, weight, acc in self.last:
-            ce_sum, n_sel, loc_sum, n_pos = [float(v) for v in acc.tolist()]
-            ce = (self.negative_ratio + 1.0) * ce_sum / max(n_sel, 1.0)
-            loc = loc_sum / max(n_pos, 1.0)
+        towers = getattr(self, "last_towers", None)
+        if not towers or towers[-1] is not self.last:         # (a replayed graph step, or a caller that assigned .last itself)
+            towers = [self.last]
+        # several towers on this rank (train_step_towers): the reference reports the mean of the tower losses, each normalised by its own
+        # counts (tf_replicate_model_fn.py:661-663) — not the last tower's
+        for k, (name, weight, _) in enumerate(towers[0]):
+            ce = loc = 0.0
+            for terms in towers:
+                ce_sum, n_sel, loc_sum, n_pos = [float(v) for v in terms[k][2].tolist()]
+                ce += (self.negative_ratio + 1.0) * ce_sum / max(n_sel, 1.0) / len(towers)
+                loc += loc_sum / max(n_pos, 1.0) / len(towers)
             out[name] = (ce, loc)
             total += weight * (ce + loc)
         out["l2"] = float(self.flat.l2.item())

@@ -18,28 +18,126 @@ import torch.distributed as dist
 from ._lib import call, ptr, stream
 
 
+def comm_timeout_s():
+    """Deadline (seconds) of every point where a rank waits for its peers outside a stream: the control-plane barriers around the RCCL
+    bootstrap, ncclCommInitRank itself, and the watchdog's wait for a step's collectives (GradBuckets.finish).  DANHIP_COMM_TIMEOUT_S."""
+    return float(os.environ.get("DANHIP_COMM_TIMEOUT_S", "300"))
+
+
+DEADLINE_EXIT_CODE = 75          # (EX_TEMPFAIL) a rank that gave up waiting for its peers leaves with this status
+
+
+def _die(msg):
+    """A peer is gone or stuck: this rank cannot leave the RCCL call (or the stream) it waits in, so the PROCESS ends — message on stderr,
+    non-zero status, no destructors (they would wait for the device), never a re-exec.  The launcher (torch.distributed.run) then takes the
+    other ranks down; a supervisor restarts the job from its last checkpoint as a fresh set of processes."""
+    sys.stderr.write("dan_amd: FATAL (rank %s): %s\n" % (os.environ.get("RANK", "0"), msg))
+    sys.stderr.flush()
+    os._exit(DEADLINE_EXIT_CODE)
+
+
+def _with_deadline(fn, seconds, what):
+    """fn() on a helper thread (ctypes releases the GIL inside the library); the calling thread waits `seconds` for it and ends the
+    process otherwise (a thread blocked inside ncclCommInitRank cannot be cancelled)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as e:                  # noqa: BLE001 - re-raised on the calling thread
+            box["e"] = e
+
+    th = threading.Thread(target=run, name="danhip-comm-bootstrap", daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        _die("%s did not return within %.0f s (DANHIP_COMM_TIMEOUT_S): a peer rank never entered it or died inside it" % (what, seconds))
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
+_control = {"group": None, "made": False}
+
+
+def control_group():
+    """The process group that carries CONTROL traffic (CPU tensors, pickled objects, monitored barriers): the default group when its
+    backend is gloo, else a gloo group over the same ranks created once (collective: every rank reaches this at the same point of
+    GradBuckets / RcclComm construction).  A default group on the nccl backend (DANHIP_DIST_BACKEND=nccl, or a caller's own
+    init_process_group) cannot carry CPU tensors: ADVICE r5."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if not _control["made"]:
+        _control["made"] = True
+        if dist.get_backend() != "gloo":
+            import datetime
+            _control["group"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(comm_timeout_s(), 1.0)))
+    return _control["group"]
+
+
+def control_barrier(what):
+    """All ranks are alive and HERE, or this rank ends within the deadline: gloo's monitored barrier names the missing rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    import datetime
+    try:
+        dist.monitored_barrier(group=control_group(), timeout=datetime.timedelta(seconds=comm_timeout_s()), wait_all_ranks=False)
+    except Exception as e:                          # noqa: BLE001 - any failure of the control plane here means a peer is gone
+        _die("control-plane barrier %s failed: %s" % (what, str(e).splitlines()[0] if str(e) else type(e).__name__))
+
+
+def rccl_library_path():
+    """DANHIP_RCCL_PATH (a test's stand-in, tests/ddp/fake_rccl.cpp, or another build) or the copy PyTorch ships — that one is (or will
+    be) in this process: bind that file rather than a second copy from the loader path.  None: the loader path."""
+    env = os.environ.get("DANHIP_RCCL_PATH")
+    if env:
+        return env.encode()
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand.encode() if os.path.exists(cand) else None
+
+
 class RcclComm(object):
     """This rank's RCCL communicator behind include/danhip.h's danhip_comm_* (csrc/comm.cpp): collectives are plain asynchronous calls on
     the CURRENT torch stream — no process-group work objects, no watchdog thread, capturable into a hipGraph like a kernel launch.
 
-    torch.distributed (any backend; gloo by default, see init_distributed) is the CONTROL plane only: it carries the 128-byte unique id
-    from rank 0 to the others.  One communicator per process is shared by every trainer (RcclComm.shared)."""
+    torch.distributed (gloo, see init_distributed / control_group) is the CONTROL plane only: it carries the 128-byte unique id from rank 0
+    to the others and the barriers around the bootstrap.  One communicator per process is shared by every trainer (RcclComm.shared).
+
+    No step of the bootstrap can hang a job: a monitored control-plane barrier stands in front of it
+    (a rank that died earlier is noticed there), rank 0 broadcasts (ok, id) so a failing ncclGetUniqueId is seen by every rank,
+    ncclCommInitRank runs under a deadline on a helper thread, and a second barrier stands behind it."""
     _shared = None
     _live = weakref.WeakSet()
 
     def __init__(self, rank, world, device_index):
-        # the RCCL copy PyTorch ships is (or will be) in this process: bind that file rather than a second copy from the loader path
-        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        call("danhip_comm_load", cand.encode() if os.path.exists(cand) else None)
+        call("danhip_comm_load", rccl_library_path())
         ident = ctypes.create_string_buffer(128)
-        if rank == 0:
-            call("danhip_comm_unique_id", ident)
         if world > 1:
-            box = [ident.raw]
-            dist.broadcast_object_list(box, src=0)
-            ident = ctypes.create_string_buffer(box[0], 128)
+            control_barrier("before the RCCL bootstrap")
+            box = [None]
+            if rank == 0:
+                try:
+                    call("danhip_comm_unique_id", ident)
+                    box = [(True, ident.raw)]
+                except Exception as e:              # noqa: BLE001 - every rank must learn of it: they all wait in the broadcast below
+                    box = [(False, "%s: %s" % (type(e).__name__, e))]
+            dist.broadcast_object_list(box, src=0, group=control_group())
+            ok, payload = box[0]
+            if not ok:
+                raise RuntimeError("rank 0 could not produce the RCCL unique id: %s" % payload)
+            ident = ctypes.create_string_buffer(payload, 128)
+        else:
+            call("danhip_comm_unique_id", ident)
         h = ctypes.c_void_p()
-        call("danhip_comm_create", ident, world, rank, int(device_index), ctypes.byref(h))
+
+        def create():
+            call("danhip_comm_create", ident, world, rank, int(device_index), ctypes.byref(h))
+
+        if world > 1:
+            _with_deadline(create, comm_timeout_s(), "ncclCommInitRank (danhip_comm_create, %d ranks)" % world)
+        else:
+            create()
         self.handle, self.rank, self.world = h, rank, world
         v = ctypes.c_int(0)
         call("danhip_comm_rccl_version", ctypes.byref(v))
@@ -51,7 +149,8 @@ class RcclComm(object):
         if cls._shared is None or cls._shared.handle is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
             world = dist.get_world_size() if dist.is_initialized() else 1
-            cls._shared = cls(rank, world, device.index if device.index is not None else torch.cuda.current_device())
+            index = -1 if device.type != "cuda" else (device.index if device.index is not None else torch.cuda.current_device())
+            cls._shared = cls(rank, world, index)
         return cls._shared
 
     @classmethod
@@ -65,29 +164,29 @@ class RcclComm(object):
         multi = dist.is_initialized() and dist.get_world_size() > 1
         strict = os.environ.get("DANHIP_DP_NO_FALLBACK", "0") == "1"
 
-        def everyone(ok):
+        def everyone(ok, what):
             if not multi:
                 return ok
+            control_barrier(what)                    # (a rank that died since the last agreement ends the job here, within the deadline)
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=control_group())
             return bool(flag.item())
 
         err = None
         try:                                         # (1) the library is loadable here (a local step: no rank waits on another)
-            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-            call("danhip_comm_load", cand.encode() if os.path.exists(cand) else None)
+            call("danhip_comm_load", rccl_library_path())
         except Exception as e:                       # noqa: BLE001 - reported below
             err = e
-        if not everyone(err is None):
+        if not everyone(err is None, "after loading librccl"):
             if strict and err is not None:
                 raise err
             sys.stderr.write("dan_amd: RCCL is not loadable on every rank (%s): gradients travel on the process group (gloo)\n" % (err,))
             return None
-        try:                                         # (2) the communicator itself (collective inside RCCL)
+        try:                                         # (2) the communicator itself (collective inside RCCL, under a deadline)
             comm = cls.shared(device)
         except Exception as e:                       # noqa: BLE001
             err, comm = e, None
-        if not everyone(comm is not None):
+        if not everyone(comm is not None, "after ncclCommInitRank"):
             if comm is not None:
                 comm.close()
             if strict and err is not None:
@@ -109,6 +208,25 @@ class RcclComm(object):
     def all_gather(self, full, shard):
         call("danhip_comm_allgather", self.handle, ptr(shard), ptr(full), shard.numel(), self._dtype(full), stream())
 
+    def async_error(self):
+        """0 while healthy, else the RCCL error code of a collective that failed asynchronously (ncclCommGetAsyncError)."""
+        if self.handle is None:
+            return 0
+        e = ctypes.c_int32(0)
+        call("danhip_comm_async_error", self.handle, ctypes.byref(e))
+        return e.value
+
+    def abort(self):
+        """Tear down WITHOUT waiting for outstanding collectives (ncclCommAbort): the only way out when a peer is gone."""
+        if self.handle is not None:
+            h, self.handle = self.handle, None
+            try:
+                call("danhip_comm_abort", h)
+            except Exception:                        # noqa: BLE001 - the process is on its way out
+                pass
+        if RcclComm._shared is self:
+            RcclComm._shared = None
+
     def close(self):
         """Every stream that carries this communicator's collectives must have drained, and every hipGraph holding them must be gone."""
         if self.handle is not None:
@@ -118,6 +236,55 @@ class RcclComm(object):
             call("danhip_comm_destroy", h)
         if RcclComm._shared is self:
             RcclComm._shared = None
+
+
+class CommWatch(object):
+    """What ProcessGroupNCCL's watchdog thread did, done by the training loop itself (with the collectives issued straight on
+    RCCL nothing notices a dead peer — the host runs ahead, the device waits in ncclAllReduce for ever).
+
+    tick(stream) is called once per step behind the step's last collective: it records an event there and polls
+    ncclCommGetAsyncError (one C call).  The host may run at most `lag` steps ahead of the device: before it records step k's event it
+    requires step k - lag's event to have completed, polling that event and the async error until DANHIP_COMM_TIMEOUT_S — in the normal
+    case the event is long done and the check costs one hipEventQuery.  On an error or on expiry the communicator is aborted and the
+    process ends non-zero (a fresh set of processes resumes from the checkpoint; never a re-exec)."""
+
+    def __init__(self, comm, lag=2):
+        self.comm, self.lag, self.events = comm, lag, []
+
+    def _check_error(self):
+        e = self.comm.async_error() if self.comm is not None else 0
+        if e != 0:
+            from ._lib import lib
+            msg = lib().danhip_last_error().decode(errors="replace")
+            self.comm.abort()
+            _die("asynchronous RCCL error %d in the gradient exchange: %s" % (e, msg))
+
+    def wait(self, ev, what):
+        import time
+        deadline = time.monotonic() + comm_timeout_s()
+        pause = 1e-4
+        while not ev.query():
+            self._check_error()
+            if time.monotonic() > deadline:
+                if self.comm is not None:
+                    self.comm.abort()
+                _die("%s did not complete within %.0f s (DANHIP_COMM_TIMEOUT_S): a peer rank is gone or stuck" % (what, comm_timeout_s()))
+            time.sleep(pause)
+            pause = min(pause * 2, 0.05)
+        self._check_error()
+
+    def tick(self, stream_):
+        self._check_error()
+        if len(self.events) >= self.lag:
+            self.wait(self.events.pop(0), "the gradient exchange of an earlier step")
+        ev = torch.cuda.Event()
+        ev.record(stream_)
+        self.events.append(ev)
+
+    def drain(self):
+        """Before shutdown: every recorded step has finished (or the process ends)."""
+        while self.events:
+            self.wait(self.events.pop(0), "the gradient exchange of the last steps")
 
 
 @atexit.register
@@ -384,6 +551,10 @@ class GradBuckets(object):
             if not (dist.is_initialized() and dist.get_world_size() > 1):
                 raise RuntimeError("RCCL communicator unavailable and no process group to fall back to (DANHIP_FORCE_DIST on one rank)")
         self.device_collectives = self.enabled and (self.fake or self.rccl is not None)
+        # failure detection of the RCCL data plane (CommWatch): on whenever peers exist; DANHIP_COMM_WATCH=1 forces it for a one-rank
+        # communicator (tests), =0 switches it off
+        watch = os.environ.get("DANHIP_COMM_WATCH", "")
+        self.watch = CommWatch(self.rccl) if (self.rccl is not None and watch != "0" and (self.rccl.world > 1 or watch == "1")) else None
         self.comm_stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None     # (enable_local creates it for one-GPU runs)
         self.pending = []
         self.next_bucket = 0
@@ -515,6 +686,8 @@ class GradBuckets(object):
             w.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.watch is not None and not torch.cuda.is_current_stream_capturing():
+                self.watch.tick(self.comm_stream)    # (a captured step is watched at replay: DetectorTrainer._graph_step)
         if self.check:
             from . import ops
             for st in ops.wgrad_streams():
@@ -563,6 +736,10 @@ def init_distributed():
 def shutdown_distributed(*trainers):
     """Orderly end of a data-parallel job: captured graphs (they hold the collectives' kernel nodes) first, then the streams drain, then
     the RCCL communicator, then the control-plane process group."""
+    for tr in trainers:                              # (a dead peer would make the device waits below endless: the watchdog goes first)
+        w = getattr(getattr(tr, "buckets", None), "watch", None)
+        if w is not None:
+            w.drain()
     for tr in trainers:
         if tr is not None:
             tr.close()
@@ -571,5 +748,6 @@ def shutdown_distributed(*trainers):
     if RcclComm._shared is not None:
         RcclComm._shared.close()
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        control_barrier("at shutdown")
+        _control["group"], _control["made"] = None, False
         dist.destroy_process_group()

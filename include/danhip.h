@@ -522,6 +522,12 @@ int danhip_comm_unique_id(void* id128);                                /* host b
 int danhip_comm_create(const void* id128, int32_t nranks, int32_t rank, int32_t device, void** comm_out);
 int danhip_comm_destroy(void* comm);                                   /* after the streams that carry its collectives have drained */
 int danhip_comm_info(void* comm, int32_t* nranks, int32_t* rank, int32_t* device);
+/* Failure detection (ncclCommGetAsyncError / ncclCommAbort; ProcessGroupNCCL's watchdog did this from a background thread, here the
+ * CALLER polls): *err = 0 while the communicator is healthy, else the RCCL error code of a collective that failed asynchronously (a
+ * peer died, a link dropped) with its text in danhip_last_error().  danhip_comm_abort tears a communicator down WITHOUT waiting for
+ * its outstanding collectives (the only way out when a peer is gone; danhip_comm_destroy would wait for ever). */
+int danhip_comm_async_error(void* comm, int32_t* err);
+int danhip_comm_abort(void* comm);
 /* buf[i] = sum over ranks of buf[i], in place, asynchronous on stream */
 int danhip_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, void* stream);
 /* recv[0:recvcount] = sum over ranks of send[rank*recvcount : (rank+1)*recvcount]   (send holds nranks*recvcount elements; recv may be

@@ -6,7 +6,10 @@ mode "graph": as "dp", with the step captured as one hipGraph (bucketed all-redu
 mode "shards" (DDP_MODE=shards, one plain process): the same global batch cut into DDP_SHARDS contiguous shards; for each shard the
 gradient of loss_shard / N is computed from the SAME initial parameters (what one tower of tf_replicate_model_fn.py:297-302 computes) and
 saved, for the oracle's dp_step to aggregate.
-DDP_MODEL selects the graph: sfd | pb | dan | dan_deform."""
+DDP_MODEL selects the graph: sfd | pb | dan | dan_deform.
+With DANHIP_RCCL_PATH=tests/ddp/libfake_rccl.so (tests/ddp/fake_rccl.cpp: the nccl* entry points over shared memory, duplicate devices
+accepted) the SAME code runs the transport "rccl" with WORLD_SIZE > 1 ranks on one GPU: unique-id broadcast, ncclCommInitRank(N), the
+bucketed all-reduce / reduce-scatter + all-gather with real peers, eager or captured."""
 import os
 import sys
 
@@ -78,6 +81,9 @@ forced = os.environ.get("DANHIP_FORCE_DIST") == "1"
 assert tr.buckets.enabled == (world > 1 or forced)
 if forced:
     assert tr.buckets.device_collectives and tr.buckets.rccl is not None    # the library's own RCCL communicator: the weight-gradient stream stays on beside the buckets
+if os.environ.get("DDP_EXPECT_RCCL_RANKS"):                                 # the stand-in library: a REAL multi-rank communicator behind danhip_comm_*
+    assert tr.buckets.transport == "rccl" and tr.buckets.rccl.world == int(os.environ["DDP_EXPECT_RCCL_RANKS"]) == world, (tr.buckets.transport, world)
+    assert tr.buckets.rccl.version == 29999 and tr.buckets.watch is not None
 w0 = tr.flat.w.clone()
 if mode == "graph":                                      # the data-parallel step (bucketed all-reduce included) replayed as ONE hipGraph
     tr.enable_graph(*args_of(sl), warmup=1)
@@ -90,6 +96,13 @@ if mode == "graph":                                      # the data-parallel ste
     sys.exit(0)
 tr.train_step(*args_of(sl))
 torch.cuda.synchronize()
+if os.environ.get("DDP_DIE_RANK"):                      # failure-detection test: one rank leaves without a word, the other keeps stepping
+    if rank == int(os.environ["DDP_DIE_RANK"]):
+        os._exit(17)
+    for _ in range(int(os.environ.get("DDP_STEPS", "6"))):
+        tr.train_step(*args_of(sl))
+    torch.cuda.synchronize()                             # (never reached: CommWatch ends the process first)
+    sys.exit(1)
 g1, w1 = tr.flat.g.clone(), tr.flat.w.clone()
 loss1 = tr.loss_values()["total"] - tr.loss_values()["l2"]
 tr.train_step(*args_of(sl))

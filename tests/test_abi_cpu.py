@@ -584,3 +584,70 @@ def test_ops_steering_state_lives_in_a_context_object(monkeypatch):
     ops.SOME_NEW_MODULE_ATTRIBUTE = 3                           # anything that is not a context field stays an ordinary module attribute
     assert vars(ops)["SOME_NEW_MODULE_ATTRIBUTE"] == 3
     del ops.SOME_NEW_MODULE_ATTRIBUTE
+
+
+# ---- the RCCL bootstrap cannot hang a job: tests/ddp/fake_rccl.cpp stands in for librccl; its
+# ncclCommInitRank needs no GPU, and with FAKE_RCCL_INIT_HANG=1 it waits for its peers for ever, as the real one does.
+BOOTSTRAP_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from dan_amd import trainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+scenario = os.environ["SCENARIO"]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+if scenario == "dies_before_bootstrap" and rank == 1:
+    os._exit(17)                                     # gone before anybody reaches the communicator
+if scenario == "never_calls_create" and rank == 1:
+    real = trainer.call
+    def stuck(name, *a):
+        if name == "danhip_comm_create":
+            time.sleep(1000)                         # alive, but never enters ncclCommInitRank
+        return real(name, *a)
+    trainer.call = stuck
+comm = trainer.RcclComm.shared_or_none(torch.device("cpu"))
+assert scenario == "healthy", "a rank got past a bootstrap that cannot complete"
+import ctypes
+n, r, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+trainer.call("danhip_comm_info", comm.handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d))
+assert (n.value, r.value) == (world, rank) and comm.version == 29999 and comm.async_error() == 0
+comm.close()
+trainer.shutdown_distributed()
+print("bootstrap ok", rank)
+'''
+
+
+def _bootstrap(tmp_path, scenario, hang):
+    import time
+    from tests_ddp_paths import FAKE_RCCL
+    script = tmp_path / "b.py"
+    script.write_text(BOOTSTRAP_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", SCENARIO=scenario, DANHIP_RCCL_PATH=FAKE_RCCL,
+               DANHIP_COMM_TIMEOUT_S="6", FAKE_RCCL_INIT_HANG="1" if hang else "0", DANHIP_DP_NO_FALLBACK="1")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    return procs, outs, time.time() - t0
+
+
+def test_two_ranks_bootstrap_a_communicator_through_the_stand_in_library(tmp_path):
+    """unique id on rank 0 -> (ok, id) broadcast over the control plane -> ncclCommInitRank(2) under its deadline -> info / async error /
+    destroy -> orderly shutdown, on CPU (no collective: those need a device)."""
+    procs, outs, _ = _bootstrap(tmp_path, "healthy", hang=False)
+    assert all(p.returncode == 0 for p in procs) and all("bootstrap ok" in o for o in outs), outs
+
+
+def test_a_rank_that_never_enters_comm_create_ends_the_job_within_the_deadline(tmp_path):
+    """One rank is alive but never calls danhip_comm_create; the other waits inside ncclCommInitRank, which (like the real library) has
+    no timeout of its own: after DANHIP_COMM_TIMEOUT_S every rank ends with trainer.DEADLINE_EXIT_CODE and says why."""
+    procs, outs, took = _bootstrap(tmp_path, "never_calls_create", hang=True)
+    assert [p.returncode for p in procs] == [75, 75], outs
+    assert all("FATAL" in o and "ncclCommInitRank" in o and "did not return within" in o for o in outs), outs
+    assert took < 60, took
+
+
+def test_a_rank_that_died_before_the_bootstrap_is_noticed_at_the_control_barrier(tmp_path):
+    procs, outs, took = _bootstrap(tmp_path, "dies_before_bootstrap", hang=True)
+    assert procs[1].returncode == 17 and procs[0].returncode == 75, outs
+    assert "FATAL" in outs[0] and "control-plane barrier" in outs[0], outs
+    assert took < 60, took
