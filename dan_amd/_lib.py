@@ -51,6 +51,9 @@ SIGNATURES = {
     "danhip_conv2d_fwd_ws": [DESC, P, P, P, P, ctypes.c_int, ctypes.c_int, P, P, ctypes.c_size_t, P],
     "danhip_conv2d_fwd_f32": [DESC, P, P, P, P, ctypes.c_int, P, P],
     "danhip_maxpool2x2_fwd_f32": [P, P, I32, I32, I32, I32, P],
+    "danhip_split3_f32": [P, P, I64, I32, I32, ctypes.c_int, P],
+    "danhip_unsplit3_f32": [P, P, I64, I32, I32, P],
+    "danhip_maxpool2x2_split3": [P, P, I32, I32, I32, I32, P],
     "danhip_l2norm_fwd_f32": [P, P, P, I64, I32, P],
     "danhip_resize_bilinear_add_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, P],
     "danhip_avgpool2x2s1_same_fwd_f32": [P, P, I32, I32, I32, I32, P],
@@ -148,15 +151,41 @@ def lib():
     """Loads libdanhip.so; raises loudly when it is missing (no CPU / eager fallback exists)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise DanhipError("libdanhip.so not found at %s — run `python -m dan_amd.build` (there is no fallback path)" % SO_PATH)
-        L = ctypes.CDLL(SO_PATH)
+        _lib = _load(SO_PATH, ACT_NAME)
+    return _lib
+
+
+_lib_f16 = None
+
+
+def lib_f16():
+    """The fp16 build (libdanhip_f16.so) whatever DANHIP_DTYPE says: the split-operand evaluation path (csrc/split_infer.hip) runs its
+    three-limb-product convolutions on v_mfma_f32_16x16x32_f16 also inside a bf16 process.  The two libraries share nothing (separate
+    option tables, error strings, RCCL binding); this one is used for forward convolutions and weight packing only."""
+    global _lib_f16
+    if _lib_f16 is None:
+        _lib_f16 = lib() if ACT_NAME == "fp16" else _load(os.path.join(_HERE, "libdanhip_f16.so"), "fp16")
+    return _lib_f16
+
+
+def call_f16(name, *args):
+    L = lib_f16()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise DanhipError("%s (fp16 build) failed (%d): %s" % (name, rc, L.danhip_last_error().decode()))
+
+
+def _load(so_path, act_name):
+    if True:
+        if not os.path.exists(so_path):
+            raise DanhipError("libdanhip.so not found at %s — run `python -m dan_amd.build` (there is no fallback path)" % so_path)
+        L = ctypes.CDLL(so_path)
         L.danhip_last_error.restype = ctypes.c_char_p
         L.danhip_last_error.argtypes = []
         L.danhip_version.restype = ctypes.c_int
         L.danhip_act_dtype.restype = ctypes.c_int
-        if L.danhip_act_dtype() != (2 if ACT_NAME == "fp16" else 1):
-            raise DanhipError("%s was built for another activation dtype than DANHIP_DTYPE=%s" % (SO_PATH, ACT_NAME))
+        if L.danhip_act_dtype() != (2 if act_name == "fp16" else 1):
+            raise DanhipError("%s was built for another activation dtype than %s" % (so_path, act_name))
         L.danhip_match_workspace_bytes.restype = ctypes.c_size_t
         L.danhip_conv_kernel_label.restype = ctypes.c_char_p
         L.danhip_conv_kernel_label.argtypes = [DESC, ctypes.c_int]
@@ -199,8 +228,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.restype = ctypes.c_int
             fn.argtypes = args
-        _lib = L
-    return _lib
+    return L
 
 
 def check(rc, what):

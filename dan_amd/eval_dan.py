@@ -22,9 +22,10 @@ class Detector(object):
 
     def __init__(self, model, anchor_config_fn, precision="act"):
         """precision: "act" = the library build's 16-bit activations (fast path, 3 k img/s); "fp32" = the fp32 inference kernels end to end,
-        the path whose box outputs agree with an fp32 reference to 1e-4 (tests/test_eval_f32_gpu.py)."""
-        if precision not in ("act", "fp32"):
-            raise ValueError("precision must be 'act' or 'fp32'")
+        the path whose box outputs agree with an fp32 reference to 1e-4 (tests/test_eval_f32_gpu.py); "split" = the same graph with every
+        convolution as a split-operand product on the fp16 MFMA (csrc/split_infer.hip): the same bound at about three times the fp32 path's rate."""
+        if precision not in ("act", "fp32", "split"):
+            raise ValueError("precision must be 'act', 'fp32' or 'split'")
         self.model = model
         self.model.precision = precision
         self.anchor_config_fn = anchor_config_fn

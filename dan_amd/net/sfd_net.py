@@ -156,10 +156,27 @@ class VGG16Backbone(object):
         return self.predict_heads(feature_layers, pos_maxout, neg_maxout, num_anchors_depth_per_layer, "multibox_head")
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def precision_scope(precision):
+    """precision "split": the fp32 inference path with its convolutions as split-operand products on the fp16 MFMA (ops.SPLIT_EVAL,
+    csrc/split_infer.hip) for the duration of the forward pass; anything else leaves the ops' context alone."""
+    ctx = ops.context()
+    prev = ctx.SPLIT_EVAL
+    ctx.SPLIT_EVAL = precision == "split"
+    try:
+        yield
+    finally:
+        ctx.SPLIT_EVAL = prev
+
+
 def prepare_input(img_u8_rgb, precision="act"):
     """uint8 RGB [B,H,W,3] (device) -> network input.  precision "act": the build's 16-bit activation type (training and fast inference);
-    "fp32": the fp32 inference path (ops._f32_infer: every layer then runs the fp32 kernels)."""
-    if precision == "fp32":
+    "fp32": the fp32 inference path (ops._f32_infer: every layer then runs the fp32 kernels); "split": fp32 maps between the ops as in
+    "fp32", convolutions as three-limb-product half convolutions (inside precision_scope)."""
+    if precision in ("fp32", "split"):
         return ops.preprocess_f32(img_u8_rgb)
     x = ops.preprocess_u8(img_u8_rgb)
     x._real_channels = 3

@@ -36,12 +36,14 @@ class OpsContext(object):
       POOL_ONLY_TRAIN  [DANHIP_POOL_ONLY_TRAIN, 1]  0: the training forward of a conv whose only consumer is a fused pool still writes its map
       KEEP_DEFORM_COL  False: the deformable backward re-samples the im2col buffer as the reference does instead of keeping the forward's
       WGRAD_STREAM     [DANHIP_WGRAD_STREAM, 1]  0: weight gradients on the data gradients' stream
+      SPLIT_EVAL       True: convolutions of the fp32 inference path run as split-operand products on the fp16 MFMA (csrc/split_infer.hip;
+                       models set it for precision "split"): fp32-accurate boxes at a third of the 16-bit rate instead of a tenth
     Diagnostic sinks (None = off): TRACE (tests: activations / decisions by variable id), PROFILE / PROFILE_BYTES (bench.py: HIP events
     and algorithmic bytes per convolution launch).
     Per-step state a trainer arms: GRAD_READY_HOOK (a parameter's gradient is final), LOSS_SCALE_DEV (device scalar of the dynamic loss
     scale), wgrad (the second backward stream: {"on", "side", "main", "keep"})."""
-    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "TRACE", "PROFILE",
-                 "PROFILE_BYTES", "GRAD_READY_HOOK", "LOSS_SCALE_DEV", "wgrad")
+    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "SPLIT_EVAL", "TRACE",
+                 "PROFILE", "PROFILE_BYTES", "GRAD_READY_HOOK", "LOSS_SCALE_DEV", "wgrad")
 
     def __init__(self, **overrides):
         env = os.environ.get
@@ -52,6 +54,7 @@ class OpsContext(object):
         self.POOL_ONLY_TRAIN = env("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
         self.KEEP_DEFORM_COL = True
         self.WGRAD_STREAM = env("DANHIP_WGRAD_STREAM", "1") == "1"
+        self.SPLIT_EVAL = False
         self.TRACE = self.PROFILE = self.PROFILE_BYTES = None
         self.GRAD_READY_HOOK = self.LOSS_SCALE_DEV = None
         self.wgrad = {"on": False, "side": None, "main": None, "keep": []}
@@ -220,7 +223,10 @@ def _prof_begin(st=None):
     return e
 
 
-def _prof_end(e0, d, which, st=None):
+def _prof_end(e0, d, which, st=None, wrote_y=True, pooled=False):
+    """wrote_y = False: a pool-only launch (the full-resolution map is never stored); pooled: the launch also stores the 2x2-pooled map.
+    Both only change the ALGORITHMIC byte count of the launch (conv1_2 / conv2_2 were credited the 839 / 419 MB map
+    they no longer write, which filed an MFMA-bound launch under the HBM-bound ones)."""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
@@ -234,7 +240,8 @@ def _prof_end(e0, d, which, st=None):
     _CTX.PROFILE.setdefault(label, []).append((e0, e1, flops))
     if _CTX.PROFILE_BYTES is not None:            # algorithmic HBM bytes: activations in + out (16-bit; the heads write fp32), weights once
         co8 = (d.Cout + 7) // 8 * 8
-        nbytes = 2.0 * d.N * (d.H * d.W * cin + d.Ho * d.Wo * co8) + 2.0 * d.kh * d.kw * cin * d.Cout
+        out_px = (d.Ho * d.Wo if wrote_y else 0) + (((d.Ho + 1) // 2) * ((d.Wo + 1) // 2) if pooled else 0)
+        nbytes = 2.0 * d.N * (d.H * d.W * cin + out_px * co8) + 2.0 * d.kh * d.kw * cin * d.Cout
         _CTX.PROFILE_BYTES.setdefault(label, []).append(nbytes)
 
 
@@ -419,7 +426,7 @@ class _Conv2d(torch.autograd.Function):
             pooled = torch.empty((N, (d.Ho + 1) // 2, (d.Wo + 1) // 2, cout), dtype=ACT, device=x.device)
             e0 = _prof_begin()
             call("danhip_conv2d_fwd_pool", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()), None, ptr(pooled), stream())
-            _prof_end(e0, d, 4)
+            _prof_end(e0, d, 4, wrote_y=False, pooled=True)
             pooled._dh_already_pooled = True
             return pooled
         # pool_only == 2 (training): nothing but the fused pool reads this activation, and backward reaches it only through the pool's arg-max
@@ -464,7 +471,7 @@ class _Conv2d(torch.autograd.Function):
             ws, nws = _conv_scratch(d, 0, x.device)
             call("danhip_conv2d_fwd_ws", ctypes.byref(d), ptr(x), ptr(wf), ptr(b.detach()) if b is not None else None, ptr(y),
                  F32 if out_f32 else BF16, int(relu), ptr(residual), ptr(ws), nws, stream())
-        _prof_end(e0, d, 4 if pool_out is not None else 0)
+        _prof_end(e0, d, 4 if pool_out is not None else 0, wrote_y=not skip_y, pooled=pool_out is not None)
         ctx.d, ctx.relu, ctx.cin_real = d, relu, cin_real
         ctx.xslot, ctx.yslot, ctx.xbits = xslot, yslot, xbits
         ctx.set_materialize_grads(False)
@@ -597,11 +604,69 @@ def _conv2d_f32(x, w, b, stride, relu, residual, padding):
     return y
 
 
+# ---- split-operand inference (csrc/split_infer.hip): the fp32 path's convolutions at the 16-bit MFMA rate.  fp32 NHWC tensors stay the
+# currency between ops (every non-convolution op is the fp32 path's); a convolution takes its input in the 3C half layout [hi | lo | hi]
+# — from the producing convolution's epilogue when it left one behind (`_dh_split3`), else converted here — and runs the fp16 build's
+# ordinary kernels over 3C input channels with weights [hi | hi | lo].
+_SPLIT_W = {}                # id(variable) -> (stamp, weakref, packed fp16 weights): evaluation weights are static, packed once
+
+
+def _split_weight(d3, w, cin):
+    """HWIO fp32 [kh, kw, cin, cout] -> the fp16 build's forward packing of [w_hi | w_hi | w_lo | 0] over d3.Cin = 3 cin (+ padding) channels."""
+    import weakref
+    key = id(w)
+    stamp = (WEIGHT_EPOCH, w._version, w.data_ptr(), d3.Cin)
+    e = _SPLIT_W.get(key)
+    if e is not None and e[0] == stamp and e[1]() is w:
+        return e[2]
+    wd = w.detach().float()
+    hi = wd.half().float()
+    lo = (wd - hi).half().float()
+    w3 = torch.cat([hi, hi, lo], dim=2).contiguous()
+    r, c = ctypes.c_int64(), ctypes.c_int64()
+    _lib.call_f16("danhip_conv_packed_dims", ctypes.byref(d3), 0, ctypes.byref(r), ctypes.byref(c))
+    wf = torch.empty((r.value, c.value), dtype=torch.float16, device=w.device)
+    _lib.call_f16("danhip_pack_conv_weight", ctypes.byref(d3), ptr(w3), 3 * cin, ptr(wf), None, stream())
+    if isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad"):        # (a per-call concatenation of head kernels is not worth caching)
+        _SPLIT_W[key] = (stamp, weakref.ref(w, lambda _r, k=key: _SPLIT_W.pop(k, None)), wf)
+    return wf
+
+
+def split3(x):
+    """fp32 NHWC [.., C] -> IEEE-half [.., C3] = [hi | lo | hi | 0-padding], C3 = 3C rounded up to 8 (cached on the tensor)."""
+    x3 = getattr(x, "_dh_split3", None)
+    if x3 is None:
+        C = x.shape[-1]
+        C3 = (3 * C + 7) // 8 * 8
+        x3 = torch.empty(x.shape[:-1] + (C3,), dtype=torch.float16, device=x.device)
+        call("danhip_split3_f32", ptr(x.contiguous()), ptr(x3), x.numel() // C, C, C3, 0, stream())
+    return x3
+
+
+def _conv2d_split(x, w, b, stride, relu, residual, padding):
+    N, H, W, C = x.shape
+    kh, kw, cin, cout = w.shape
+    assert cin == C, "split conv: input channels must match the kernel"
+    x3 = split3(x)
+    d3 = _desc(N, H, W, x3.shape[-1], cout, kh, kw, stride, padding == "valid")
+    wf = _split_weight(d3, w, cin)
+    y = torch.empty((N, d3.Ho, d3.Wo, cout), dtype=torch.float32, device=x.device)
+    n = _lib.lib_f16().danhip_conv2d_workspace_bytes(ctypes.byref(d3), 0) if -(-(N * d3.Ho * d3.Wo) // 128) * -(-cout // 128) <= 160 else 0
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device) if n else None
+    _lib.call_f16("danhip_conv2d_fwd_ws", ctypes.byref(d3), ptr(x3), ptr(wf), ptr(b.detach().float()) if b is not None else None, ptr(y), F32, int(relu),
+                  None, ptr(ws), n, stream())
+    if residual is not None:                             # (added after the activation, as the 16-bit kernels' fused residual is)
+        y.add_(residual)
+    return y
+
+
 def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, pool=False, padding="same", pool_only=False):
     """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up.
     pool_only=True (with pool, no gradient tracked): the caller promises that ONLY the pooled map is used - where the kernel pools in its
     epilogue the full-resolution activation is never written and the POOLED tensor is returned (ops.max_pool_2x2 passes it through)."""
     if _f32_infer(x):
+        if _CTX.SPLIT_EVAL:
+            return _conv2d_split(x, w, b, stride, relu, residual, padding)
         return _conv2d_f32(x, w, b, stride, relu, residual, padding)
     # a plain tensor carrying a gradient sink is a fused block of parameters (FlatParams): cached packing, gradients written in place
     wp = w if (isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad")) else None
@@ -1606,7 +1671,7 @@ def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_gr
         S = torch.empty((N, Ho, Wo, kh * kw * C), dtype=torch.float32, device=x.device)
         call("danhip_deform_sample_fwd_f32", ptr(x.contiguous()), ptr(offsets.contiguous()), ptr(S), N, H, W, C, kh, kw, stride, dilation, deformable_group,
              stream())
-        return _conv2d_f32(S, w1x1, b, 1, relu, None, "same")
+        return (_conv2d_split if _CTX.SPLIT_EVAL else _conv2d_f32)(S, w1x1, b, 1, relu, None, "same")
     bp = b if isinstance(b, torch.nn.Parameter) else None
     wp = w1x1 if hasattr(w1x1, "_danhip_grad") else None
     track = torch.is_grad_enabled() and (x.requires_grad or w1x1.requires_grad or offsets.requires_grad or _sink_trainable(w1x1))

@@ -27,18 +27,20 @@ class DANModel(object):
 
     def forward(self, images_u8):
         """train_dan.py:410-428 -> ((loc1 [B,A,4], cls1 [B,A,2]), (loc2, cls2), feature map sizes)."""
-        b = self.backbone
-        x = sfd_net.prepare_input(images_u8, getattr(self, "precision", "act"))
-        feats = b.get_featmaps(x, training=True)
-        feats = b.build_lfpn(feats, skip_last=3)
-        s1 = b.get_features_stage1(feats, name="prediction_modules_stage1")
-        s1 = b.build_lfpn(s1, skip_last=3, name="lfpn_stage1")
-        n = len(feats)
-        stage1 = b.get_predict_module(s1, [1] * n, [1] * n, [1] * n, name="predict_face")
-        s2 = b.get_features_stage2(s1, feats, name="prediction_modules_stage2")
-        s2 = b.build_lfpn(s2, skip_last=3, name="lfpn_stage2")
-        stage2 = b.get_predict_module(s2, [1] * n, [3] + [1] * (n - 1), [1] * n, name="predict_cascade")
-        return stage1, stage2, [(f.shape[1], f.shape[2]) for f in feats]
+        prec = getattr(self, "precision", "act")
+        with sfd_net.precision_scope(prec):
+            b = self.backbone
+            x = sfd_net.prepare_input(images_u8, prec)
+            feats = b.get_featmaps(x, training=True)
+            feats = b.build_lfpn(feats, skip_last=3)
+            s1 = b.get_features_stage1(feats, name="prediction_modules_stage1")
+            s1 = b.build_lfpn(s1, skip_last=3, name="lfpn_stage1")
+            n = len(feats)
+            stage1 = b.get_predict_module(s1, [1] * n, [1] * n, [1] * n, name="predict_face")
+            s2 = b.get_features_stage2(s1, feats, name="prediction_modules_stage2")
+            s2 = b.build_lfpn(s2, skip_last=3, name="lfpn_stage2")
+            stage2 = b.get_predict_module(s2, [1] * n, [3] + [1] * (n - 1), [1] * n, name="predict_cascade")
+            return stage1, stage2, [(f.shape[1], f.shape[2]) for f in feats]
 
     @torch.no_grad()
     def predict(self, images_u8, anchors, select_thres=0.03):

@@ -16,16 +16,18 @@ class PBModel(object):
     def forward(self, images_u8):
         """train_pb.py:396-420: {'face','head','body'} -> (location_pred [B,A_k,4], cls_pred [B,A_k,2]); the head / body
         heads predict on levels 1.. / 2.. (A_head = 8 525, A_body = 2 125 at 640x640)."""
-        b = self.backbone
-        x = sfd_net.prepare_input(images_u8, getattr(self, "precision", "act"))
-        feats = b.get_featmaps(x, training=True)
-        feats = b.build_lfpn(feats, skip_last=3)
-        feats = b.context_pred_module(feats)
-        n = len(feats)
-        face = b.get_predict_module(feats, [1] + [3] * (n - 1), [3] + [1] * (n - 1), [1] * n, name="predict_face")
-        head = b.get_predict_module(feats[1:], [1] * (n - 1), [1] * (n - 1), [1] * (n - 1), name="predict_head")
-        body = b.get_predict_module(feats[2:], [1] * (n - 2), [1] * (n - 2), [1] * (n - 2), name="predict_body")
-        return {"face": face, "head": head, "body": body}
+        prec = getattr(self, "precision", "act")
+        with sfd_net.precision_scope(prec):
+            b = self.backbone
+            x = sfd_net.prepare_input(images_u8, prec)
+            feats = b.get_featmaps(x, training=True)
+            feats = b.build_lfpn(feats, skip_last=3)
+            feats = b.context_pred_module(feats)
+            n = len(feats)
+            face = b.get_predict_module(feats, [1] + [3] * (n - 1), [3] + [1] * (n - 1), [1] * n, name="predict_face")
+            head = b.get_predict_module(feats[1:], [1] * (n - 1), [1] * (n - 1), [1] * (n - 1), name="predict_head")
+            body = b.get_predict_module(feats[2:], [1] * (n - 2), [1] * (n - 2), [1] * (n - 2), name="predict_body")
+            return {"face": face, "head": head, "body": body}
 
     @torch.no_grad()
     def predict(self, images_u8, anchors):

@@ -59,9 +59,10 @@ class SFDModel(object):
         """train_sfd.py:286-304: returns (location_pred [B,A,4], cls_pred [B,A,2]) fp32."""
         prec = getattr(self, "precision", "act")
         self.backbone.fp32_heads = prec == "mixed"          # 16-bit backbone, fp32 L2-norm taps + heads (inference only)
-        x = sfd_net.prepare_input(images_u8, "fp32" if prec == "fp32" else "act")
-        feats = self.backbone.get_featmaps(x, training=True)
-        return self.backbone.multibox_head(feats, [1] * 6, [3] + [1] * 5, [1] * 6)
+        with sfd_net.precision_scope(prec):
+            x = sfd_net.prepare_input(images_u8, prec if prec in ("fp32", "split") else "act")
+            feats = self.backbone.get_featmaps(x, training=True)
+            return self.backbone.multibox_head(feats, [1] * 6, [3] + [1] * 5, [1] * 6)
 
     @torch.no_grad()
     def predict(self, images_u8, anchors):

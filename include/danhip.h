@@ -15,7 +15,10 @@
  *   - every tensor pointer is a caller-owned DEVICE pointer (16-byte aligned); nothing is allocated
  *     inside; scratch comes from a caller-supplied workspace where a *_workspace_bytes() query exists.
  *   - every call takes a hipStream_t (passed as void*) and is asynchronous on it; no host sync.
- *   - re-entrant and thread-safe: no mutable globals.
+ *   - re-entrant and thread-safe.  The ONE piece of process-wide mutable state is the table of kernel-FORM switches behind
+ *     danhip_set_option (below): filled from the environment exactly once, every value an atomic, read once per call by a launcher;
+ *     whatever it says, results agree up to fp32 summation order.  (Bound once and read-only afterwards: the RCCL entry points of
+ *     danhip_comm_*.)  Nothing else outlives a call.
  *   - activations are NHWC, 16-bit, passed as raw uint16.  The 16-bit type is a property of the library build:
  *     libdanhip.so = bf16 (default; every "bf16" below), libdanhip_f16.so = IEEE fp16 (same entry points, same layouts,
  *     v_mfma_f32_16x16x32_f16; BASELINE.json configs[4] "fp16 + MFMA").  danhip_act_dtype() tells which one is loaded;
@@ -535,6 +538,16 @@ int danhip_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, v
 int danhip_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t recvcount, int dtype, void* stream);
 /* recv[r*sendcount : (r+1)*sendcount] = rank r's send   (send may be the caller's slice of recv: in place) */
 int danhip_comm_allgather(void* comm, const void* send, void* recv, int64_t sendcount, int dtype, void* stream);
+
+/* ---- split-operand inference (csrc/split_infer.hip): fp32-accurate evaluation at the 16-bit MFMA rate, for the same north-star bound as the
+ * fp32 path below (eval_dan.py:299-404 box outputs within 1e-4).  An fp32 map [M, C] is carried as IEEE-half limbs in a 3C-channel NHWC
+ * map X3 = [hi | lo | hi] (hi = half(x), lo = half(x - hi)), C3 = 3C rounded up to 8; with weights W3 = [hi | hi | lo] along Cin the
+ * ordinary 16-bit convolution of the fp16 build (libdanhip_f16.so: danhip_conv2d_fwd with Cin = C3, fp32 output) computes
+ * hi.hi + lo.hi + hi.lo with exact products and fp32 accumulation.  These entry points are identical in both builds (always IEEE half).
+ * relu != 0: max(x, 0) first.  danhip_maxpool2x2_split3: tf.layers.max_pooling2d([2,2],[2,2],'same') on the 3C layout (C % 8 == 0). */
+int danhip_split3_f32(const float* x, uint16_t* y3, int64_t M, int32_t C, int32_t C3, int relu, void* stream);
+int danhip_unsplit3_f32(const uint16_t* x3, float* y, int64_t M, int32_t C, int32_t C3, void* stream);
+int danhip_maxpool2x2_split3(const uint16_t* x3, uint16_t* y3, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 
 /* ---- fp32 inference path (csrc/f32_infer.hip): the evaluation graphs of eval_sfd.py:232-283 / eval_pb.py / eval_dan.py:299-404 with fp32
  * storage and arithmetic end to end, for the north-star tolerance "eval box outputs within 1e-4 of the reference".  NHWC fp32

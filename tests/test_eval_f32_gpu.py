@@ -50,6 +50,10 @@ def _box_bad(got, ref):
 @pytest.mark.parametrize("h,w", SIZES)
 @pytest.mark.parametrize("which", ["sfd", "pb"])
 def test_single_stage_eval_boxes_fp32(which, h, w, dev):
+    single_stage_case(which, h, w, dev, "fp32")
+
+
+def single_stage_case(which, h, w, dev, precision):
     from dan_amd import synthetic
     from dan_amd.train_pb import PBModel
     from dan_amd.train_sfd import AnchorConfig, SFDModel
@@ -61,7 +65,7 @@ def test_single_stage_eval_boxes_fp32(which, h, w, dev):
         loc_r, cls_r = ofwd(ON.Params(P.t), x)
     model = (SFDModel if which == "sfd" else PBModel)(device=dev)
     model.vs.load_tf_named(P.t)
-    model.precision = "fp32"
+    model.precision = precision
     anchors = AnchorConfig(h, w, dev)
     with torch.no_grad():
         out = model.forward(imgs.to(dev))
@@ -84,7 +88,7 @@ def test_dan_eval_boxes_fp32(deform, h, w, dev):
     dan_eval_case(deform, h, w, dev)
 
 
-def dan_eval_case(deform, h, w, dev, logits16_tol=None):
+def dan_eval_case(deform, h, w, dev, logits16_tol=None, precision="fp32"):
     """One image through the DAN evaluation graph on the fp32 path against the oracle (logits, stage-1 boxes, routed stage-2 boxes, scores);
     logits16_tol: also compare the 16-bit path's four logit tensors at that fraction of the reference scale (tests/test_size_1024_gpu.py)."""
     from dan_amd import synthetic
@@ -105,7 +109,7 @@ def dan_eval_case(deform, h, w, dev, logits16_tol=None):
             err = (got.float().cpu() - want).abs().max().item()
             assert err <= logits16_tol * want.abs().max().item(), (name, err, want.abs().max().item())
         del a1, b1, a2, b2
-    model.precision = "fp32"
+    model.precision = precision
     with torch.no_grad():
         (l1, c1), (l2, c2), sizes = model.forward(imgs.to(dev))
         boxes, scores = model.predict(imgs.to(dev), anchors)
