@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--strong-global-batch", type=int, default=128,
                     help="global batch of the strong-scaling leg printed beside the weak line (BASELINE.json configs[2]: 128 = 16 images per GPU "
                          "at 8 GPUs); each rank takes global/N images as 16-image towers (train_step_towers); 0 = skip the leg")
+    ap.add_argument("--strong16-global-batch", type=int, default=16,
+                    help="SURVEY 8(e)'s own strong series: 'S3FD 16 -> 2 per rank' - a fixed global batch of 16 on the N ranks, 16 / N images per "
+                         "rank as one tower (tf_replicate_model_fn.py:458-498); 0 = skip")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of K steps each (the first one is `value`; all of them are in `repeats`)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -398,6 +401,34 @@ def main():
                               "16-image towers into one gradient buffer (tf_replicate_model_fn.py:504-560), one bucketed all-reduce + one "
                               "optimizer step per global batch; speed-up over N = value(N) / value(1) of THIS field"}
             del towers
+    # ---- SURVEY 8(e)'s strong series (the `strong` leg above keeps 16-image towers, so at N = 8 it is the weak line again):
+    # a FIXED global batch of 16 = BASELINE.json configs[1]'s batch, 16 / N images per rank (S3FD 16 -> 2 at N = 8), one bucketed all-reduce +
+    # one optimizer step per global batch.  At N = 1 the shard IS the weak line's batch: its region is quoted, nothing is re-run.
+    strong16 = None
+    G16 = args.strong16_global_batch
+    if G16 and not args.global_batch and G16 % world == 0:
+        per16 = G16 // world
+        what16 = ("fixed global batch of %d (SURVEY 8e: S3FD 16 -> 2 per rank at 8 GPUs): every rank trains on its %d-image contiguous shard, one "
+                  "bucketed all-reduce + one optimizer step per global batch; speed-up over N = value(N) / value(1) of THIS field" % (G16, per16))
+        if per16 == B and world == 1:
+            strong16 = {"scaling": "strong", "global_batch": G16, "n_gpus": 1, "batch_per_gpu": per16, "steps": args.steps, "step_launch": "hipGraph replay" if args.graph else "eager",
+                        "ms_per_step": round(dt / args.steps * 1e3, 3), "value": round(G16 * args.steps / dt, 3), "unit": "images/sec",
+                        "what": what16 + " (N = 1: the timed region of `value` itself)"}
+        elif trainer._graph is None:
+            seed16 = synthetic.SEED + 2000 + rank
+            a16 = args_of(synthetic.make_images(per16, S, S, dev, seed=seed16), synthetic.make_gt_boxes(per16, S, S, seed=seed16 + 50000))
+            for _ in range(3):
+                trainer.train_step(*a16)
+            barrier()
+            k16 = max(4, min(4 * args.steps, args.steps * B // max(1, per16)))
+            s0 = time.perf_counter()
+            for _ in range(k16):
+                trainer.train_step(*a16)
+            barrier()
+            (sdt,) = max_over_ranks(time.perf_counter() - s0)
+            strong16 = {"scaling": "strong", "global_batch": G16, "n_gpus": world, "batch_per_gpu": per16, "steps": k16, "step_launch": "eager",
+                        "ms_per_step": round(sdt / k16 * 1e3, 3), "value": round(G16 * k16 / sdt, 3), "unit": "images/sec", "what": what16}
+            del a16
     dt, dt_prof = max_over_ranks(dt, dt_prof)
     region_dts = list(max_over_ranks(*region_dts))
 
@@ -559,7 +590,7 @@ def main():
                         "min_ms_per_step": round(min(region_dts) / args.steps * 1e3, 3),
                         "median_ms_per_step": round(sorted(region_dts)[len(region_dts) // 2] / args.steps * 1e3, 3),
                         "value_at_median": round(world * B * args.steps / sorted(region_dts)[len(region_dts) // 2], 3)},
-            "strong": strong,
+            "strong": strong, "strong16": strong16,
             "loss": {"ce": round(ce, 4), "loc": round(ll, 4), "l2": round(l2, 4)},
             "roofline": roof,
             "kernels": [{"kernel": l, "ms_per_step": round(m / prof_steps, 3), "tflops": round(f / (m * 1e-3) / 1e12, 1)} for m, l, _, f in stats[:6]],

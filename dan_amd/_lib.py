@@ -18,6 +18,7 @@ if os.environ.get("DANHIP_LIB_PATH"):          # diagnosis: A/B another in-tree 
     SO_PATH = os.path.abspath(os.environ["DANHIP_LIB_PATH"])
 
 F32, BF16 = 0, 1      # BF16 = "the build's 16-bit activation type" in out_dtype arguments
+SPLIT3 = 3            # fp16 build, forward convolutions: the [hi | lo | hi] half-limb layout of csrc/split_infer.hip
 
 
 class ConvDesc(ctypes.Structure):

@@ -35,7 +35,22 @@ struct ConvArgs {
   // (appended last: the layout of everything above is what the tuned kernels were built against)
   const bf16_t* x2;   // conv_pointwise.hip, forward 1x1: second source of the K axis (channels ksplit*64 .. C-1 of the virtual input [x | x2], same
   int ksplit;         // pixel pitch ldx as x); null = one source.  Only danhip_conv2d_fwd_concat2 sets them.
+  // Split-operand evaluation (csrc/split_infer.hip; fp16 build, forward, Co % 8 == 0): y is the 3-limb-layout map [M][3 Co] of the NEXT
+  // convolution — hi = half(v) at column co, lo = half(v - hi) at Co + co, hi again at 2 Co + co — written from the fp32 epilogue value.
+  // Honoured by conv_halo.hip's general epilogue and by the flat-M kernel / split-K finish (conv_store4); every other kernel declines.
+  int split_out;
 };
+
+// hi / lo limbs of 4 fp32 values as two packed pairs each (the build's 16-bit type: IEEE half where split_out is allowed)
+__device__ __forceinline__ void dh_split4(const float v[4], uint2& hi, uint2& lo) {
+  hi.x = pack2bf(v[0], v[1]);
+  hi.y = pack2bf(v[2], v[3]);
+  float h[4];
+  unpack2bf(hi.x, h[0], h[1]);
+  unpack2bf(hi.y, h[2], h[3]);
+  lo.x = pack2bf(v[0] - h[0], v[1] - h[1]);
+  lo.y = pack2bf(v[2] - h[2], v[3] - h[3]);
+}
 
 // true when launch_conv's kernel for these args writes a.pool_y itself (conv_halo_c64.hip / conv_halo.hip forward tiles)
 bool danhip_conv_pool_fusable(const ConvArgs& a);
@@ -153,7 +168,7 @@ int danhip_launch_wgrad_c8(const danhip_conv_desc* d, const bf16_t* x, const bf1
 // Epilogue for one lane's 4 consecutive output channels [co, co+4) of output pixel m (shared by both kernels).
 __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_t m, int co) {
   if (co >= a.Co) return;
-  const size_t o = m * (size_t)a.ldy + co;          // output (pitched view: ldy elements per pixel)
+  const size_t o = m * (size_t)(a.split_out ? 3 * a.ldy : a.ldy) + co;      // output (pitched view: ldy elements per pixel; limb layout: three of them)
   const size_t om = m * (size_t)a.ldm + co;         // mask tensor of a data gradient
   const size_t orr = m * (size_t)a.Co + co;         // residual: always dense
   const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
@@ -177,6 +192,14 @@ __device__ __forceinline__ void conv_store4(const ConvArgs& a, float v[4], size_
     }
   } else {
     bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
+    if (a.split_out) {                                  // (forward only, Co % 8 == 0: always a full quad)
+      uint2 hi, lo;
+      dh_split4(v, hi, lo);
+      *reinterpret_cast<uint2*>(y) = hi;
+      *reinterpret_cast<uint2*>(y + a.Co) = lo;
+      *reinterpret_cast<uint2*>(y + 2 * a.Co) = hi;
+      return;
+    }
     if (full) {
       if (a.mask) {
         const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + om);

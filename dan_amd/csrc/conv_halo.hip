@@ -126,6 +126,17 @@ __device__ __forceinline__ u32x4 halo_finish8(const ConvArgs& a, const f32x4& lo
       *reinterpret_cast<float4*>(y + 4) = make_float4(v[4], v[5], v[6], v[7]);
       return u32x4{0u, 0u, 0u, 0u};
     }
+    if (a.split_out) {                  // limb layout of the next convolution (split_infer.hip): o = pixel * 3 Co + co, set by the caller
+      uint2 h0, l0, h1, l1;
+      dh_split4(v, h0, l0);
+      dh_split4(v + 4, h1, l1);
+      bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
+      const u32x4 hi = {h0.x, h0.y, h1.x, h1.y}, lo = {l0.x, l0.y, l1.x, l1.y};
+      *reinterpret_cast<u32x4*>(y) = hi;
+      *reinterpret_cast<u32x4*>(y + a.Co) = lo;
+      *reinterpret_cast<u32x4*>(y + 2 * a.Co) = hi;
+      return hi;
+    }
     if (a.resid) {
       const bf16_t* rp = reinterpret_cast<const bf16_t*>(&in0);
 #pragma unroll
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int t = wm * TP + p * 16 + frow;
         const int y = y0 + t / TW, x = x0 + t % TW;
         const bool ok = y < a.H && x < a.W;
-        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * a.Co + cb;
+        const size_t o0 = (size_t)((n * a.H + y) * a.W + x) * (a.split_out ? 3 * a.Co : a.Co) + cb;
         uint4 in0[NPAIR], in1[NPAIR];              // the residual is read before the first store
         if (ok) {
 #pragma unroll
@@ -1065,7 +1076,7 @@ int launch_halo_cfg(const ConvArgs& a, hipStream_t s) {
   g.cch = (a.C + 63) / 64;
   g.crem = (a.C % 64) / 8;
   g.b2 = danhip_option("halo_b2");
-  g.fast = (NCU == 0 && !a.out_f32 && !a.mask && !a.resid && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
+  g.fast = (NCU == 0 && !a.out_f32 && !a.split_out && !a.mask && !a.resid && (int64_t)a.N * a.H * a.W * a.Co * 2 <= (1ll << 31) &&
             (!danhip_option("halo_general_epilogue") || !a.y)) ? 1 : 0;
   if (!a.y && !(g.fast && POOL)) { danhip_set_error("conv_halo: y == NULL (pool-only) needs the pool-fusing instance with the lean epilogue"); return DANHIP_EINVAL; }
 #ifdef H_TRACE
@@ -1115,7 +1126,8 @@ int launch_halo(const ConvArgs& a, const HaloPlan& p, hipStream_t s) {
 int danhip_launch_conv_halo(const ConvArgs& a, hipStream_t s) {
   HaloPlan p;
   if (!plan_halo(a, &p)) return 1;
-  const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32 && !p.head;
+  const bool dgrad = !a.bias && !a.relu && !a.resid && !a.out_f32 && !a.split_out && !p.head;
+  if (a.split_out && p.head) return 1;
   if (a.mask_bits && !(dgrad && p.bn == 128 && a.Co % 128 == 0)) return 1;
   if (!dgrad && a.accumulate) return 1;
   if (!dgrad && a.mask) return 1;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int co = n0 + wn * TC + c * 16 + fq * 4;
       if (co >= a.Co) continue;
       float v[4] = {acc[c][p][0], acc[c][p][1], acc[c][p][2], acc[c][p][3]};
-      const size_t o = (size_t)m * a.ldy + co;          // (pitched views: conv_common.h ConvArgs::ldx / ldy / ldm)
+      const size_t o = (size_t)m * (a.split_out ? 3 * a.ldy : a.ldy) + co;          // (pitched views: conv_common.h ConvArgs::ldx / ldy / ldm)
       const size_t om = (size_t)m * a.ldm + co, orr = (size_t)m * a.Co + co;
       const bool full = (co + 4 <= a.Co) && ((a.Co & 3) == 0);
       if (a.bias) {
@@ -269,6 +269,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
       } else {
         bf16_t* y = reinterpret_cast<bf16_t*>(a.y) + o;
+        if (a.split_out) {                                // the next convolution's [hi | lo | hi] limb layout (split_infer.hip)
+          uint2 hi, lo;
+          dh_split4(v, hi, lo);
+          *reinterpret_cast<uint2*>(y) = hi;
+          *reinterpret_cast<uint2*>(y + a.Co) = lo;
+          *reinterpret_cast<uint2*>(y + 2 * a.Co) = hi;
+          continue;
+        }
         if (full) {
           if (a.mask) {
             const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + om);
@@ -426,11 +434,12 @@ int launch_cfg(const ConvArgs& a0, bool fast, hipStream_t s) {
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   const bool view = a.strided();                       // channel-slice views / partial ReLU: the streaming GEMM and the flat-M kernel only
-  if (!view) {
+  const bool limbs = a.split_out != 0;                 // limb-layout output: the halo kernel's general epilogue or the flat-M kernel (conv_store4)
+  if (!view && !limbs) {
     const int c8 = danhip_launch_conv_c8(a, s);        // conv1_1: 3 (padded to 8) -> 64 channels, bound by its output write
     if (c8 <= 0) return c8;
   }
-  {
+  if (!limbs) {
     const int cr = danhip_launch_conv_c64(a, s);       // 3x3 / stride-1, 64 -> 64 channels: register-resident weights (views too)
     if (cr <= 0) return cr;
   }
@@ -440,8 +449,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
       const int hr = danhip_launch_conv_halo(a, s);    // 3x3 / stride-1 on large maps: halo-reuse kernel
       if (hr <= 0) return hr;
     }
-    const int pr = danhip_launch_conv_pointwise(a, s); // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
-    if (pr <= 0) return pr;
+    if (!limbs) {
+      const int pr = danhip_launch_conv_pointwise(a, s); // 1x1 / stride-1 with 64-multiple channels: streaming GEMM
+      if (pr <= 0) return pr;
+    }
   }
   const bool fast = (a.C % 64 == 0);
   switch (pick_bn(a.Co)) {
@@ -720,11 +731,16 @@ extern "C" int danhip_conv2d_fwd_ws(const danhip_conv_desc* d, const uint16_t* x
   if (rc) return rc;
   DH_REQUIRE(x && wf_packed && y, DANHIP_EINVAL, "conv2d_fwd: null pointer");
   if (out_dtype == DANHIP_F16 && danhip_act_dtype() == DANHIP_F16) out_dtype = DANHIP_BF16;      // alias for "the build's 16-bit type"
-  DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
-  DH_REQUIRE(!(residual && out_dtype == DANHIP_F32), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
+  DH_REQUIRE(out_dtype == DANHIP_BF16 || out_dtype == DANHIP_F32 || out_dtype == DANHIP_SPLIT3, DANHIP_EINVAL, "conv2d_fwd: bad out_dtype %d", out_dtype);
+  DH_REQUIRE(!(residual && out_dtype != DANHIP_BF16), DANHIP_EINVAL, "conv2d_fwd: residual needs bf16 output");
+  if (out_dtype == DANHIP_SPLIT3) {
+    DH_REQUIRE(danhip_act_dtype() == DANHIP_F16, DANHIP_EINVAL, "conv2d_fwd: DANHIP_SPLIT3 output needs the fp16 build (IEEE-half limbs)");
+    DH_REQUIRE(d->Cout % 8 == 0, DANHIP_EINVAL, "conv2d_fwd: DANHIP_SPLIT3 output needs Cout %% 8 == 0");
+    DH_REQUIRE((int64_t)d->N * d->Ho * d->Wo * 3 * d->Cout < (1ll << 31), DANHIP_EINVAL, "conv2d_fwd: the limb-layout output exceeds 2^31 elements");
+  }
   ConvArgs a = fwd_args(d);
   a.x = x; a.w = wf_packed; a.bias = bias; a.mask = nullptr; a.resid = residual; a.y = y;
-  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0;
+  a.relu = relu; a.out_f32 = (out_dtype == DANHIP_F32); a.accumulate = 0; a.split_out = (out_dtype == DANHIP_SPLIT3);
   if (ws && ws_bytes >= danhip_conv2d_workspace_bytes(d, 0) && ws_bytes > 0) a.splitk_ws = reinterpret_cast<float*>(ws);
   return launch_conv(a, (hipStream_t)stream);
 }

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_DTYPE as ACT, BF16, F32, ConvDesc, call, ptr, stream
+from ._lib import ACT_DTYPE as ACT, BF16, F32, SPLIT3, ConvDesc, call, ptr, stream
 
 
 class OpsContext(object):
@@ -36,13 +36,15 @@ class OpsContext(object):
       POOL_ONLY_TRAIN  [DANHIP_POOL_ONLY_TRAIN, 1]  0: the training forward of a conv whose only consumer is a fused pool still writes its map
       KEEP_DEFORM_COL  False: the deformable backward re-samples the im2col buffer as the reference does instead of keeping the forward's
       WGRAD_STREAM     [DANHIP_WGRAD_STREAM, 1]  0: weight gradients on the data gradients' stream
+      WGRAD_FIRST      [DANHIP_WGRAD_FIRST, 1]   0: a convolution's backward issues its data gradient before its weight gradient (rounds 2-5: the
+                       side stream then waits for the data gradient to finish, not just for dY)
       SPLIT_EVAL       True: convolutions of the fp32 inference path run as split-operand products on the fp16 MFMA (csrc/split_infer.hip;
                        models set it for precision "split"): fp32-accurate boxes at a third of the 16-bit rate instead of a tenth
     Diagnostic sinks (None = off): TRACE (tests: activations / decisions by variable id), PROFILE / PROFILE_BYTES (bench.py: HIP events
     and algorithmic bytes per convolution launch).
     Per-step state a trainer arms: GRAD_READY_HOOK (a parameter's gradient is final), LOSS_SCALE_DEV (device scalar of the dynamic loss
     scale), wgrad (the second backward stream: {"on", "side", "main", "keep"})."""
-    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "SPLIT_EVAL", "TRACE",
+    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "WGRAD_FIRST", "SPLIT_EVAL", "TRACE",
                  "PROFILE", "PROFILE_BYTES", "GRAD_READY_HOOK", "LOSS_SCALE_DEV", "wgrad")
 
     def __init__(self, **overrides):
@@ -54,6 +56,7 @@ class OpsContext(object):
         self.POOL_ONLY_TRAIN = env("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
         self.KEEP_DEFORM_COL = True
         self.WGRAD_STREAM = env("DANHIP_WGRAD_STREAM", "1") == "1"
+        self.WGRAD_FIRST = env("DANHIP_WGRAD_FIRST", "1") == "1"
         self.SPLIT_EVAL = False
         self.TRACE = self.PROFILE = self.PROFILE_BYTES = None
         self.GRAD_READY_HOOK = self.LOSS_SCALE_DEV = None
@@ -529,53 +532,71 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(g), None, ptr(db), M, co8, stream())
             else:
                 db.add_(g.view(M, co8)[:, :d.Cout].to(torch.float32).sum(0))
+        # Order of the two launches (round 6, ops.WGRAD_FIRST): the weight gradient goes to the side stream FIRST.  Both kernels read the same dY;
+        # issued dgrad-first (rounds 2-5) the side stream's event was recorded BEHIND the data gradient, so wgrad(L) waited for dgrad(L) to
+        # FINISH and ran beside dgrad(L-1) — and at the end of backward conv1_2's weight gradient (0.44 ms) and conv1_1's (0.19 ms) ran with the
+        # other queue empty (profiles/r5/s3fd_b16_step_timeline_full.txt: the 0.63 ms single-queue tail).  Weight gradient first: its event
+        # only waits for dY, wgrad(L) runs beside dgrad(L), and the tail is conv1_1's weight gradient alone.
         dx = None
-        if ctx.needs_input_grad[0]:
-            xs = ctx.xslot
-            if xs is not None:                           # deliver straight into the producer's slot (+ its ReLU backward)
-                buf, acc = xs.target()
-                e0 = _prof_begin()
-                if xs.is_relu and ctx.xbits is not None and _lib.lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d)):
-                    # the kernel keeps its tile's mask in LDS as bits: 1/16 of the bytes, and not a load in its epilogue
-                    call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(g), ptr(wb), ptr(relu_bits(x, ctx.xbits)), ptr(buf), acc, stream())
-                else:
-                    ws, nws = _conv_scratch(d, 1, g.device)
-                    call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, ptr(ws), nws,
-                         stream())
-                _prof_end(e0, d, 5 if xs.is_relu else 1)
-            else:
-                dx = torch.empty_like(x)
-                e0 = _prof_begin()
-                ws, nws = _conv_scratch(d, 1, g.device)
-                call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, ptr(ws), nws, stream())
-                _prof_end(e0, d, 1)
         dw = None
         hooked = False
-        if need_dw:
-            sink = _grad_sink(wp) if wp is not None else None
-            dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
-            # split partial sums as plain stores into a scratch slab + a combine pass, where the library's kernel for this shape offers it
-            ws, nws = _wgrad_scratch(d, g.device)
-            if _CTX.wgrad["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
-                side = _CTX.wgrad["side"]
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                side.wait_event(ev)
-                e0 = _prof_begin(side)                  # (explicit stream handle: no stream-context switch per layer on the host)
-                call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
-                     ptr(ws), nws, ctypes.c_void_p(side.cuda_stream))
-                _prof_end(e0, d, 2, side)
-                if _CTX.GRAD_READY_HOOK is not None and wp is not None:
-                    _CTX.GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
-                _CTX.wgrad["keep"].append((g, x, ws))
-                hooked = True
-            else:
-                e0 = _prof_begin()
-                call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
-                     ptr(ws), nws, stream())
-                _prof_end(e0, d, 2)
-            if sink is not None:
-                dw = None
+
+        def launch_dx():
+            nonlocal dx
+            if ctx.needs_input_grad[0]:
+                xs = ctx.xslot
+                if xs is not None:                           # deliver straight into the producer's slot (+ its ReLU backward)
+                    buf, acc = xs.target()
+                    e0 = _prof_begin()
+                    if xs.is_relu and ctx.xbits is not None and _lib.lib().danhip_conv2d_bwd_data_takes_bits(ctypes.byref(d)):
+                        # the kernel keeps its tile's mask in LDS as bits: 1/16 of the bytes, and not a load in its epilogue
+                        call("danhip_conv2d_bwd_data_bits", ctypes.byref(d), ptr(g), ptr(wb), ptr(relu_bits(x, ctx.xbits)), ptr(buf), acc, stream())
+                    else:
+                        ws, nws = _conv_scratch(d, 1, g.device)
+                        call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), ptr(x) if xs.is_relu else None, ptr(buf), acc, ptr(ws), nws,
+                             stream())
+                    _prof_end(e0, d, 5 if xs.is_relu else 1)
+                else:
+                    dx = torch.empty_like(x)
+                    e0 = _prof_begin()
+                    ws, nws = _conv_scratch(d, 1, g.device)
+                    call("danhip_conv2d_bwd_data_ws", ctypes.byref(d), ptr(g), ptr(wb), None, ptr(dx), 0, ptr(ws), nws, stream())
+                    _prof_end(e0, d, 1)
+
+        def launch_dw():
+            nonlocal dw, hooked
+            if need_dw:
+                sink = _grad_sink(wp) if wp is not None else None
+                dw = sink if sink is not None else torch.zeros((d.kh, d.kw, ctx.cin_real, d.Cout), dtype=torch.float32, device=g.device)
+                # split partial sums as plain stores into a scratch slab + a combine pass, where the library's kernel for this shape offers it
+                ws, nws = _wgrad_scratch(d, g.device)
+                if _CTX.wgrad["on"] and sink is not None:      # side stream: needs dY (final now) and the zeroed sinks, both ordered on this stream
+                    side = _CTX.wgrad["side"]
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    side.wait_event(ev)
+                    e0 = _prof_begin(side)                  # (explicit stream handle: no stream-context switch per layer on the host)
+                    call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
+                         ptr(ws), nws, ctypes.c_void_p(side.cuda_stream))
+                    _prof_end(e0, d, 2, side)
+                    if _CTX.GRAD_READY_HOOK is not None and wp is not None:
+                        _CTX.GRAD_READY_HOOK(wp)                 # the buckets wait for both gradient streams (trainer.GradBuckets._launch_ready)
+                    _CTX.wgrad["keep"].append((g, x, ws))
+                    hooked = True
+                else:
+                    e0 = _prof_begin()
+                    call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(g), ptr(dw), ptr(db) if db_in_wgrad else None, ctx.cin_real,
+                         ptr(ws), nws, stream())
+                    _prof_end(e0, d, 2)
+                if sink is not None:
+                    dw = None
+
+        if _CTX.WGRAD_FIRST:
+            launch_dw()
+            launch_dx()
+        else:
+            launch_dx()
+            launch_dw()
         if db_sink is not None:
             db = None
         if _CTX.GRAD_READY_HOOK is not None and wp is not None and not hooked:
@@ -632,31 +653,67 @@ def _split_weight(d3, w, cin):
     return wf
 
 
+def _limb_view(x3, C):
+    """The tensor a split-mode convolution hands on: shape [.., C] (the nets read channel counts from it), IEEE half, a strided view of the
+    HI limbs of the [.., 3C] limb-layout map, which rides along as `_dh_split3`.  Consumers inside this module: conv2d and max_pool_2x2
+    take the limb layout as it is; every other op widens it to fp32 first (_f32_in)."""
+    v = x3[..., :C]
+    v._dh_split3 = x3
+    return v
+
+
+def _is_limbs(x):
+    return getattr(x, "_dh_split3", None) is not None
+
+
+def unsplit3(x):
+    """limb view -> contiguous fp32 NHWC (hi + lo)."""
+    x3 = x._dh_split3
+    C = x.shape[-1]
+    y = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+    call("danhip_unsplit3_f32", ptr(x3), ptr(y), y.numel() // C, C, x3.shape[-1], stream())
+    return y
+
+
+def _f32_in(*ts):
+    """Inputs of an op of the fp32 inference path: limb views (split-operand mode) widened to fp32, everything else untouched."""
+    out = tuple(unsplit3(t) if (t is not None and _is_limbs(t)) else t for t in ts)
+    return out[0] if len(out) == 1 else out
+
+
 def split3(x):
-    """fp32 NHWC [.., C] -> IEEE-half [.., C3] = [hi | lo | hi | 0-padding], C3 = 3C rounded up to 8 (cached on the tensor)."""
-    x3 = getattr(x, "_dh_split3", None)
-    if x3 is None:
-        C = x.shape[-1]
-        C3 = (3 * C + 7) // 8 * 8
-        x3 = torch.empty(x.shape[:-1] + (C3,), dtype=torch.float16, device=x.device)
-        call("danhip_split3_f32", ptr(x.contiguous()), ptr(x3), x.numel() // C, C, C3, 0, stream())
+    """fp32 NHWC [.., C] (or a limb view) -> IEEE-half [.., C3] = [hi | lo | hi | 0-padding], C3 = 3C rounded up to 8."""
+    if _is_limbs(x):
+        return x._dh_split3
+    C = x.shape[-1]
+    C3 = (3 * C + 7) // 8 * 8
+    x3 = torch.empty(x.shape[:-1] + (C3,), dtype=torch.float16, device=x.device)
+    call("danhip_split3_f32", ptr(x.contiguous()), ptr(x3), x.numel() // C, C, C3, 0, stream())
     return x3
 
 
-def _conv2d_split(x, w, b, stride, relu, residual, padding):
+def _conv2d_split(x, w, b, stride, relu, residual, padding, want_f32=False):
+    """-> fp32 [N,Ho,Wo,cout] when the caller asks for it (heads), has a residual, or cout is ragged; else the next convolution's limb
+    layout written by the kernel's epilogue (DANHIP_SPLIT3), returned as a limb view."""
     N, H, W, C = x.shape
     kh, kw, cin, cout = w.shape
     assert cin == C, "split conv: input channels must match the kernel"
     x3 = split3(x)
     d3 = _desc(N, H, W, x3.shape[-1], cout, kh, kw, stride, padding == "valid")
     wf = _split_weight(d3, w, cin)
-    y = torch.empty((N, d3.Ho, d3.Wo, cout), dtype=torch.float32, device=x.device)
+    limbs = not want_f32 and residual is None and cout % 8 == 0 and N * d3.Ho * d3.Wo * 3 * cout < (1 << 31)
+    if limbs:
+        y = torch.empty((N, d3.Ho, d3.Wo, 3 * cout), dtype=torch.float16, device=x.device)
+    else:
+        y = torch.empty((N, d3.Ho, d3.Wo, cout), dtype=torch.float32, device=x.device)
     n = _lib.lib_f16().danhip_conv2d_workspace_bytes(ctypes.byref(d3), 0) if -(-(N * d3.Ho * d3.Wo) // 128) * -(-cout // 128) <= 160 else 0
     ws = torch.empty(n, dtype=torch.uint8, device=x.device) if n else None
-    _lib.call_f16("danhip_conv2d_fwd_ws", ctypes.byref(d3), ptr(x3), ptr(wf), ptr(b.detach().float()) if b is not None else None, ptr(y), F32, int(relu),
-                  None, ptr(ws), n, stream())
+    _lib.call_f16("danhip_conv2d_fwd_ws", ctypes.byref(d3), ptr(x3), ptr(wf), ptr(b.detach().float()) if b is not None else None, ptr(y),
+                  SPLIT3 if limbs else F32, int(relu), None, ptr(ws), n, stream())
+    if limbs:
+        return _limb_view(y, cout)
     if residual is not None:                             # (added after the activation, as the 16-bit kernels' fused residual is)
-        y.add_(residual)
+        y.add_(_f32_in(residual))
     return y
 
 
@@ -664,10 +721,10 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     """pool=True: also computes max_pool_2x2(y) (danhip_conv2d_fwd_pool); the next ops.max_pool_2x2(y) call picks it up.
     pool_only=True (with pool, no gradient tracked): the caller promises that ONLY the pooled map is used - where the kernel pools in its
     epilogue the full-resolution activation is never written and the POOLED tensor is returned (ops.max_pool_2x2 passes it through)."""
+    if _is_limbs(x) or (_CTX.SPLIT_EVAL and _f32_infer(x)):
+        return _conv2d_split(x, w, b, stride, relu, residual, padding, want_f32=out_f32)
     if _f32_infer(x):
-        if _CTX.SPLIT_EVAL:
-            return _conv2d_split(x, w, b, stride, relu, residual, padding)
-        return _conv2d_f32(x, w, b, stride, relu, residual, padding)
+        return _conv2d_f32(x, w, b, stride, relu, _f32_in(residual), padding)
     # a plain tensor carrying a gradient sink is a fused block of parameters (FlatParams): cached packing, gradients written in place
     wp = w if (isinstance(w, torch.nn.Parameter) or hasattr(w, "_danhip_grad")) else None
     bp = b if (isinstance(b, torch.nn.Parameter) or hasattr(b, "_danhip_grad")) else None
@@ -766,6 +823,13 @@ def _pool_deliver_ok(ctx, dy):
 def max_pool_2x2(x):
     if getattr(x, "_dh_already_pooled", False):           # conv2d(pool=True, pool_only=True) already returned the pooled map
         return x
+    if _is_limbs(x):                                      # split-operand mode: pooled straight on the limb layout
+        N, H, W, C = x.shape
+        if C % 8 == 0 and x._dh_split3.shape[-1] == 3 * C:
+            y3 = torch.empty((N, (H + 1) // 2, (W + 1) // 2, 3 * C), dtype=torch.float16, device=x.device)
+            call("danhip_maxpool2x2_split3", ptr(x._dh_split3), ptr(y3), N, H, W, C, stream())
+            return _limb_view(y3, C)
+        x = unsplit3(x)
     if _f32_infer(x):
         N, H, W, C = x.shape
         y = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C), dtype=torch.float32, device=x.device)
@@ -808,7 +872,7 @@ class _MaxPool3x3S2(torch.autograd.Function):
 
 
 def max_pool_3x3_s2(x):
-    return _MaxPool3x3S2.apply(x)
+    return _MaxPool3x3S2.apply(_f32_in(x))
 
 
 class _L2Norm(torch.autograd.Function):
@@ -848,6 +912,7 @@ class _L2Norm(torch.autograd.Function):
 
 
 def l2_normalize(x, gamma):
+    x = _f32_in(x)
     if _f32_infer(x):
         y = torch.empty_like(x)
         call("danhip_l2norm_fwd_f32", ptr(x.contiguous()), ptr(gamma.detach()), ptr(y), x.numel() // x.shape[-1], x.shape[-1], stream())
@@ -995,6 +1060,7 @@ class _ResizeAdd(torch.autograd.Function):
 
 
 def resize_bilinear_add(up, lateral=None, size=None):
+    up, lateral = _f32_in(up, lateral)
     if _f32_infer(up):
         N, Hi, Wi, C = up.shape
         Ho, Wo = (lateral.shape[1], lateral.shape[2]) if lateral is not None else size
@@ -1045,6 +1111,7 @@ class _AvgPool2x2S1(torch.autograd.Function):
 
 
 def avg_pool_2x2_s1(x):
+    x = _f32_in(x)
     if _f32_infer(x):
         N, H, W, C = x.shape
         y = torch.empty_like(x)
@@ -1102,7 +1169,7 @@ class _Concat(torch.autograd.Function):
 
 def concat(tensors):
     """Channel concatenation of NHWC activations."""
-    tensors = list(tensors)
+    tensors = [_f32_in(t) for t in tensors]
     track = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
     if tensors[0].dtype != ACT or not track or not _CTX.USE_SLOTS:
         return torch.cat(tensors, dim=-1)
@@ -1165,6 +1232,7 @@ class _Add(torch.autograd.Function):
 
 
 def add(a, b):
+    a, b = _f32_in(a, b)
     track = torch.is_grad_enabled() and (a.requires_grad or b.requires_grad)
     if a.dtype != ACT or not track or not _CTX.USE_SLOTS or a.shape != b.shape or a.shape[-1] % 8:
         return a + b
@@ -1367,6 +1435,7 @@ def context_block(x, params, hook_order, trace_params=None):
     """params: six (w, b) pairs in the order b1, cat(b3 | b4 | b2), plus(b3a 3x1 | b3b 1x3) as a [3, 3, 64, 64] kernel, b43 (3x3), plus(b4a | b4b), res;
     hook_order: the block's kernel Parameters in reverse creation order (data-parallel gradient buckets); trace_params: {"b1", "b2", "b3",
     "b3a", "b3b", "b4", "b43", "b4a", "b4b", "res"} -> kernel Parameter (ops.TRACE: tests).  -> out (with a gradient slot)."""
+    assert not _is_limbs(x), "context_block is a 16-bit training op (the nets take the unfused block on the fp32 / split paths)"
     track = torch.is_grad_enabled()
     handles, flat = [], []
     for w, b in params:
@@ -1490,6 +1559,7 @@ def concat_conv1x1_relu(a, f, wv, bv, split=None, trace_params=None):
     """relu(conv1x1(concat([a, f]), wv) + bv) without the concatenation; a is treated as a constant (stop_gradient).  wv: [1, 1, Ca + Cf, Co]
     (a FlatParams block-diagonal block, or any tensor); split = (rows, columns) of its upper-left block when wv is block-diagonal - the
     off-diagonal blocks of its gradient are then cleared.  trace_params: (w1, w2) kernel Parameters of the two parts (ops.TRACE: tests)."""
+    assert not (_is_limbs(a) or _is_limbs(f)), "concat_conv1x1_relu is a 16-bit op (the nets take the unfused mix on the fp32 / split paths)"
     track = torch.is_grad_enabled() and (f.requires_grad or wv.requires_grad or _sink_trainable(wv))
     wvp = wv if (isinstance(wv, torch.nn.Parameter) or hasattr(wv, "_danhip_grad")) else None
     bvp = bv if (isinstance(bv, torch.nn.Parameter) or hasattr(bv, "_danhip_grad")) else None
@@ -1540,10 +1610,12 @@ class _BatchNorm(torch.autograd.Function):
 
 
 def batch_norm_train(x, gamma, beta, moving_mean=None, moving_var=None, eps=1e-5, momentum=0.997, relu=False):
+    assert not _is_limbs(x), "batch_norm_train: a 16-bit training op"
     return _BatchNorm.apply(x, gamma, beta, moving_mean, moving_var, eps, momentum, relu)
 
 
 def batch_norm_infer(x, gamma, beta, moving_mean, moving_var, eps=1e-5, relu=False):
+    x = _f32_in(x)
     C = x.shape[-1]
     y = torch.empty_like(x)
     rstd = torch.rsqrt(moving_var + eps)
@@ -1665,6 +1737,7 @@ class _DeformConv(torch.autograd.Function):
 
 def deform_conv(x, w1x1, b, offsets, kh, kw, stride=1, dilation=1, deformable_group=1, relu=False):
     """y = act(DeformConvOp(x, filter, offsets) + b); w1x1 = the filter viewed [1,1,kh*kw*C,Cout]."""
+    x, offsets = _f32_in(x, offsets)
     if _f32_infer(x):
         N, H, W, C = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
@@ -1692,6 +1765,7 @@ def preprocess_f32(img_rgb_u8):
 
 
 def deform_sample(x, offsets, kh, kw, stride=1, dilation=1, deformable_group=1):
+    x, offsets = _f32_in(x, offsets)
     return _DeformSample.apply(x, offsets, kh, kw, stride, dilation, deformable_group)
 
 

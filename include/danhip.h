@@ -42,6 +42,7 @@ extern "C" {
 #define DANHIP_F32 0
 #define DANHIP_BF16 1
 #define DANHIP_F16 2
+#define DANHIP_SPLIT3 3      /* out_dtype of danhip_conv2d_fwd[_ws] in the fp16 build: y = the [hi | lo | hi] half-limb map [N,Ho,Wo,3*Cout] (split_infer.hip) */
 
 const char* danhip_last_error(void);
 int danhip_version(void);

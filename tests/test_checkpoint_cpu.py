@@ -212,3 +212,26 @@ def test_fused_inference_blocks_follow_a_restore_and_raw_pointer_writers(tmp_pat
         ops.WEIGHT_EPOCH += 1                                              # ... which every raw-pointer writer closes this way
         t_new = dst.fuse(*groups[0])
         assert t_new is not t_old and torch.equal(t_new[..., 4:], p)
+
+
+def test_reader_accepts_a_bundle_written_by_an_independent_encoder(tmp_path):
+    """SURVEY 8f row 2 / VERDICT r5 (f2 "partial": the reader had only ever read its own writer's files).  tests/tf_bundle_encoder.py writes
+    the TF-V2 format from the format definitions with different free choices (two shards, restart interval 1, small blocks, a CRC per
+    tensor, an empty-shape int64 scalar): every tensor comes back bit for bit, checksums verified, shapes / dtypes as written."""
+    import numpy as np
+    from tf_bundle_encoder import crc32c as crc_indep, write_bundle
+    from dan_amd.utility import checkpoint as C
+    assert crc_indep(b"123456789") == 0xE3069283 and C.crc32c(b"123456789") == 0xE3069283        # the CRC-32C check value, both implementations
+    rng = np.random.default_rng(3)
+    tensors = {"vgg_16/conv1/conv1_%d/weights" % i: rng.standard_normal((3, 3, 8 * i + 3, 16), dtype=np.float32) for i in range(1, 9)}
+    tensors.update({"vgg_16/conv1/conv1_%d/biases" % i: rng.standard_normal((16,), dtype=np.float32) for i in range(1, 9)})
+    tensors["global_step"] = np.asarray(120000, dtype=np.int64)
+    tensors["a/very/" + "long/" * 40 + "name"] = np.arange(7, dtype=np.int32)
+    prefix = str(tmp_path / "model.ckpt-120000")
+    write_bundle(prefix, tensors)
+    r = C.CheckpointReader(prefix)
+    assert r.num_shards == 2 and set(r.get_variable_to_shape_map()) == set(tensors)
+    for n, a in tensors.items():
+        got = r.get_tensor(n, verify=True)
+        assert got.dtype == a.dtype and got.shape == a.shape and np.array_equal(got, a), n
+    assert int(r.get_tensor("global_step")) == 120000

@@ -77,6 +77,34 @@ def test_split_conv_vs_the_fp32_oracle(N, H, W, Cin, Cout, k, stride, relu, dev)
     b = torch.randn((Cout,), generator=g)
     want = T.conv2d_same(x, w, b, stride=stride, relu=relu)
     with ops.use_context(ops.OpsContext(SPLIT_EVAL=True)), torch.no_grad():
-        got = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=stride, relu=relu).cpu()
+        y = ops.conv2d(x.to(dev), w.to(dev), b.to(dev), stride=stride, relu=relu)
+        if Cout % 8 == 0:                      # the kernel's epilogue wrote the NEXT convolution's limb layout: a half view of the hi limbs + the map
+            assert y.dtype == torch.float16 and y.shape[-1] == Cout and y._dh_split3.shape[-1] == 3 * Cout
+            assert torch.equal(y._dh_split3[..., :Cout], y._dh_split3[..., 2 * Cout:])
+        got = ops._f32_in(y).cpu()
     assert got.dtype == torch.float32 and torch.isfinite(got).all()
     assert (got - want).abs().max().item() <= 4e-6 * want.abs().max().item(), (got - want).abs().max().item() / want.abs().max().item()
+
+
+def test_two_split_convs_chained_through_the_limb_layout_and_a_pool(dev):
+    """conv -> (epilogue limb layout) -> conv -> pool on the limb layout -> conv with fp32 output, against the fp32 oracle chain: the
+    limbs handed from epilogue to operand lose nothing beyond 2^-22 per value."""
+    from dan_amd import ops
+    from oracle import tf_ops as T
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 64, 96, 64), generator=g)
+    ws = [torch.randn((3, 3, ci, co), generator=g) / (9 * ci) ** 0.5 for ci, co in ((64, 128), (128, 128), (128, 8))]
+    bs = [0.1 * torch.randn((w.shape[-1],), generator=g) for w in ws]
+    want = T.conv2d_same(x, ws[0], bs[0], stride=1, relu=True)
+    want = T.conv2d_same(want, ws[1], bs[1], stride=1, relu=True)
+    want = T.max_pool_2x2_same(want)
+    want = T.conv2d_same(want, ws[2], bs[2], stride=1, relu=False)
+    with ops.use_context(ops.OpsContext(SPLIT_EVAL=True)), torch.no_grad():
+        y = ops.conv2d(x.to(dev), ws[0].to(dev), bs[0].to(dev), relu=True)
+        y = ops.conv2d(y, ws[1].to(dev), bs[1].to(dev), relu=True)
+        assert ops._is_limbs(y)
+        y = ops.max_pool_2x2(y)
+        assert ops._is_limbs(y) and y.shape == (2, 32, 48, 128)
+        y = ops.conv2d(y, ws[2].to(dev), bs[2].to(dev), relu=False, out_f32=True)
+    assert y.dtype == torch.float32
+    assert (y.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item()

@@ -281,5 +281,7 @@ def test_bench_line_of_a_two_rank_run_on_one_gpu(dev):
     assert d["repeats"]["regions"] == 2 and len(d["repeats"]["ms_per_step"]) == 2
     s = d["strong"]
     assert s["global_batch"] == 8 and s["n_gpus"] == 2 and s["batch_per_gpu"] == 4 and s["towers_per_gpu"] * s["tower_batch"] == 4 and s["value"] > 0
+    s16 = d["strong16"]                                # SURVEY 8(e)'s series: global batch 16 on 2 ranks = 8 images per rank, eager
+    assert s16["global_batch"] == 16 and s16["n_gpus"] == 2 and s16["batch_per_gpu"] == 8 and s16["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
     assert d["config"]["dp_transport"] == "gloo" and d["config"]["rccl_ranks"] == 1
