@@ -142,7 +142,7 @@ class VGG16Backbone(pb_net.VGG16Backbone):
             if self.FUSED_STAGE2_MIX and f.dtype == ops.ACT and c % 64 == 0 and f.is_contiguous() and feature_stage1[i].shape == f.shape:
                 mixed = self._stage2_mix_fused(feature_stage1[i], f, s1n, rsn)
             else:
-                s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), s1n)
+                s1 = self._cr(ops.stop_gradient(feature_stage1[i]), c // 3, (1, 1), s1n)
                 rs = self._cr(f, c - c // 3, (1, 1), rsn)
                 mixed = ops.concat([s1, rs])
             outs.append(self.se_inception_block(mixed, "{}/predict_stage2_{}".format(name, i)))

@@ -33,7 +33,7 @@ class VGG16Backbone(danet.VGG16Backbone):
         outs = []
         for i, f in enumerate(feature_layers):
             c = f.shape[-1]
-            s1 = self._cr(feature_stage1[i].detach(), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))            # (sic)
+            s1 = self._cr(ops.stop_gradient(feature_stage1[i]), c // 3, (1, 1), "{}/satge1_conv_1x1_{}".format(name, i))            # (sic)
             rs = self._cr(f, c - c // 3, (1, 1), "{}/residual_conv_1x1_{}".format(name, i))
             outs.append(self._deform_relu(ops.concat([s1, rs]), "{}/predict_stage2_conv{}".format(name, i)))
         return outs

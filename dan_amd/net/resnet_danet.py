@@ -61,7 +61,7 @@ class ResNetBackbone(danet.VGG16Backbone):
                 x = self.bottleneck_block(x, input_depth[ind], "block_{}/conv_{}".format(ind + 1, unit), training, need_reduce, is_root)
                 need_reduce, is_root = False, False
             if freeze and ind == 0:
-                x = x.detach()                                                                      # tf.stop_gradient: un-freeze from here
+                x = ops.stop_gradient(x)                                                                      # tf.stop_gradient: un-freeze from here
                 training = training_sts
             collected.append(x)
         x = self.conv_bn_relu(x, 512, (1, 1), 1, "additional_layers/conv6_1", training)

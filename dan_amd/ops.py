@@ -36,8 +36,10 @@ class OpsContext(object):
       POOL_ONLY_TRAIN  [DANHIP_POOL_ONLY_TRAIN, 1]  0: the training forward of a conv whose only consumer is a fused pool still writes its map
       KEEP_DEFORM_COL  False: the deformable backward re-samples the im2col buffer as the reference does instead of keeping the forward's
       WGRAD_STREAM     [DANHIP_WGRAD_STREAM, 1]  0: weight gradients on the data gradients' stream
-      WGRAD_FIRST      [DANHIP_WGRAD_FIRST, 1]   0: a convolution's backward issues its data gradient before its weight gradient (rounds 2-5: the
-                       side stream then waits for the data gradient to finish, not just for dY)
+      WGRAD_FIRST      [DANHIP_WGRAD_FIRST, 0]   1: a convolution's backward issues its weight gradient (side stream) BEFORE its data gradient, so the
+                       side stream waits for dY only, not for the data gradient.  Measured slower (round 6, same box, alternating: 12.81 against
+                       12.73 ms): both kernels are full-chip persistent grids, "beside each other" means taking turns, and the data gradient —
+                       the critical path — then queues behind the weight gradient's workgroups
       SPLIT_EVAL       True: convolutions of the fp32 inference path run as split-operand products on the fp16 MFMA (csrc/split_infer.hip;
                        models set it for precision "split"): fp32-accurate boxes at a third of the 16-bit rate instead of a tenth
     Diagnostic sinks (None = off): TRACE (tests: activations / decisions by variable id), PROFILE / PROFILE_BYTES (bench.py: HIP events
@@ -56,7 +58,7 @@ class OpsContext(object):
         self.POOL_ONLY_TRAIN = env("DANHIP_POOL_ONLY_TRAIN", "1") == "1"
         self.KEEP_DEFORM_COL = True
         self.WGRAD_STREAM = env("DANHIP_WGRAD_STREAM", "1") == "1"
-        self.WGRAD_FIRST = env("DANHIP_WGRAD_FIRST", "1") == "1"
+        self.WGRAD_FIRST = env("DANHIP_WGRAD_FIRST", "0") == "1"
         self.SPLIT_EVAL = False
         self.TRACE = self.PROFILE = self.PROFILE_BYTES = None
         self.GRAD_READY_HOOK = self.LOSS_SCALE_DEV = None
@@ -532,11 +534,14 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(g), None, ptr(db), M, co8, stream())
             else:
                 db.add_(g.view(M, co8)[:, :d.Cout].to(torch.float32).sum(0))
-        # Order of the two launches (round 6, ops.WGRAD_FIRST): the weight gradient goes to the side stream FIRST.  Both kernels read the same dY;
-        # issued dgrad-first (rounds 2-5) the side stream's event was recorded BEHIND the data gradient, so wgrad(L) waited for dgrad(L) to
-        # FINISH and ran beside dgrad(L-1) — and at the end of backward conv1_2's weight gradient (0.44 ms) and conv1_1's (0.19 ms) ran with the
-        # other queue empty (profiles/r5/s3fd_b16_step_timeline_full.txt: the 0.63 ms single-queue tail).  Weight gradient first: its event
-        # only waits for dY, wgrad(L) runs beside dgrad(L), and the tail is conv1_1's weight gradient alone.
+        # Order of the two launches (ops.WGRAD_FIRST, round 6).  Default: data gradient first — the side stream's event is recorded BEHIND it, so
+        # wgrad(L) waits for dgrad(L) to finish and runs beside dgrad(L-1); at the end of backward conv1_2's weight gradient (0.44 ms) and conv1_1's
+        # (0.19 ms) run with the other queue empty (profiles/r5/s3fd_b16_step_timeline_full.txt: VERDICT r5's "0.63 ms single-queue tail").
+        # WGRAD_FIRST issues the weight gradient first (its event then waits for dY only).  Measured on one box, alternating processes
+        # (profiles/r6/ab_wgrad_first_same_box.txt): 12.81 ms against 12.73 for the default — SLOWER.  Two full-chip persistent grids cannot share
+        # a CU, so "beside" means taking turns: what the second queue buys is tail filling, whatever the order, and with the weight gradient
+        # ahead the data-gradient chain (the critical path: every later layer waits for it) queues behind 256 weight-gradient workgroups.  The
+        # tail cannot be closed by reordering: conv1_2's two gradients are both chip-filling and conv1_1's needs conv1_2's data gradient.
         dx = None
         dw = None
         hooked = False
@@ -675,6 +680,12 @@ def unsplit3(x):
     return y
 
 
+def stop_gradient(x):
+    """tf.stop_gradient.  A limb view (split-operand inference: nothing is differentiated) passes through — Tensor.detach() would return a
+    plain half tensor without the limb map riding on it."""
+    return x if _is_limbs(x) else x.detach()
+
+
 def _f32_in(*ts):
     """Inputs of an op of the fp32 inference path: limb views (split-operand mode) widened to fp32, everything else untouched."""
     out = tuple(unsplit3(t) if (t is not None and _is_limbs(t)) else t for t in ts)
@@ -698,6 +709,16 @@ def _conv2d_split(x, w, b, stride, relu, residual, padding, want_f32=False):
     N, H, W, C = x.shape
     kh, kw, cin, cout = w.shape
     assert cin == C, "split conv: input channels must match the kernel"
+    # tensors of the 16-bit kernels are addressed with 32-bit element offsets: 3C input channels (the deformable GEMM's 27 x 256 at 160 x 160)
+    # or 3 Cout output limbs can exceed 2^31 elements at batch 16 — such a call runs in batch slices
+    C3 = (3 * C + 7) // 8 * 8
+    ho, wo = (((H - kh) // stride + 1), ((W - kw) // stride + 1)) if padding == "valid" else (-(-H // stride), -(-W // stride))
+    nmax = ((1 << 31) - 1) // max(H * W * C3, ho * wo * 3 * ((cout + 7) // 8 * 8))
+    if N > nmax >= 1:
+        residual = _f32_in(residual)
+        parts = [_conv2d_split(x[i:i + nmax] if not _is_limbs(x) else _limb_view(x._dh_split3[i:i + nmax], C), w, b, stride, relu,
+                               None if residual is None else residual[i:i + nmax], padding, want_f32=True) for i in range(0, N, nmax)]
+        return torch.cat(parts, dim=0)
     x3 = split3(x)
     d3 = _desc(N, H, W, x3.shape[-1], cout, kh, kw, stride, padding == "valid")
     wf = _split_weight(d3, w, cin)
@@ -912,6 +933,11 @@ class _L2Norm(torch.autograd.Function):
 
 
 def l2_normalize(x, gamma):
+    if _is_limbs(x) and x.shape[-1] % 8 == 0 and x._dh_split3.shape[-1] == 3 * x.shape[-1]:
+        C = x.shape[-1]                                      # split-operand mode: normalised on the limb layout, for the head convolution that follows
+        y3 = torch.empty_like(x._dh_split3)
+        call("danhip_l2norm_split3", ptr(x._dh_split3), ptr(gamma.detach().float()), ptr(y3), y3.numel() // (3 * C), C, stream())
+        return _limb_view(y3, C)
     x = _f32_in(x)
     if _f32_infer(x):
         y = torch.empty_like(x)

@@ -59,6 +59,7 @@ def deform_conv_op(x, filter, offset, rates, padding, strides, num_groups, defor
                           with the deformable groups that slice covers (needs G | dg or dg | G), outputs concatenated.
     fp32 / fp64 activations stay unsupported on the training path (16-bit storage; the fp32 inference path is ops.*_f32)."""
     from .. import ops
+    x, offset = ops._f32_in(x, offset)               # (split-operand inference: limb views are widened here, before any slicing / transposing)
     if data_format == "NCHW":
         y = deform_conv_op(x.permute(0, 2, 3, 1).contiguous(), filter, offset.permute(0, 2, 3, 1).contiguous(), rates, padding, strides, num_groups,
                            deformable_group, bias=bias, relu=relu)

@@ -549,6 +549,8 @@ int danhip_comm_allgather(void* comm, const void* send, void* recv, int64_t send
 int danhip_split3_f32(const float* x, uint16_t* y3, int64_t M, int32_t C, int32_t C3, int relu, void* stream);
 int danhip_unsplit3_f32(const uint16_t* x3, float* y, int64_t M, int32_t C, int32_t C3, void* stream);
 int danhip_maxpool2x2_split3(const uint16_t* x3, uint16_t* y3, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+/* l2_normalize (net/sfd_net.py:68-79) on the limb layout -> limb layout; the arithmetic of unsplit -> danhip_l2norm_fwd_f32 -> split in one pass */
+int danhip_l2norm_split3(const uint16_t* x3, const float* gamma, uint16_t* y3, int64_t M, int32_t C, void* stream);
 
 /* ---- fp32 inference path (csrc/f32_infer.hip): the evaluation graphs of eval_sfd.py:232-283 / eval_pb.py / eval_dan.py:299-404 with fp32
  * storage and arithmetic end to end, for the north-star tolerance "eval box outputs within 1e-4 of the reference".  NHWC fp32

@@ -108,3 +108,33 @@ def test_two_split_convs_chained_through_the_limb_layout_and_a_pool(dev):
         y = ops.conv2d(y, ws[2].to(dev), bs[2].to(dev), relu=False, out_f32=True)
     assert y.dtype == torch.float32
     assert (y.cpu() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+
+
+def test_l2norm_on_the_limb_layout_equals_the_fp32_chain(dev):
+    """danhip_l2norm_split3 against unsplit -> danhip_l2norm_fwd_f32 -> split (same lane-strided sum, shuffle reduction and multiply order; the
+    two compilations may contract differently): equal to the limbs' own precision, 2^-20 of the map's maximum."""
+    from dan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn((2, 40, 56, 256), generator=g) * 3).to(dev)
+    gamma = (10 + torch.randn((256,), generator=g)).to(dev)
+    xv = ops._limb_view(ops.split3(x), 256)
+    got = ops.l2_normalize(xv, gamma)
+    assert ops._is_limbs(got)
+    want = ops.l2_normalize(ops.unsplit3(xv), gamma)
+    assert torch.equal(got._dh_split3[..., :256], got._dh_split3[..., 512:])
+    assert (ops.unsplit3(got) - want).abs().max().item() <= 2.0 ** -20 * want.abs().max().item()
+
+
+def test_a_split_conv_larger_than_2_pow_31_elements_runs_in_batch_slices(dev):
+    """The deformable GEMM's operand at batch 16 (27 x 256 limb channels at 160 x 160) exceeds the 16-bit kernels' 32-bit element offsets:
+    _conv2d_split slices the batch.  Here: 1 x 1 over 6144 channels (18432 limb channels), 6 images of 160 x 160 = 2.8e9 input elements."""
+    from dan_amd import ops
+    from oracle import tf_ops as T
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((6, 160, 160, 6144), generator=g, dtype=torch.float32)
+    w = torch.randn((1, 1, 6144, 8), generator=g) / 6144 ** 0.5
+    want = torch.einsum("nhwc,co->nhwo", x.double(), w[0, 0].double()).float()
+    with ops.use_context(ops.OpsContext(SPLIT_EVAL=True)), torch.no_grad():
+        got = ops._f32_in(ops.conv2d(x.to(dev), w.to(dev), None, relu=False)).cpu()
+    # (K = 6144 products accumulated in fp32: sqrt(K) * 2^-24 = 4.7e-6 of the terms' scale on top of the limbs' 2^-22)
+    assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()

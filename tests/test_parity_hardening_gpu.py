@@ -60,9 +60,11 @@ def test_batch16_gradient_at_640_is_the_sum_of_its_sixteen_images(dev):
         if scale < 1e-12:
             continue
         # activations and their gradients are per-image quantities, identical bit patterns in both runs unless a layer changes its
-        # kernel form with the batch size (bf16 re-rounding of a data gradient: 2^-9); the weight gradients differ by fp32 summation order
+        # kernel form with the batch size (split-K on the 20 x 20 ... 5 x 5 maps at one image: a data gradient re-rounded to bf16, 2^-9 per
+        # element, carried through the layers below); the weight gradients differ by fp32 summation order.  Measured: every variable
+        # <= 1e-2 except additional_layers/conv6_1 (2.0e-2); a dropped image or a mis-addressed tile is >= 6e-2 (1/16 of the sum)
         rel = (a - b).norm().item() / (b.norm().item() + 1e-30)
-        if rel > 2e-2:
+        if rel > 4e-2:
             bad.append((name, rel))
     assert not bad, bad[:8]
     cos = torch.nn.functional.cosine_similarity(g16, gsum, dim=0).item()
@@ -86,8 +88,8 @@ def test_twenty_step_trajectory_tracks_the_oracle(dev):
     model.vs.load_tf_named(P.t)
     anchors = AnchorConfig(S, S, dev)
     loc_t, cls_t, _ = anchors.encode_batch(synthetic.make_gt_boxes(B, S, S, seed=5, max_faces=6))
-    lr = 1e-3                                                 # (x 0.1 of the schedule's first segment would move nothing in 20 steps)
-    tr = SFDTrainer(model, base_lr=lr, lr_factors=(1.0, 1.0, 0.1, 0.01))
+    lr = 1e-4                                                 # the reference's own first segment: 1e-3 x 0.1 for steps <= 1000 (train_sfd.py:98-109, 429-434)
+    tr = SFDTrainer(model)
     w0 = {n: p.detach().clone().cpu() for n, p in model.vs.named()}
     # ---- oracle trajectory: bf16-storage emulation (weights / activations rounded as the HIP path stores them), fp32 master weights
     params = {n: v.clone() for n, v in P.t.items()}
@@ -111,9 +113,10 @@ def test_twenty_step_trajectory_tracks_the_oracle(dev):
         tr.train_step(dimgs, loc_t, cls_t)
         ce, ll, _, _ = tr.losses()
         got_losses.append((ce, ll))
+    curves = [(k, round(a[0], 4), round(b[0], 4), round(a[1], 4), round(b[1], 4)) for k, (a, b) in enumerate(zip(got_losses, ref_losses))]
     for k, ((ce, ll), (rce, rll)) in enumerate(zip(got_losses, ref_losses)):
-        assert abs(ce - rce) <= 0.03 * abs(rce) + 1e-3, ("cross entropy", k, ce, rce)
-        assert abs(ll - rll) <= 0.03 * abs(rll) + 1e-3, ("localisation", k, ll, rll)
+        assert abs(ce - rce) <= 0.03 * abs(rce) + 1e-3, ("cross entropy", k, ce, rce, curves)
+        assert abs(ll - rll) <= 0.03 * abs(rll) + 1e-3, ("localisation", k, ll, rll, curves)
     assert ref_losses[-1][0] + ref_losses[-1][1] < ref_losses[0][0] + ref_losses[0][1], "the oracle's loss did not go down: the run says nothing"
     # the parameters' MOVEMENT over the 20 steps: whole-model relative distance and direction
     num = den = dot = nrm = 0.0
@@ -167,3 +170,60 @@ def test_restore_from_a_bundle_the_repo_did_not_write(dev, tmp_path):
     mv = C._momentum_views(tr)
     for n in list(slots)[:5] + list(slots)[-5:]:
         assert np.array_equal(mv[n].detach().cpu().numpy(), slots[n]), n
+
+
+@pytest.mark.parametrize("which,H,W", [("sfd", 96, 96), ("pb", 64, 64), ("dan", 64, 96), ("dan_deform", 64, 96)])
+def test_free_running_decisions_flip_rarely_and_only_near_zero(which, H, W, dev, monkeypatch):
+    """(c) The tight gradient tests IMPOSE the HIP forward's discrete decisions on the oracle, so a wrong decision is invisible there
+    (VERDICT r5 weak 2).  Here nothing is imposed: the oracle (bf16-storage emulation) and the HIP path each take their own ReLU decisions on the
+    same weights and image, and the test bounds how often they differ and where — per ReLU layer at most 1.5 % of the elements flip (measured,
+    profiles/r6/decision_flips.jsonl: S3FD <= 0.24 %, PyramidBox <= 0.39 %, DAN <= 0.52 %; medians 0.06-0.13 %), and every flipped element is
+    small in BOTH runs (|activation| <= 2 % of the layer's maximum; measured <= 0.8 %: a pre-activation within 16-bit rounding of zero, not
+    a wrong decision).  With the flip rate bounded, what the imposed tests cover is the remaining 98 %+ of each layer.  DANHIP_TEST_REPORT_DIR:
+    the per-graph worst layers are written there (profiles/r6/decision_flips.jsonl has the measured figures)."""
+    import gradcheck as GC
+    from dan_amd import ops
+    model, flat, ofwd, P, imgs, x = GC.setup(which, H, W, 2, dev, torch.bfloat16)
+    own = {}
+    real_relu = ON._relu
+
+    def recording_relu(Pp, y, scope):
+        out = real_relu(Pp, y, scope)
+        own[scope + "/kernel"] = out.detach()
+        return out
+
+    monkeypatch.setattr(ON, "_relu", recording_relu)
+    with torch.no_grad():
+        flat(ofwd(ON.Params({n: v.clone() for n, v in P.t.items()}, emulate_bf16=True), x))
+    monkeypatch.setattr(ON, "_relu", real_relu)
+    trace = {}
+    ops.TRACE = {}
+    try:
+        model.forward(imgs.to(dev))      # (gradients tracked: the training graph — at inference DAN fuses a residual add into some ReLU convolutions'
+        rec, ops.TRACE = ops.TRACE, None  #  epilogues, and what TRACE then holds for them is relu(conv) + x, not a ReLU output)
+    finally:
+        ops.TRACE = None
+    GC.collect_trace(model.vs.named(), rec, trace)
+    layers = [n for n in trace["relu"] if n in own and trace["relu"][n].shape == own[n].shape]
+    assert len(layers) >= (13 if which == "sfd" else 30), (len(layers), len(trace["relu"]), len(own))
+    worst = []
+    for n in layers:
+        a, b = trace["relu"][n], own[n]
+        if a.min().item() < 0:                     # (what the HIP path recorded for this kernel is not a bare ReLU output: a fused residual)
+            continue
+        flip = (a > 0) != (b > 0)
+        rate = flip.float().mean().item()
+        scale = max(b.abs().max().item(), 1e-12)
+        size = (torch.maximum(a.abs(), b.abs())[flip].max().item() / scale) if flip.any() else 0.0
+        worst.append((rate, size, n))
+    worst.sort(reverse=True)
+    import json, os
+    rep = os.environ.get("DANHIP_TEST_REPORT_DIR")
+    if rep:
+        os.makedirs(rep, exist_ok=True)
+        with open(os.path.join(rep, "decision_flips.jsonl"), "a") as f:
+            f.write(json.dumps({"graph": which, "relu_layers": len(worst), "max_flip_rate": worst[0][0], "median_flip_rate": sorted(w[0] for w in worst)[len(worst) // 2],
+                                "max_flipped_activation_over_layer_max": max(w[1] for w in worst), "worst_layers": [[round(r, 5), round(z, 5), n] for r, z, n in worst[:3]]}) + "\n")
+    assert len(worst) >= (13 if which == "sfd" else 30)
+    assert worst[0][0] <= 0.015, worst[:5]
+    assert max(w[1] for w in worst) <= 0.02, sorted(worst, key=lambda w: -w[1])[:5]
