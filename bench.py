@@ -520,8 +520,8 @@ def main():
         # happen inside this process).  The file is stamped with the hash of the kernel sources it was measured on: with other sources
         # the numbers describe another binary and `traffic` is null (the stale figure is reported beside it, flagged).
         traffic, traffic_stale, pmc = None, None, {}
-        tj = next((c for c in (os.path.join(ROOT, "profiles", r, "pmc_bench_traffic.json") for r in ("r5", "r4", "r3")) if os.path.exists(c)),
-                  os.path.join(ROOT, "profiles", "r5", "pmc_bench_traffic.json"))
+        tj = next((c for c in (os.path.join(ROOT, "profiles", r, "pmc_bench_traffic.json") for r in ("r6", "r5", "r4", "r3")) if os.path.exists(c)),
+                  os.path.join(ROOT, "profiles", "r6", "pmc_bench_traffic.json"))
         if os.path.exists(tj):
             pmc = json.load(open(tj))
             t = pmc.get(label)

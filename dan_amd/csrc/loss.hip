@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void kth_largest_rows_kernel(const float* __r
   k = min(k, counts[b * 2 + 1]);
   if (at_least_one) k = max(k, 1);
   if (threadIdx.x == 0) kout[b] = k;
+  // (k derives from counts[b] alone: it is BLOCK-UNIFORM, so this return in front of the loops' __syncthreads() is taken by all 1024 threads or none)
   if (k <= 0 || k > A) { if (threadIdx.x == 0) thr[b] = k <= 0 ? INFINITY : -INFINITY; return; }
   [[maybe_unused]] unsigned keys[KREG > 0 ? KREG : 1];
   if constexpr (KREG > 0) {

@@ -179,3 +179,33 @@ def test_pooling_conv_epilogues_write_the_same_arg_max_codes_as_the_pool_kernel(
                   _lib.ptr(arg2), _lib.stream())
         torch.cuda.synchronize()
         assert torch.equal(arg2, arg_ref)
+
+
+@pytest.mark.parametrize("A", [87360, 36 * 1024 + 1, 88 * 1024 + 5])
+def test_hard_negative_threshold_at_1024_sized_anchor_counts_equals_topk(A, dev):
+    """The k-th-largest selection of hard-negative mining at the anchor count of a 1024 x 1024 input (87 360: the 88-register instantiation of
+    kth_largest_rows_kernel: 128 VGPRs, no scratch — ADVICE r5), just past the 36-register one, and past 88 * 1024 (the streaming form): the
+    threshold equals torch.topk's k-th value bit for bit and the selection has exactly k negatives (train_dan.py:286-324: k = max(min(3 n_pos, n_neg), 1))."""
+    import ctypes
+    from dan_amd import _lib
+    B = 3
+    g = torch.Generator().manual_seed(A)
+    cls = (torch.randn((B, A, 2), generator=g) * 3).to(dev)
+    labels = torch.zeros((B, A), dtype=torch.int32)
+    labels[0, :500] = 1; labels[0, 500:900] = -1
+    labels[1, 7] = 1
+    labels[2, ::3] = 1                                     # 3 n_pos > n_neg: k = n_neg
+    labels = labels.to(dev)
+    score = torch.empty((B, A), dtype=torch.float32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    thr = torch.empty((B,), dtype=torch.float32, device=dev)
+    k = torch.empty((B,), dtype=torch.int32, device=dev)
+    _lib.call("danhip_hard_neg_select", _lib.ptr(cls), _lib.ptr(labels), _lib.ptr(score), _lib.ptr(counts), _lib.ptr(thr), _lib.ptr(k), B, A, 3.0, 1, _lib.stream())
+    torch.cuda.synchronize()
+    for b in range(B):
+        n_pos, n_neg = int((labels[b] > 0).sum()), int((labels[b] == 0).sum())
+        kk = max(min(3 * n_pos, n_neg), 1)
+        assert counts[b].tolist() == [n_pos, n_neg] and int(k[b]) == kk
+        want = torch.topk(score[b], kk).values[-1]
+        assert thr[b].item() == want.item(), (A, b, kk, thr[b].item(), want.item())
+        assert int(((labels[b] == 0) & (score[b] >= thr[b])).sum()) >= kk

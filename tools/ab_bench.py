@@ -30,7 +30,7 @@ def main():
     ms = {n: [] for n, _ in arms}
     for r in range(a.rounds):
         for name, env in arms:
-            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--no-cpu-baseline", "--no-eval", "--strong-global-batch", "0",
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--no-cpu-baseline", "--no-eval", "--strong-global-batch", "0", "--strong16-global-batch", "0",
                    "--no-serialized-roofline", "--events-steps", "1"] + a.bench_args.split()
             out = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True)
             lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
