@@ -514,7 +514,11 @@ def main():
             fl = sum(f for _, _, f in evs)
             stats.append((ms, label, len(evs), fl))
         stats.sort(reverse=True)
-        ms, label, n, fl = stats[0]
+        # The DOMINANT kernel is the one that carries the largest share of the step's FLOPs (round 6).  Ranking by bracketed time let a kernel
+        # with a thousandth of the FLOPs take the slot whenever its brackets were inflated as a family (DAN at 1024 x 1024, eager: the 16-channel
+        # flat-M head kernel "averaging" 37 ms inside a 40 ms step, frac 0.0000 - profiles/r6/size1024_lines.jsonl of the first collection);
+        # for S3FD both rankings name conv_wgrad_rows_kernel<128>.  `kernels` below stays ranked by time, so such a family remains visible.
+        ms, label, n, fl = max(stats, key=lambda t: t[3])
         achieved = fl / (ms * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC passes (tools/pmc_bench.sh; PMC collection needs its own rocprofv3 runs, so it cannot
         # happen inside this process).  The file is stamped with the hash of the kernel sources it was measured on: with other sources

@@ -63,6 +63,7 @@ SIGNATURES = {
     "danhip_conv2d_bwd_data": [DESC, P, P, P, P, ctypes.c_int, P],
     "danhip_conv2d_bwd_data_ws": [DESC, P, P, P, P, ctypes.c_int, P, ctypes.c_size_t, P],
     "danhip_conv2d_bwd_data_bits": [DESC, P, P, P, P, ctypes.c_int, P],
+    "danhip_conv2d_bwd_data_bits_first": [DESC, P, P, P, P, I32, P, P, P],
     "danhip_relu_bits": [P, P, I64, I32, P],
     "danhip_conv2d_fwd_relu_bits": [DESC, P, P, P, P, P, P, P, P],
     "danhip_conv2d_bwd_weight": [DESC, P, P, P, P, I32, P],
@@ -223,6 +224,8 @@ def _load(so_path, act_name):
         L.danhip_conv2d_fwd_emits_bits.argtypes = [DESC, ctypes.c_int]
         L.danhip_conv2d_bwd_data_takes_bits.restype = ctypes.c_int
         L.danhip_conv2d_bwd_data_takes_bits.argtypes = [DESC]
+        L.danhip_conv2d_bwd_data_first_supported.restype = ctypes.c_int
+        L.danhip_conv2d_bwd_data_first_supported.argtypes = [DESC]
         L.danhip_deform_conv_fused.restype = ctypes.c_int
         L.danhip_deform_conv_fused.argtypes = [I32] * 9
         L.danhip_bbox_vote_workspace_bytes.argtypes = [I32, I32]

@@ -39,6 +39,14 @@ struct ConvArgs {
   // convolution — hi = half(v) at column co, lo = half(v - hi) at Co + co, hi again at 2 Co + co — written from the fp32 epilogue value.
   // Honoured by conv_halo.hip's general epilogue and by the flat-M kernel / split-K finish (conv_store4); every other kernel declines.
   int split_out;
+  // conv_halo_c64.hip, data gradient of the SECOND layer (conv1_2) with the FIRST layer's weight gradient folded in (round 6): dx of this
+  // call is conv1_1's dY; conv1_1 has no data gradient of its own, so dx's only reader would be conv_wgrad_c8.hip.  With fuse_dw set the
+  // kernel keeps each dx tile in LDS, multiplies it with the tile's patch of the 8-channel image x8 (transposing reads, M = 12 tap slots x 4
+  // channels, N = 64) into per-wave accumulators and never stores dx (y == NULL allowed): dw8 [3,3,cin_real,64] / db8 [64] fp32, atomically added.
+  const bf16_t* fuse_x8;
+  float* fuse_dw;
+  float* fuse_db;
+  int fuse_cin_real;
 };
 
 // hi / lo limbs of 4 fp32 values as two packed pairs each (the build's 16-bit type: IEEE half where split_out is allowed)

@@ -24,8 +24,18 @@ __device__ __forceinline__ void c64_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool DGRAD>
+// FUSE8 (round 6, data gradient only): the call is conv1_2's data gradient and its output dX is conv1_1's dY, which nothing reads but conv1_1's
+// WEIGHT gradient (the first layer has no data gradient).  Instead of storing dX (839 MB per batch-16 step at 640 x 640) for conv_wgrad_c8.hip to
+// read back (188 us, the LAST kernel of backward, with the other queue empty), every tile's masked dX goes to LDS in 16 bits — the values the store
+// would have written — and multiplied with the tile's 10 x 34 patch of the 8-channel image as conv_wgrad_c8.hip does (both MFMA operands by
+// ds_read_b64_tr_b16, the nine taps as address offsets into the patch, tap slot 9 = the constant [1, 0, 0, 0] whose row is the bias gradient).
+// The register file is full (144 weight + 32 accumulator + 48 pixel-fragment registers of 256), so the gradient tile M = 12 tap slots x 4 channels,
+// N = 64 is split over the waves by N: wave w owns output channels 16 (w & 3) .. +15 for tile rows 4 (w >> 2) .. +3 — 12 accumulator registers,
+// 12 MFMAs and 32 transposing reads per tile, one extra workgroup barrier.  At the end the waves' accumulators are summed in LDS and leave the CU
+// as 1728 + 64 fp32 atomics.
+template <bool DGRAD, bool FUSE8 = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(const ConvArgs a, const C64Geom g) {
+  static_assert(DGRAD || !FUSE8, "the folded first-layer weight gradient belongs to the data gradient");
   constexpr int TH = 8, TW = 32, PW = TW + 2;
   constexpr int PROWS = (TH + 2) * PW, PPIECES = (PROWS + 7) / 8, PBYTES = PPIECES * 1024, PL = (PPIECES + 7) / 8;
   constexpr int NPT = 4, NCT = 2;                  // wave tile: 64 pixels (2 tile rows) x 32 channels
@@ -107,6 +117,25 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * 8u : 0xFFFFFFFFu;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_AS void*)(smem + RWBASE + bbuf * 2048 + wave * 1024), 16, off, 0, 0, 0);
   };
+  // FUSE8 LDS map inside the epilogue-input region (bit-mask form only: the 16-bit mask / old-value areas are unused):
+  //   [RWBASE, +4096) bit masks (2 buffers) | [+4096, +4096 + 2 * 6144) image patches (2 buffers: 340 pixels x 16 bytes in six 1 KiB DMA pieces)
+  //   | [+16384, +16384 + 32768) the dX tile [256 pixels][64 channels] | [+49152, +16) the constant fragment [1, 0, 0, 0 | 0 ...]
+  constexpr int IMGBASE = RWBASE + 4096, IMGBYTES = 6144, DXBASE = RWBASE + 16384, C1BASE = RWBASE + 49152;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(FUSE8 ? a.fuse_x8 : a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 16u), 0x00020000);
+  [[maybe_unused]] auto issue_img = [&](int sp, int ibuf) __attribute__((always_inline)) {
+    if (wave >= 6) return;                         // (uniform per wave) 340 patch pixels = six pieces of 64
+    int n, y0, x0;
+    sp_coords(sp, n, y0, x0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                   // (recomputed per tile: the register file has no room for hoisted geometry)
+    const int e = wave * 64 + ln;
+    const int r = e / PW, c = e - r * PW;
+    const int y = y0 - 1 + r, x = x0 - 1 + c;
+    const bool ok = e < PROWS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_i, (LDS_AS void*)(smem + IMGBASE + ibuf * IMGBYTES + wave * 1024), 16,
+                                             ok ? (unsigned)((n * a.H + y) * a.W + x) * 16u : 0xFFFFFFFFu, 0, 0, 0);
+  };
   auto issue_rw = [&](int sp) __attribute__((always_inline)) {
     int n, y0, x0;
     sp_coords(sp, n, y0, x0);
@@ -141,6 +170,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   for (int c = 0; c < NCT; ++c)
 #pragma unroll
     for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // FUSE8: this wave's slice of conv1_1's gradient (12 tap slots x 4 channels x its 16 output channels), accumulated over all its tiles
+  [[maybe_unused]] f32x4 facc[3];
+  if constexpr (FUSE8) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) facc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) reinterpret_cast<bf16_t*>(smem + C1BASE)[tid] = tid == 0 ? f2bf(1.0f) : (bf16_t)0;
+  }
 
   bf16x8 xa[NPT], xb[NPT], xc[NPT];
   auto read_px = [&](bf16x8 (&x)[NPT], auto tapc, int ks) __attribute__((always_inline)) {
@@ -181,6 +218,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if constexpr (DGRAD) {
       issue_rw(sp);                                // this tile's mask / old value (its own reads of the region ended with its last epilogue)
       if (a.mask_bits) issue_bits(sp, buf);
+      if constexpr (FUSE8) issue_img(sp, buf);     // this tile's image patch (its buffer's last reads ended two hand-off barriers ago)
     }
     if (has_next) issue_patch(nsp, buf ^ 1);       // the other buffer was released by the barrier that ended the previous tile
     // ---- 18 half-taps (tap, k-slice); pixel fragments software-pipelined TWO half-taps ahead through three rotating
@@ -285,12 +323,49 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             // (mask and old value were folded into acc above)
           }
           const u32x4 tt = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          if (a.y)            // (uniform; NULL = the pool-only inference call: the full-resolution map is never written)
+          if (a.y)            // (uniform; NULL = the pool-only inference call / the folded first-layer gradient: the map is never written)
             __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
           pk[p] = tt;
         }
+        if constexpr (FUSE8)                         // the tile of dX the store would have written (zeros outside the image), [pixel][64 channels]
+          *reinterpret_cast<u32x4*>(smem + DXBASE + t * 128 + cbase * 2) = pk[p];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (FUSE8) {
+        // ---- conv1_1's weight + bias gradient of this tile: dW[tap][c][co] += sum over pixels of X8[pixel @ tap][c] * dX[pixel][co]
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // (lgkmcnt(0): this wave's tile writes are in LDS)
+        __builtin_amdgcn_s_barrier();                 // ... and so is everybody else's
+        const char* im = smem + IMGBASE + buf * IMGBYTES;
+        // lane 4q+p of 16-lane group g supplies pixel 8g + q (+ 4h) of the row: tap slot p of M tile mt (image side), channels 4p..4p+3 of
+        // the wave's N tile (dX side) — conv_wgrad_c8.hip's fragment addressing with a 32-pixel row
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                  // (as above: nothing of this block may be hoisted into long-lived registers)
+        const int gg = ln >> 4, qq = (ln & 15) >> 2, pp = ln & 3;
+        const int nt = wave & 3, r0 = (wave >> 2) * 4;
+        const int ybase = DXBASE + (8 * gg + qq) * 128 + pp * 8 + nt * 32;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = r0 + rr;
+          s16x4 xh[2][3], yh[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+              const int tap = mt * 4 + pp;
+              const int ti = tap / 3, tj = tap - ti * 3;
+              const char* ad = tap < 9 ? im + ((row + ti) * PW + 8 * gg + qq + tj + 4 * h) * 16 : smem + C1BASE + (tap == 9 ? 0 : 8);
+              xh[h][mt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)ad);
+            }
+            yh[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + ybase + (row * 32 + 4 * h) * 128));
+          }
+          const bf16x8 yf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(yh[0], yh[1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+          for (int mt = 0; mt < 3; ++mt) {
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xh[0][mt], xh[1][mt], 0, 1, 2, 3, 4, 5, 6, 7));
+            facc[mt] = DH_MFMA_16x16x32(xf, yf, facc[mt]);
+          }
+        }
       }
       if (!DGRAD && a.pool_y) {
         // fused 2x2 / stride-2 SAME max-pool (pool1, net/sfd_net.py:132): wave rows (2*wm, 2*wm+1); fragments p = 0,1 are the top
@@ -328,6 +403,26 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
       for (int p = 0; p < NPT; ++p) pxaddr[j][p] += dir;
   }
+  if constexpr (FUSE8) {
+    // ---- eight waves -> one gradient in LDS -> global atomics (conv_wgrad_c8.hip).  Lane holds facc[mt][r] = dW[tap slot mt*4 + g][channel r][co]
+    // of the wave's N tile: co = 16 (wave & 3) + (lane & 15); waves w and w + 4 own the same tile for different rows
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                   // every wave is past its last reads of the patch buffers: reuse buffer 0
+    float* red = reinterpret_cast<float*>(smem);    // [12 slots][4 channels][64 co]
+    for (int i = tid; i < 12 * 4 * 64; i += 512) red[i] = 0.f;
+    __syncthreads();
+    const int gg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[((mt * 4 + gg) * 4 + r) * 64 + (wave & 3) * 16 + (lane & 15)], facc[mt][r]);
+    __syncthreads();
+    for (int i = tid; i < 9 * 4 * 64; i += 512) {
+      const int co = i & 63, c = (i >> 6) & 3, slot = i >> 8;
+      if (c < a.fuse_cin_real) atomicAdd(a.fuse_dw + (size_t)(slot * a.fuse_cin_real + c) * 64 + co, red[i]);
+    }
+    if (a.fuse_db && tid < 64) atomicAdd(a.fuse_db + tid, red[(9 * 4 + 0) * 64 + tid]);
+  }
 }
 
 int c64_cu_count() {
@@ -351,11 +446,11 @@ bool c64_eligible(const ConvArgs& a) {
   return util >= 0.78 && (int64_t)a.N * a.H * a.W * ldmax * 2 < (1ll << 32);
 }
 
-template <bool DGRAD>
+template <bool DGRAD, bool FUSE8 = false>
 int launch_c64(const ConvArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024 + (DGRAD ? 65536 : 256);      // patches + (mask, old) tiles | bias
   static const bool attr_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<DGRAD, FUSE8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
   C64Geom g{};
   g.tiles_x = (a.W + 31) / 32;
@@ -365,7 +460,7 @@ int launch_c64(const ConvArgs& a, hipStream_t s) {
   g.div_txy = make_fastdiv(g.tiles_x * g.tiles_y);
   int G = c64_cu_count();
   if (g.sp_items < G) G = g.sp_items;
-  hipLaunchKernelGGL((conv3x3_c64_kernel<DGRAD>), dim3(G), dim3(512), LDS, s, a, g);
+  hipLaunchKernelGGL((conv3x3_c64_kernel<DGRAD, FUSE8>), dim3(G), dim3(512), LDS, s, a, g);
   DH_LAUNCH_CHECK();
   return DANHIP_OK;
 }
@@ -377,6 +472,10 @@ int danhip_launch_conv_c64(const ConvArgs& a, hipStream_t s) {
   const bool dgrad = !a.bias && !a.relu && !a.resid;
   if (!dgrad && (a.accumulate || a.mask || a.mask_bits)) return 1;
   if (a.mask && a.mask_bits) return 1;              // one mask form per call (the bits share the 16-bit mask's LDS region)
+  if (a.fuse_dw) {                                  // conv1_1's weight gradient folded into this data gradient (bit-mask form, dense tensors)
+    if (!dgrad || !a.mask_bits || a.accumulate || a.strided() || !a.fuse_x8 || a.fuse_cin_real < 1 || a.fuse_cin_real > 4) return 1;
+    return launch_c64<true, true>(a, s);
+  }
   return dgrad ? launch_c64<true>(a, s) : launch_c64<false>(a, s);
 }
 

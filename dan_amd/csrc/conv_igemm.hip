@@ -1000,6 +1000,32 @@ extern "C" int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d) {
   return danhip_conv_halo_takes_bits(a) ? 1 : 0;
 }
 
+// conv1_2's data gradient with conv1_1's weight / bias gradient folded in (conv_halo_c64.hip FUSE8): dX is never written.
+extern "C" int danhip_conv2d_bwd_data_first_supported(const danhip_conv_desc* d) {
+  if (!d || check_desc(d) != DANHIP_OK || d->stride != 1) return 0;
+  ConvArgs a = bwd_args(d);
+  static const unsigned char dummy = 0;
+  a.mask_bits = &dummy;
+  return (danhip_conv_c64_eligible(a) && !a.strided() && a.W % 2 == 0 && (int64_t)a.N * a.H * a.W * 16 < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int danhip_conv2d_bwd_data_bits_first(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
+                                                 const uint16_t* x8, int32_t cin_real, float* dw8, float* db8, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  DH_REQUIRE(dy && wb_packed && relu_bits && x8 && dw8, DANHIP_EINVAL, "conv2d_bwd_data_bits_first: null pointer");
+  DH_REQUIRE(cin_real >= 1 && cin_real <= 4, DANHIP_EINVAL, "conv2d_bwd_data_bits_first: cin_real = %d (1..4 real channels of the 8-channel image)", cin_real);
+  DH_REQUIRE(danhip_conv2d_bwd_data_first_supported(d), DANHIP_EINVAL, "conv2d_bwd_data_bits_first: not the 64 -> 64 3x3 shape the folded kernel takes "
+             "(ask danhip_conv2d_bwd_data_first_supported first)");
+  ConvArgs a = bwd_args(d);
+  a.x = dy; a.w = wb_packed; a.bias = nullptr; a.mask = nullptr; a.mask_bits = relu_bits; a.resid = nullptr; a.y = nullptr;
+  a.relu = 0; a.out_f32 = 0; a.accumulate = 0;
+  a.fuse_x8 = x8; a.fuse_dw = dw8; a.fuse_db = db8; a.fuse_cin_real = cin_real;
+  rc = danhip_launch_conv_c64(a, (hipStream_t)stream);
+  DH_REQUIRE(rc <= 0, DANHIP_EINVAL, "conv2d_bwd_data_bits_first: the folded kernel declined the call");
+  return rc;
+}
+
 extern "C" int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
                                            uint16_t* dx, int accumulate, void* stream) {
   int rc = check_desc(d);

@@ -40,13 +40,16 @@ class OpsContext(object):
                        side stream waits for dY only, not for the data gradient.  Measured slower (round 6, same box, alternating: 12.81 against
                        12.73 ms): both kernels are full-chip persistent grids, "beside each other" means taking turns, and the data gradient —
                        the critical path — then queues behind the weight gradient's workgroups
+      FUSE_FIRST_WGRAD [DANHIP_FUSE_FIRST_WGRAD, 1]  0: conv1_2's data gradient stores its output and conv1_1's weight gradient is a launch of its own
+                       (rounds 1-5); 1: the first layer's weight / bias gradient is folded into the second layer's data gradient
+                       (danhip_conv2d_bwd_data_bits_first: conv1_1's dY never reaches HBM) where a trainer's gradient sinks exist
       SPLIT_EVAL       True: convolutions of the fp32 inference path run as split-operand products on the fp16 MFMA (csrc/split_infer.hip;
                        models set it for precision "split"): fp32-accurate boxes at a third of the 16-bit rate instead of a tenth
     Diagnostic sinks (None = off): TRACE (tests: activations / decisions by variable id), PROFILE / PROFILE_BYTES (bench.py: HIP events
     and algorithmic bytes per convolution launch).
     Per-step state a trainer arms: GRAD_READY_HOOK (a parameter's gradient is final), LOSS_SCALE_DEV (device scalar of the dynamic loss
     scale), wgrad (the second backward stream: {"on", "side", "main", "keep"})."""
-    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "WGRAD_FIRST", "SPLIT_EVAL", "TRACE",
+    __slots__ = ("USE_SPLITK", "USE_SLOTS", "USE_RELU_BITS", "USE_POOL_ARG", "POOL_ONLY_TRAIN", "KEEP_DEFORM_COL", "WGRAD_STREAM", "WGRAD_FIRST", "FUSE_FIRST_WGRAD", "SPLIT_EVAL", "TRACE",
                  "PROFILE", "PROFILE_BYTES", "GRAD_READY_HOOK", "LOSS_SCALE_DEV", "wgrad")
 
     def __init__(self, **overrides):
@@ -59,6 +62,7 @@ class OpsContext(object):
         self.KEEP_DEFORM_COL = True
         self.WGRAD_STREAM = env("DANHIP_WGRAD_STREAM", "1") == "1"
         self.WGRAD_FIRST = env("DANHIP_WGRAD_FIRST", "0") == "1"
+        self.FUSE_FIRST_WGRAD = env("DANHIP_FUSE_FIRST_WGRAD", "1") == "1"
         self.SPLIT_EVAL = False
         self.TRACE = self.PROFILE = self.PROFILE_BYTES = None
         self.GRAD_READY_HOOK = self.LOSS_SCALE_DEV = None
@@ -418,9 +422,10 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, relu, out_f32, residual, w_param, b_param, xslot, yslot, pool_out=None, valid=False, block_grads=0, xbits=None, bits_out=None,
-                pool_only=False, tracked=True):
+                pool_only=False, tracked=True, first=None):
         N, H, W, C = x.shape
         kh, kw, cin_real, cout = w.shape
+        ctx.first = first                                # (image, kernel, bias, real channels) of the FIRST layer when x is its output (conv2d)
         assert x.dtype == ACT and x.is_contiguous(), "conv input must be contiguous NHWC bf16"
         assert C % 8 == 0 and cin_real <= C
         d = _desc(N, H, W, C, cout, kh, kw, stride, valid)
@@ -527,7 +532,7 @@ class _Conv2d(torch.autograd.Function):
                 call("danhip_relu_bwd_bias_grad", ptr(dy), ptr(y), None, M, co8, stream())
             g = dy if g is None else g.add_(dy)
         if g is None:                                    # no gradient reached this layer
-            return (None,) * 18
+            return (None,) * 19
         db_in_wgrad = need_db and need_dw                        # the weight-gradient kernel also emits the bias gradient
         if need_db and not db_in_wgrad:
             if co8 == d.Cout:
@@ -545,11 +550,25 @@ class _Conv2d(torch.autograd.Function):
         dx = None
         dw = None
         hooked = False
+        fused_first = False
 
         def launch_dx():
-            nonlocal dx
+            nonlocal dx, fused_first
             if ctx.needs_input_grad[0]:
                 xs = ctx.xslot
+                fi = ctx.first
+                if (fi is not None and _CTX.FUSE_FIRST_WGRAD and xs is not None and xs.is_relu and xs.count == 0 and ctx.xbits is not None
+                        and _grad_sink(fi[1]) is not None and (fi[2] is None or _grad_sink(fi[2]) is not None)
+                        and _lib.lib().danhip_conv2d_bwd_data_first_supported(ctypes.byref(d))):
+                    # x is the FIRST layer's output: that layer has no data gradient, so this call's dX would be read by nothing but its weight
+                    # gradient — the kernel folds that product in (dX tile in LDS x image patch), adds it to the first layer's gradient sinks and
+                    # never stores dX; the slot stays empty and the first layer's backward finds nothing to do
+                    e0 = _prof_begin()
+                    call("danhip_conv2d_bwd_data_bits_first", ctypes.byref(d), ptr(g), ptr(wb), ptr(relu_bits(x, ctx.xbits)), ptr(fi[0]), int(fi[3]),
+                         ptr(_grad_sink(fi[1])), ptr(_grad_sink(fi[2])) if fi[2] is not None else None, stream())
+                    _prof_end(e0, d, 5, wrote_y=False)       # (dX is never stored: algorithmic bytes = dY + bit mask + image + weights)
+                    fused_first = True
+                    return
                 if xs is not None:                           # deliver straight into the producer's slot (+ its ReLU backward)
                     buf, acc = xs.target()
                     e0 = _prof_begin()
@@ -606,7 +625,9 @@ class _Conv2d(torch.autograd.Function):
             db = None
         if _CTX.GRAD_READY_HOOK is not None and wp is not None and not hooked:
             _CTX.GRAD_READY_HOOK(wp)
-        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None, None
+        if fused_first and _CTX.GRAD_READY_HOOK is not None:
+            _CTX.GRAD_READY_HOOK(ctx.first[1])           # the first layer's gradients are final too (its own backward will find nothing to do)
+        return dx, dw, db, None, None, None, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ---- fp32 inference path (csrc/f32_infer.hip): every op below accepts fp32 NHWC activations and then runs the fp32 kernels — forward
@@ -766,7 +787,10 @@ def conv2d(x, w, b=None, stride=1, relu=False, out_f32=False, residual=None, poo
     # (POOL_ONLY_TRAIN; off while a test records activations through TRACE)
     po = (1 if not track else (2 if (_CTX.POOL_ONLY_TRAIN and _CTX.TRACE is None and _CTX.USE_SLOTS and yslot is not None) else 0)) if pool_only else 0
     y = _Conv2d.apply(x, w, b, stride, relu, out_f32, residual, wp, bp, xs, yslot, pool_out, padding == "valid", blk, xbits, bits_out,
-                      po, bool(track))
+                      po, bool(track), getattr(x, "_dh_first", None) if track else None)
+    if (track and relu and not x.requires_grad and wp is not None and x.shape[-1] == 8 and w.shape[2] <= 4 and w.shape[3] == 64 and w.shape[0] == 3
+            and w.shape[1] == 3 and stride == 1 and padding == "same" and residual is None and not out_f32):
+        y._dh_first = (x, wp, bp, w.shape[2])               # the first layer (image in, no data gradient): its consumer may fold its weight gradient in
     if getattr(y, "_dh_already_pooled", False):
         return y
     if _CTX.TRACE is not None and relu and wp is not None:

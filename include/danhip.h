@@ -154,6 +154,15 @@ int danhip_conv2d_fwd_emits_bits(const danhip_conv_desc* d, int with_pool);
 int danhip_conv2d_fwd_relu_bits(const danhip_conv_desc* d, const uint16_t* x, const uint16_t* wf_packed, const float* bias, uint16_t* y,
                                 uint8_t* y_bits, uint16_t* pool_y, uint8_t* pool_bits, void* stream);
 int danhip_conv2d_bwd_data_takes_bits(const danhip_conv_desc* d);
+/* The data gradient of the SECOND layer (conv1_2: 3x3, 64 -> 64) with the FIRST layer's weight / bias gradient folded into it (round 6).  conv1_1 has
+ * no data gradient (its input is the image), so the dX this call would store is read by nothing but conv1_1's weight gradient: the kernel keeps each
+ * dX tile in LDS, multiplies it with the tile's patch of the 8-channel image x8 ([N,H,W,8], cin_real <= 4 real channels) and ADDS the result to
+ * dw8 [3,3,cin_real,64] / db8 [64] (fp32, may be NULL) — dX never reaches HBM and the first layer's own weight-gradient launch disappears
+ * (train_sfd.py's graph: net/sfd_net.py:128 conv1 block).  relu_bits = the bit mask of conv1_1's output (danhip_conv2d_bwd_data_bits).
+ * danhip_conv2d_bwd_data_first_supported(d) == 1 where the kernel takes descriptor d (else: danhip_conv2d_bwd_data_bits + danhip_conv2d_bwd_weight). */
+int danhip_conv2d_bwd_data_first_supported(const danhip_conv_desc* d);
+int danhip_conv2d_bwd_data_bits_first(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
+                                      const uint16_t* x8, int32_t cin_real, float* dw8, float* db8, void* stream);
 int danhip_conv2d_bwd_data_bits(const danhip_conv_desc* d, const uint16_t* dy, const uint16_t* wb_packed, const uint8_t* relu_bits,
                                 uint16_t* dx, int accumulate, void* stream);
 

@@ -844,3 +844,89 @@ def test_first_layer_weight_gradient_kernel_vs_the_oracle_and_the_general_kernel
         assert (dw - w.grad).abs().max().item() <= 1e-3 * sw + 2e-6 * N * H * W ** 0.5      # (+ the 0.5 start value's fp32 rounding of large sums)
         assert (db - b.grad).abs().max().item() <= 1e-3 * sb + 2e-6 * N * H * W ** 0.5
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-3 * sw + 2e-6 * N * H * W ** 0.5
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 64), (1, 30, 62), (9, 64, 128), (3, 40, 96), (2, 128, 128)])
+def test_second_layer_data_gradient_with_the_first_layers_weight_gradient_folded_in(shape, dev):
+    """danhip_conv2d_bwd_data_bits_first (conv_halo_c64.hip FUSE8, round 6): conv1_2's data gradient that keeps its output tiles in LDS and folds
+    conv1_1's weight / bias gradient in, against the two calls it replaces on the SAME inputs — danhip_conv2d_bwd_data_bits (dX stored in 16
+    bits) followed by danhip_conv2d_bwd_weight of the first layer on that dX.  Both consume the identical 16-bit dX values; what differs is the
+    fp32 summation order: 1e-4 of the gradient's max-norm.  Ragged tile edges, several tiles per workgroup, more tiles than workgroups; the
+    gradients are ADDED to what the sinks hold."""
+    import ctypes
+    from dan_amd import ops
+    from dan_amd._lib import call, lib, ptr, stream
+    N, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    d1 = ops._desc(N, H, W, 8, 64, 3, 3, 1)
+    d2 = ops._desc(N, H, W, 64, 64, 3, 3, 1)
+    assert lib().danhip_conv2d_bwd_data_first_supported(ctypes.byref(d2)) == 1
+    x0 = torch.zeros((N, H, W, 8), dtype=torch.bfloat16)
+    x0[..., :3] = torch.randn((N, H, W, 3), generator=g).to(torch.bfloat16)
+    x0d = x0.to(dev)
+    y1 = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).to(dev)          # conv1_1's output: only its sign pattern matters here
+    bits = torch.empty((N * H * W, 8), dtype=torch.uint8, device=dev)
+    call("danhip_relu_bits", ptr(y1), ptr(bits), N * H * W, 64, stream())
+    w2 = (torch.randn((3, 3, 64, 64), generator=g) / 576 ** 0.5).to(dev)
+    _, wb = ops.pack_conv_weight(d2, w2, need_bwd=True)
+    dy = torch.randn((N, H, W, 64), generator=g).to(torch.bfloat16).to(dev)
+    # the two calls it replaces
+    dx = torch.empty((N, H, W, 64), dtype=torch.bfloat16, device=dev)
+    call("danhip_conv2d_bwd_data_bits", ctypes.byref(d2), ptr(dy), ptr(wb), ptr(bits), ptr(dx), 0, stream())
+    seed_w = torch.randn((3, 3, 3, 64), generator=g).to(dev)
+    seed_b = torch.randn((64,), generator=g).to(dev)
+    dw_ref, db_ref = seed_w.clone(), seed_b.clone()
+    call("danhip_conv2d_bwd_weight", ctypes.byref(d1), ptr(x0d), ptr(dx), ptr(dw_ref), ptr(db_ref), 3, stream())
+    # the folded call
+    dw, db = seed_w.clone(), seed_b.clone()
+    call("danhip_conv2d_bwd_data_bits_first", ctypes.byref(d2), ptr(dy), ptr(wb), ptr(bits), ptr(x0d), 3, ptr(dw), ptr(db), stream())
+    torch.cuda.synchronize()
+    assert (dw_ref - seed_w).abs().max().item() > 0
+    for got, want, what in ((dw, dw_ref, "dW"), (db, db_ref, "db")):
+        err = (got - want).abs().max().item()
+        assert torch.isfinite(got).all() and err <= 1e-4 * want.abs().max().item(), (what, err, want.abs().max().item())
+    # no bias sink: allowed
+    dw2 = seed_w.clone()
+    call("danhip_conv2d_bwd_data_bits_first", ctypes.byref(d2), ptr(dy), ptr(wb), ptr(bits), ptr(x0d), 3, ptr(dw2), None, stream())
+    torch.cuda.synchronize()
+    assert (dw2 - dw_ref).abs().max().item() <= 1e-4 * dw_ref.abs().max().item()
+    d3 = ops._desc(1, 30, 47, 64, 64, 3, 3, 1)      # odd width: no bit-mask form, no folded form
+    assert lib().danhip_conv2d_bwd_data_first_supported(ctypes.byref(d3)) == 0
+
+
+def test_training_step_with_and_without_the_folded_first_layer_gradient(dev):
+    """The S3FD trainer's step with ops.FUSE_FIRST_WGRAD on (default) and off: every variable's gradient agrees (fp32 summation order on
+    conv1_1's kernel and bias, bit-identical elsewhere), the first layer's gradient is non-zero, and with the fold the first layer's own
+    weight-gradient kernel is not launched (ops.PROFILE sees no first-layer weight gradient)."""
+    from dan_amd import ops, synthetic
+    from dan_amd.train_sfd import AnchorConfig, SFDModel, SFDTrainer
+    B, S = 2, 128
+    imgs = synthetic.make_images(B, S, S, dev, seed=3)
+    model = SFDModel(device=dev, seed=5)
+    anchors = AnchorConfig(S, S, dev)
+    loc_t, cls_t, _ = anchors.encode_batch(synthetic.make_gt_boxes(B, S, S, seed=4, max_faces=5))
+    tr = SFDTrainer(model)
+    w0 = tr.flat.w.clone()
+    grads = {}
+    for fuse in (True, False):
+        tr.flat.w.copy_(w0); tr.flat.v.zero_(); tr.step_no = 0
+        ops.WEIGHT_EPOCH += 1
+        ops.repack_all()
+        with ops.use_context(ops.OpsContext(FUSE_FIRST_WGRAD=fuse)):
+            ops.PROFILE = {}
+            tr.train_step(imgs, loc_t, cls_t)
+            prof, ops.PROFILE = ops.PROFILE, None
+        torch.cuda.synchronize()
+        grads[fuse] = tr.flat.g.clone()
+        first_wgrad = [k for k in prof if "wgrad_c8" in k]
+        assert (len(first_wgrad) == 0) == fuse, (fuse, list(prof))
+    names = dict(zip(tr.flat.names, zip(tr.flat.starts, tr.flat.sizes)))
+    first = [n for n in tr.flat.names if "conv1_1" in n]
+    assert len(first) == 2
+    for n, (s0, sz) in names.items():
+        a, b = grads[True][s0:s0 + sz], grads[False][s0:s0 + sz]
+        if n in first:
+            assert b.abs().max().item() > 0
+            assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), n
+        else:
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-20), n      # (fp32 atomics order of the weight gradients)
