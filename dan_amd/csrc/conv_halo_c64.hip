@@ -112,7 +112,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (wave >= 2) return;                         // (uniform per wave)
     int n, y0, x0;
     sp_coords(sp, n, y0, x0);
-    const int t = (wave * 64 + lane) * 2;          // pixels t, t + 1 of the tile (same row: TW is even)
+    int ln = lane;
+    if constexpr (FUSE8) asm volatile("" : "+v"(ln));      // (the folded form has no register left for hoisted per-lane geometry: it was spilled and reloaded per tile)
+    const int t = (wave * 64 + ln) * 2;            // pixels t, t + 1 of the tile (same row: TW is even)
     const int y = y0 + t / TW, x = x0 + t % TW;
     const unsigned off = (y < a.H && x < a.W) ? (unsigned)((n * a.H + y) * a.W + x) * 8u : 0xFFFFFFFFu;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_AS void*)(smem + RWBASE + bbuf * 2048 + wave * 1024), 16, off, 0, 0, 0);
@@ -120,7 +122,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   // FUSE8 LDS map inside the epilogue-input region (bit-mask form only: the 16-bit mask / old-value areas are unused):
   //   [RWBASE, +4096) bit masks (2 buffers) | [+4096, +4096 + 2 * 6144) image patches (2 buffers: 340 pixels x 16 bytes in six 1 KiB DMA pieces)
   //   | [+16384, +16384 + 32768) the dX tile [256 pixels][64 channels] | [+49152, +16) the constant fragment [1, 0, 0, 0 | 0 ...]
-  constexpr int IMGBASE = RWBASE + 4096, IMGBYTES = 6144, DXBASE = RWBASE + 16384, C1BASE = RWBASE + 49152;
+  //   | [+49216, +49216 + 24576) the waves' gradient accumulators between tiles: [wave][M tile][lane] x 16 bytes.  The register file has no
+  //   room for them across the tile's 144 MFMAs (the compiler parked them in scratch and reloaded them, a memory latency per tile, right in
+  //   front of the MFMAs that need them: 615 us per launch against 476 for the plain data gradient); from LDS the reload is issued before
+  //   the tile-written barrier and has landed when the barrier opens.
+  constexpr int IMGBASE = RWBASE + 4096, IMGBYTES = 6144, DXBASE = RWBASE + 16384, C1BASE = RWBASE + 49152, FACCBASE = RWBASE + 49216;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<bf16_t*>(FUSE8 ? a.fuse_x8 : a.x), 0, (int)((unsigned)(a.N * a.H * a.W) * 16u), 0x00020000);
   [[maybe_unused]] auto issue_img = [&](int sp, int ibuf) __attribute__((always_inline)) {
@@ -171,11 +177,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int p = 0; p < NPT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // FUSE8: this wave's slice of conv1_1's gradient (12 tap slots x 4 channels x its 16 output channels), accumulated over all its tiles
-  [[maybe_unused]] f32x4 facc[3];
+  // FUSE8: this wave's slice of conv1_1's gradient (12 tap slots x 4 channels x its 16 output channels), accumulated over all its tiles — in LDS
+  [[maybe_unused]] const int faddr = FACCBASE + (wave * 3 * 64 + lane) * 16;       // + mt * 1024
   if constexpr (FUSE8) {
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt) facc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 3; ++mt) *reinterpret_cast<f32x4*>(smem + faddr + mt * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 16) reinterpret_cast<bf16_t*>(smem + C1BASE)[tid] = tid == 0 ? f2bf(1.0f) : (bf16_t)0;
   }
 
@@ -334,8 +340,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
       if constexpr (FUSE8) {
         // ---- conv1_1's weight + bias gradient of this tile: dW[tap][c][co] += sum over pixels of X8[pixel @ tap][c] * dX[pixel][co]
-        __builtin_amdgcn_s_waitcnt(0xC07F);           // (lgkmcnt(0): this wave's tile writes are in LDS)
-        __builtin_amdgcn_s_barrier();                 // ... and so is everybody else's
+        f32x4 facc[3];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) facc[mt] = *reinterpret_cast<const f32x4*>(smem + faddr + mt * 1024);      // (own slots: no hazard with other waves)
+        __builtin_amdgcn_s_waitcnt(0xC07F);           // (lgkmcnt(0): this wave's tile writes are in LDS, its accumulators in registers)
+        __builtin_amdgcn_s_barrier();                 // ... and so are everybody else's tile writes
         const char* im = smem + IMGBASE + buf * IMGBYTES;
         // lane 4q+p of 16-lane group g supplies pixel 8g + q (+ 4h) of the row: tap slot p of M tile mt (image side), channels 4p..4p+3 of
         // the wave's N tile (dX side) — conv_wgrad_c8.hip's fragment addressing with a 32-pixel row
@@ -366,6 +375,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             facc[mt] = DH_MFMA_16x16x32(xf, yf, facc[mt]);
           }
         }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) *reinterpret_cast<f32x4*>(smem + faddr + mt * 1024) = facc[mt];
       }
       if (!DGRAD && a.pool_y) {
         // fused 2x2 / stride-2 SAME max-pool (pool1, net/sfd_net.py:132): wave rows (2*wm, 2*wm+1); fragments p = 0,1 are the top
@@ -406,6 +417,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   if constexpr (FUSE8) {
     // ---- eight waves -> one gradient in LDS -> global atomics (conv_wgrad_c8.hip).  Lane holds facc[mt][r] = dW[tap slot mt*4 + g][channel r][co]
     // of the wave's N tile: co = 16 (wave & 3) + (lane & 15); waves w and w + 4 own the same tile for different rows
+    f32x4 facc[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) facc[mt] = *reinterpret_cast<const f32x4*>(smem + faddr + mt * 1024);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();                   // every wave is past its last reads of the patch buffers: reuse buffer 0
     float* red = reinterpret_cast<float*>(smem);    // [12 slots][4 channels][64 co]
@@ -448,7 +462,8 @@ bool c64_eligible(const ConvArgs& a) {
 
 template <bool DGRAD, bool FUSE8 = false>
 int launch_c64(const ConvArgs& a, hipStream_t s) {
-  constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024 + (DGRAD ? 65536 : 256);      // patches + (mask, old) tiles | bias
+  constexpr int LDS = 2 * ((10 * 34 + 7) / 8) * 1024 + (FUSE8 ? 75776 : (DGRAD ? 65536 : 256));      // patches + (mask, old) tiles | bias; FUSE8: 160 KiB in all
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static const bool attr_ok =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<DGRAD, FUSE8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) == hipSuccess;
   (void)attr_ok;
