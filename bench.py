@@ -500,13 +500,21 @@ def main():
         # ---- roofline of the dominant kernel (HIP events recorded on the launch stream inside the timed region)
         # A bracket [e0, launch, e1] also times whatever the stream waited for between e0 and the launch: on a host-bound graph (DAN: ~1100
         # launches per step) the queue runs dry and a bracket can hold milliseconds of host time (profiles/r5/size1024_lines.jsonl line 1:
-        # 2.5 ms "average" for a 30 us kernel).  Durations are therefore taken as the MEDIAN over the launches of one (kernel, layer shape)
-        # group times the group's launch count: a handful of inflated brackets no longer decide which kernel is "dominant" (VERDICT r5 6b).
-        def robust_ms(evs):
-            groups = {}
-            for a, b, f in evs:
-                groups.setdefault(f, []).append(a.elapsed_time(b))
-            return sum(sorted(v)[len(v) // 2] * len(v) for v in groups.values())
+        # 2.5 ms "average" for a 30 us kernel).  Durations are therefore taken per LAYER as the MEDIAN over the region's steps (the k-th launch of a kernel
+        # in every step is the same layer) and summed: a handful of inflated brackets no longer decide which kernel is "dominant" (VERDICT r5 6b).
+        def robust_ms(evs, steps=None):
+            # the k-th launch of a kernel in every step is the same layer: median over the steps, summed over the layers (a first version took the
+            # median over all launches with equal FLOPs, which lumps conv2_2 / conv3_2 / conv4_2 — equal FLOPs, different durations — together
+            # and read 10 % above rocprofv3's average)
+            steps = steps or prof_steps
+            per = len(evs) // steps if steps and len(evs) % steps == 0 else 0
+            if not per:
+                return sum(a.elapsed_time(b) for a, b, _ in evs)
+            total = 0.0
+            for j in range(per):
+                v = sorted(evs[j + k * per][0].elapsed_time(evs[j + k * per][1]) for k in range(steps))
+                total += v[len(v) // 2] * steps
+            return total
 
         stats = []
         for label, evs in prof.items():
@@ -544,7 +552,7 @@ def main():
                 calib = {"peak": cpk, "what": "library bf16 GEMM (torch.matmul) measured on this pool in round 1 (profiles/r1/calibration.json)", "frac": round(achieved / cpk, 4)}
         serial = None
         if prof_serial and label in prof_serial:
-            sms = robust_ms(prof_serial[label])
+            sms = robust_ms(prof_serial[label], 2)
             sfl = sum(f for _, _, f in prof_serial[label])
             sach = sfl / (sms * 1e-3) / 1e12
             serial = {"achieved": round(sach, 2), "frac": round(sach / PEAK_BF16_TFLOPS, 4), "avg_launch_ms": round(sms / len(prof_serial[label]), 4),

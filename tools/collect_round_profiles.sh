@@ -8,6 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
+# PMC traffic FIRST: bench.py reports roofline.traffic only from a file stamped with the hash of the sources it runs on
+bash tools/pmc_bench.sh r6 > $OUT/pmc.log 2>&1; mkdir -p profiles/r6; cp gpurun_out/pmc_bench_traffic.json profiles/r6/pmc_bench_traffic.json
+cd $ROOT
 python3 bench.py --steps 20 --warmup 5 > $OUT/s3fd_b16_bench_line.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o s3fd -- python3 bench.py --steps 5 --warmup 2 --repeats 1 --strong-global-batch 0 --strong16-global-batch 0 --no-cpu-baseline --no-serialized-roofline --no-eval > $OUT/s3fd_b16_bench_line_under_rocprof.json 2> $OUT/prof.err
@@ -18,7 +21,6 @@ for job in "conv3_2 fwd" "conv3_2 dgrad_bits" "conv3_2 wgrad" "conv4_2 fwd" "con
   set -- $job
   bash tools/pmc_conv.sh $1 $2 > $OUT/pmc_$1_$2.txt 2>&1
 done
-bash tools/pmc_bench.sh r6 > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc_bench_traffic.json $OUT/ 2>/dev/null
 : > $OUT/models_bench_lines.jsonl
 for m in pb dan dan_deform; do
