@@ -56,6 +56,7 @@ SIGNATURES = {
     "danhip_unsplit3_f32": [P, P, I64, I32, I32, P],
     "danhip_maxpool2x2_split3": [P, P, I32, I32, I32, I32, P],
     "danhip_l2norm_split3": [P, P, P, I64, I32, P],
+    "danhip_conv3x3_c3_f32_split3": [P, P, P, P, I32, I32, I32, I32, ctypes.c_int, P],
     "danhip_l2norm_fwd_f32": [P, P, P, I64, I32, P],
     "danhip_resize_bilinear_add_fwd_f32": [P, P, P, I32, I32, I32, I32, I32, I32, P],
     "danhip_avgpool2x2s1_same_fwd_f32": [P, P, I32, I32, I32, I32, P],

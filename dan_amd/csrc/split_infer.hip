@@ -152,7 +152,96 @@ __global__ void l2norm_split3_kernel(const _Float16* __restrict__ x3, const floa
   }
 }
 
+// The FIRST layer of the split-operand path (conv1_1: 3x3 / stride 1 / 'same', 3 input channels) computed directly in fp32 and stored in the
+// next convolution's limb layout.  As limbs its operand has 9 channels padded to 16 (K = 144), which only the flat-M kernel's gather form takes:
+// 1.15 ms per batch of 16 images at 640 x 640 plus 0.2 ms to split the image - for 0.7 GMAC per image.  With K = 27 the exact fp32 FMA chain
+// costs less than the limb products' operand handling: a thread owns 4 horizontally adjacent pixels x 8 output channels (32 accumulators), the
+// 3 x 6 x 3 input values it needs sit in registers, the 27 x Co weights in LDS (a lane's 8 channels = two ds_read_b128 per tap and channel);
+// eight lanes write one pixel's 128-byte limb sections.  Bound by its 6 bytes per output element of stores.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_c3_f32_split3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                    _Float16* __restrict__ y3, int N, int H, int W, int relu) {
+  constexpr int CG = CO / 8;                       // channel groups (lanes per pixel quad)
+  __shared__ float ws[27 * CO];
+  __shared__ float bs[CO];
+  for (int i = threadIdx.x; i < 27 * CO; i += 256) ws[i] = w[i];          // HWIO: [(tap * 3 + c) * CO + co]
+  for (int i = threadIdx.x; i < CO; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int W4 = (W + 3) >> 2;
+  const long quads = (long)N * H * W4;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = id / CG;
+  const int cg = (int)(id - q * CG);
+  if (q >= quads) return;
+  const int x4 = (int)(q % W4) * 4;
+  long r = q / W4;
+  const int yy = (int)(r % H);
+  const int n = (int)(r / H);
+  float in[3][6][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int sy = yy - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int sx = x4 - 1 + j;
+      const bool ok = (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+      const float* p = x + ((long)(n * H + (ok ? sy : 0)) * W + (ok ? sx : 0)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) in[i][j][c] = ok ? p[c] : 0.f;
+    }
+  }
+  float acc[4][8];
+#pragma unroll
+  for (int px = 0; px < 4; ++px)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[px][o] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float4 wa = *reinterpret_cast<const float4*>(&ws[((i * 3 + j) * 3 + c) * CO + cg * 8]);
+        const float4 wb = *reinterpret_cast<const float4*>(&ws[((i * 3 + j) * 3 + c) * CO + cg * 8 + 4]);
+        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc[px][o] = fmaf(in[i][px + j][c], wv[o], acc[px][o]);      // k order (tap, channel): conv_f32_kernel's
+      }
+  typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    if (x4 + px >= W) break;
+    h8 hi, lo;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float v = acc[px][o] + bs[cg * 8 + o];
+      if (relu) v = fmaxf(v, 0.f);
+      _Float16 a, b;
+      split_one(v, a, b);
+      hi[o] = a; lo[o] = b;
+    }
+    _Float16* row = y3 + ((long)(n * H + yy) * W + x4 + px) * (3 * CO) + cg * 8;
+    *reinterpret_cast<h8*>(row) = hi;
+    *reinterpret_cast<h8*>(row + CO) = lo;
+    *reinterpret_cast<h8*>(row + 2 * CO) = hi;
+  }
+}
+
 }  // namespace
+
+extern "C" int danhip_conv3x3_c3_f32_split3(const float* x, const float* w_hwio, const float* bias, uint16_t* y3, int32_t N, int32_t H, int32_t W,
+                                            int32_t Cout, int relu, void* stream) {
+  DH_REQUIRE(x && w_hwio && y3 && N > 0 && H > 0 && W > 0, DANHIP_EINVAL, "danhip_conv3x3_c3_f32_split3: bad arguments");
+  DH_REQUIRE(Cout == 64, DANHIP_EINVAL, "danhip_conv3x3_c3_f32_split3: Cout = %d (the first layer of the VGG backbones: 64)", Cout);
+  DH_REQUIRE((int64_t)N * H * W * 3 * Cout < (1ll << 40), DANHIP_EINVAL, "danhip_conv3x3_c3_f32_split3: too large");
+  const long threads = (long)N * H * ((W + 3) / 4) * (Cout / 8);
+  hipLaunchKernelGGL(conv3x3_c3_f32_split3_kernel<64>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w_hwio, bias,
+                     reinterpret_cast<_Float16*>(y3), N, H, W, relu);
+  DH_LAUNCH_CHECK();
+  return DANHIP_OK;
+}
 
 extern "C" int danhip_l2norm_split3(const uint16_t* x3, const float* gamma, uint16_t* y3, int64_t M, int32_t C, void* stream) {
   DH_REQUIRE(x3 && gamma && y3 && M > 0 && C > 0 && C % 8 == 0, DANHIP_EINVAL, "danhip_l2norm_split3: bad arguments (C %% 8 == 0)");

@@ -730,6 +730,13 @@ def _conv2d_split(x, w, b, stride, relu, residual, padding, want_f32=False):
     N, H, W, C = x.shape
     kh, kw, cin, cout = w.shape
     assert cin == C, "split conv: input channels must match the kernel"
+    if (C == 3 and cout == 64 and kh == 3 and kw == 3 and stride == 1 and padding == "same" and residual is None and not want_f32
+            and not _is_limbs(x) and x.dtype == torch.float32):
+        # the first layer: 27 products per output - an exact fp32 FMA chain written straight in the limb layout (split_infer.hip)
+        y3 = torch.empty((N, H, W, 3 * cout), dtype=torch.float16, device=x.device)
+        call("danhip_conv3x3_c3_f32_split3", ptr(x.contiguous()), ptr(w.detach().float().contiguous()), ptr(b.detach().float()) if b is not None else None,
+             ptr(y3), N, H, W, cout, int(relu), stream())
+        return _limb_view(y3, cout)
     # tensors of the 16-bit kernels are addressed with 32-bit element offsets: 3C input channels (the deformable GEMM's 27 x 256 at 160 x 160)
     # or 3 Cout output limbs can exceed 2^31 elements at batch 16 — such a call runs in batch slices
     C3 = (3 * C + 7) // 8 * 8

@@ -560,6 +560,10 @@ int danhip_unsplit3_f32(const uint16_t* x3, float* y, int64_t M, int32_t C, int3
 int danhip_maxpool2x2_split3(const uint16_t* x3, uint16_t* y3, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 /* l2_normalize (net/sfd_net.py:68-79) on the limb layout -> limb layout; the arithmetic of unsplit -> danhip_l2norm_fwd_f32 -> split in one pass */
 int danhip_l2norm_split3(const uint16_t* x3, const float* gamma, uint16_t* y3, int64_t M, int32_t C, void* stream);
+/* The first layer of the split-operand path (conv1_1: 3x3 / stride 1 / 'same', x fp32 [N,H,W,3], w HWIO fp32 [3,3,3,64]) as an exact fp32 FMA chain,
+ * stored straight in the next convolution's limb layout y3 [N,H,W,192]; bias may be NULL. */
+int danhip_conv3x3_c3_f32_split3(const float* x, const float* w_hwio, const float* bias, uint16_t* y3, int32_t N, int32_t H, int32_t W, int32_t Cout,
+                                 int relu, void* stream);
 
 /* ---- fp32 inference path (csrc/f32_infer.hip): the evaluation graphs of eval_sfd.py:232-283 / eval_pb.py / eval_dan.py:299-404 with fp32
  * storage and arithmetic end to end, for the north-star tolerance "eval box outputs within 1e-4 of the reference".  NHWC fp32

@@ -25,6 +25,17 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def _load(out):
+    """The worker's result; the file (a copy or two of a model's parameters) is deleted at once: 21 tests x several children otherwise leave
+    gigabytes in pytest's temporary directories until the session ends (a third back-to-back run of this file filled a box's /tmp)."""
+    d = torch.load(out)
+    try:
+        os.remove(out)
+    except OSError:
+        pass
+    return d
+
+
 def _child(cmd, env, what):
     """One child, once: a crashed child fails the test (head AND tail of its stderr: `terminate called ...` is at the head)."""
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -39,7 +50,7 @@ def _run(world, out, **extra):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), WORKER, out]
     _child(cmd, env, "world %d" % world)
-    return torch.load(out)
+    return _load(out)
 
 
 from tests_ddp_paths import FAKE_RCCL          # tests/ddp/libfake_rccl.so (built on demand)
@@ -55,7 +66,7 @@ def _run_fake_rccl(world, out, **extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), WORKER, out]
     _child(cmd, env, "fake-rccl world %d" % world)
-    return torch.load(out)
+    return _load(out)
 
 
 def _forced_rccl_env(**extra):
@@ -88,7 +99,7 @@ def test_rccl_code_path_with_a_one_rank_group(comm, wire, tol, dev, tmp_path):
     env = _forced_rccl_env(DANHIP_DP_COMM=comm, DANHIP_DP_BUCKET_DTYPE=wire)
     out = str(tmp_path / "rccl1.pt")
     _child([sys.executable, WORKER, out], env, "forced one-rank RCCL communicator")
-    a = torch.load(out)
+    a = _load(out)
     one = _run(1, str(tmp_path / "plain.pt"))
     scale = one["w"].abs().max().item()
     assert (a["w"] - one["w"]).abs().max().item() <= tol * scale
@@ -213,7 +224,7 @@ def test_data_parallel_step_replayed_as_one_hipgraph(dev, tmp_path):
     for mode in ("dp", "graph"):
         out = str(tmp_path / (mode + ".pt"))
         _child([sys.executable, WORKER, out], _forced_rccl_env(DDP_MODE=mode), mode)
-        outs[mode] = torch.load(out)
+        outs[mode] = _load(out)
     a, b = outs["dp"], outs["graph"]
     assert a["step"] == b["step"] == 3 and b["buckets"] >= 2
     scale = a["w"].abs().max().item()
