@@ -296,3 +296,24 @@ def test_bench_line_of_a_two_rank_run_on_one_gpu(dev):
     assert s16["global_batch"] == 16 and s16["n_gpus"] == 2 and s16["batch_per_gpu"] == 8 and s16["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
     assert d["config"]["dp_transport"] == "gloo" and d["config"]["rccl_ranks"] == 1
+
+
+def test_bench_line_of_a_two_rank_run_on_the_rccl_transport(dev):
+    """The line the driver asks for at N > 1, on the transport it will use: `python bench.py --gpus 2` with the data plane on the library's own
+    danhip_comm_* calls (bound to the shared-memory stand-in, so that two ranks fit on this one GPU): unique-id broadcast, ncclCommInitRank(2)
+    under its deadline, bucketed all-reduce overlapped with backward, CommWatch ticking every step, the weak `value`, both strong legs
+    (`strong`: global batch 8 as towers; `strong16`: 16 / 2 = 8 images per rank) and the orderly shutdown (communicator before process group)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DANHIP_DP_TRANSPORT")}
+    env.update(DANHIP_RCCL_PATH=FAKE_RCCL, DANHIP_DP_NO_FALLBACK="1", DANHIP_BENCH_RCCL_LOG="0", DANHIP_COMM_TIMEOUT_S="240", FAKE_RCCL_TIMEOUT_S="200")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "2", "--size", "128",
+           "--strong-global-batch", "8", "--repeats", "2", "--eager", "--no-cpu-baseline", "--no-eval"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[:3000], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["config"]["rccl_ranks"] == 2 and "rccl 29999" in d["config"]["dp_transport"], d["config"]
+    assert d["strong"]["n_gpus"] == 2 and d["strong"]["value"] > 0 and d["strong16"]["batch_per_gpu"] == 8 and d["strong16"]["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] > 0
