@@ -333,8 +333,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __builtin_nontemporal_store(tt, reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + o0));   // streamed: re-read only after it left the L2
           pk[p] = tt;
         }
-        if constexpr (FUSE8)                         // the tile of dX the store would have written (zeros outside the image), [pixel][64 channels]
-          *reinterpret_cast<u32x4*>(smem + DXBASE + t * 128 + cbase * 2) = pk[p];
+        if constexpr (FUSE8) {                       // the tile of dX the store would have written (zeros outside the image), [pixel][64 channels];
+          // 16-byte chunk c of pixel t sits at position c ^ ((t & 7) ^ ((t >> 3) & 1) << 2): with the plain layout every pixel starts on bank 0
+          // (128-byte pitch) - the eight lanes of a ds_write_b128 group conflicted 8 ways and the transposing reads 4 ways; swizzled, neither does
+          const int fz = (t & 7) ^ (((t >> 3) & 1) << 2);
+          *reinterpret_cast<u32x4*>(smem + DXBASE + t * 128 + (((cbase >> 3) ^ fz) << 4)) = pk[p];
+        }
 #pragma unroll
         for (int c = 0; c < NCT; ++c) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -352,11 +356,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         asm volatile("" : "+v"(ln));                  // (as above: nothing of this block may be hoisted into long-lived registers)
         const int gg = ln >> 4, qq = (ln & 15) >> 2, pp = ln & 3;
         const int nt = wave & 3, r0 = (wave >> 2) * 4;
-        const int ybase = DXBASE + (8 * gg + qq) * 128 + pp * 8 + nt * 32;
+        const int ypix = 8 * gg + qq;                 // + row * 32 + 4 h: the pixel of the tile this lane supplies; its chunk 2 nt + (pp >> 1), swizzled as written
+        // all 32 transposing reads first (64 registers: the main loop's pixel fragments and accumulators are dead here), then the 12 MFMAs
+        // behind counted waits — row by row the section paid four LDS latencies per tile
+        s16x4 xh[4][2][3], yh[4][2];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = r0 + rr;
-          s16x4 xh[2][3], yh[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -364,14 +370,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
               const int tap = mt * 4 + pp;
               const int ti = tap / 3, tj = tap - ti * 3;
               const char* ad = tap < 9 ? im + ((row + ti) * PW + 8 * gg + qq + tj + 4 * h) * 16 : smem + C1BASE + (tap == 9 ? 0 : 8);
-              xh[h][mt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)ad);
+              xh[rr][h][mt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)ad);
             }
-            yh[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + ybase + (row * 32 + 4 * h) * 128));
+            const int pix = row * 32 + ypix + 4 * h;
+            const int fz = (pix & 7) ^ (((pix >> 3) & 1) << 2);
+            yh[rr][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(smem + DXBASE + pix * 128 + (((2 * nt + (pp >> 1)) ^ fz) << 4) + (pp & 1) * 8));
           }
-          const bf16x8 yf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(yh[0], yh[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bf16x8 yf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(yh[rr][0], yh[rr][1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
           for (int mt = 0; mt < 3; ++mt) {
-            const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xh[0][mt], xh[1][mt], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xh[rr][0][mt], xh[rr][1][mt], 0, 1, 2, 3, 4, 5, 6, 7));
             facc[mt] = DH_MFMA_16x16x32(xf, yf, facc[mt]);
           }
         }
