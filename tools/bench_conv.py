@@ -92,6 +92,16 @@ def run(shape, iters, which, check):
     def dgrad_acc():
         call("danhip_conv2d_bwd_data", ctypes.byref(d), ptr(dy), ptr(wb), ptr(x), ptr(dx), 1, stream())
 
+    # conv1_2's data gradient with conv1_1's weight / bias gradient folded in (64 -> 64 only): dX never stored
+    img8 = torch.zeros((N, H, W, 8), dtype=torch.bfloat16)
+    img8[..., :3] = torch.randn((N, H, W, 3), generator=g).to(torch.bfloat16)
+    img8 = img8.to(dev)
+    dw8 = torch.zeros((3, 3, 3, 64), dtype=torch.float32, device=dev)
+    db8 = torch.zeros((64,), dtype=torch.float32, device=dev)
+
+    def dgrad_first():
+        call("danhip_conv2d_bwd_data_bits_first", ctypes.byref(d), ptr(dy), ptr(wb), ptr(bits), ptr(img8), 3, ptr(dw8), ptr(db8), stream())
+
     nws = lib().danhip_conv2d_bwd_weight_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
 
@@ -99,7 +109,7 @@ def run(shape, iters, which, check):
         call("danhip_conv2d_bwd_weight_ws", ctypes.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(db), cin_real, ptr(ws) if nws else None, nws, stream())
 
     fns = {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad, "dgrad_nomask": dgrad_nomask, "dgrad_acc": dgrad_acc, "dgrad_bits": dgrad_bits,
-           "relu_bits": relu_bits}
+           "relu_bits": relu_bits, "dgrad_first": dgrad_first}
     out = []
     for wname in which:
         fn = fns[wname]
